@@ -1,0 +1,403 @@
+"""ORACLE — CPU restatement of the Prior-DiffuSE sampling path.  TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import this file.  It is the *checker* of the HIP path, never the thing
+measured or shipped; the product package ``prior-diffuse_amd`` does not import it
+and fails loudly when ``libpdse.so`` is missing.
+
+What it is: a plain PyTorch-CPU fp32 functional restatement (no ``nn.Module``)
+of every reference function on the path, keyed on the reference's own
+``state_dict`` names, each function citing the reference file:line it follows.
+
+Pinning: ``oracle/make_golden.py`` imports the reference's real modules from
+``/root/reference`` (this container only), loads the same seeded weights and
+records their outputs under ``tests/golden/``; ``tests/test_oracle_golden.py``
+checks this restatement against those vectors.  The ~80 harness lines of
+``generate_wav`` that cannot execute under torch 2.10 (legacy ``torch.stft``
+signature, unconditional ``.cuda()``, librosa/soundfile) are restated from the
+source text and pinned by an independent float64 DFT in the tests.
+
+Parity mode: both networks in eval mode (BatchNorm uses running statistics),
+as in the reference's validation loop (trainer/complex_ddpm_trainer.py:400-401).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-5
+C_SCALE = 11.0  # reference: trainer/complex_ddpm_trainer.py:30
+
+
+# --------------------------------------------------------------------------
+# small helpers
+# --------------------------------------------------------------------------
+def _bn(sd, p, x):
+    """Eval-mode BatchNorm{1,2}d (running stats, eps 1e-5)."""
+    return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"],
+                        sd[p + ".weight"], sd[p + ".bias"], False, 0.0, BN_EPS)
+
+
+def _prelu(sd, p, x):
+    return F.prelu(x, sd[p + ".weight"])
+
+
+# --------------------------------------------------------------------------
+# A1  schedule  (reference: trainer/complex_ddpm_trainer.py:105-156)
+# --------------------------------------------------------------------------
+def inference_schedule(noise_schedule, inference_noise_schedule, fast_sampling):
+    training = np.array(noise_schedule)
+    inference = np.array(inference_noise_schedule) if fast_sampling else training
+    talpha_cum = np.cumprod(1 - training)
+    beta = inference
+    alpha = 1 - beta
+    alpha_cum = np.cumprod(alpha)
+    sigmas = [0 for _ in alpha]
+    for n in range(len(alpha) - 1, -1, -1):
+        sigmas[n] = ((1.0 - alpha_cum[n - 1]) / (1.0 - alpha_cum[n]) * beta[n]) ** 0.5
+    T = []
+    for s in range(len(inference)):
+        for t in range(len(training) - 1):
+            if talpha_cum[t + 1] <= alpha_cum[s] <= talpha_cum[t]:
+                tw = (talpha_cum[t] ** 0.5 - alpha_cum[s] ** 0.5) / (
+                    talpha_cum[t] ** 0.5 - talpha_cum[t + 1] ** 0.5)
+                T.append(t + tw)
+                break
+    return alpha, beta, alpha_cum, sigmas, np.array(T, dtype=np.float32)
+
+
+# --------------------------------------------------------------------------
+# A2  front-end: RMS normalise, STFT, sqrt-compression
+#     (reference: trainer/complex_ddpm_trainer.py:921-937; batched twin
+#      utils/dataset.py:45-74)
+# --------------------------------------------------------------------------
+def rms_scale(wav):
+    """c = sqrt(sum(x^2)/L) per utterance (reference :922)."""
+    return torch.sqrt(torch.sum(wav * wav, dim=-1) / wav.shape[-1])
+
+
+def stft_ri(wav):
+    """[B,L] -> [B,2,T,F]: torch.stft(n_fft=320, hop=160, win=320, periodic hann,
+    center=True, reflect) viewed as real, permuted like the reference
+    (:926-930 ``.permute(2,1,0)`` on the legacy [F,T,2] layout)."""
+    spec = torch.stft(wav, n_fft=320, hop_length=160, win_length=320,
+                      window=torch.hann_window(320), center=True, pad_mode="reflect",
+                      normalized=False, onesided=True, return_complex=True)  # [B,F,T]
+    ri = torch.view_as_real(spec)  # [B,F,T,2]
+    return ri.permute(0, 3, 2, 1).contiguous()
+
+
+def compress_sqrt(ri):
+    """phase = atan2(im, re); mag = |X|**0.5; [mag cos, mag sin] (reference :931-937)."""
+    phase = torch.atan2(ri[:, -1], ri[:, 0])
+    mag = torch.norm(ri, dim=1) ** 0.5
+    return torch.stack((mag * torch.cos(phase), mag * torch.sin(phase)), dim=1)
+
+
+# --------------------------------------------------------------------------
+# A7  back-end: square-decompression, ISTFT
+#     (reference: trainer/complex_ddpm_trainer.py:1004-1016; batched twin
+#      utils/metrics.py:528-566)
+# --------------------------------------------------------------------------
+def decompress_square(x):
+    mag, phase = torch.norm(x, dim=1), torch.atan2(x[:, -1], x[:, 0])
+    mag = mag ** 2
+    return torch.stack((mag * torch.cos(phase), mag * torch.sin(phase)), dim=1)
+
+
+def istft_ri(ri, length):
+    """[B,2,T,F] -> [B,length] (reference :1009-1015)."""
+    spec = torch.complex(ri[:, 0], ri[:, 1]).permute(0, 2, 1)  # [B,F,T]
+    return torch.istft(spec, n_fft=320, hop_length=160, win_length=320,
+                       window=torch.hann_window(320), length=length)
+
+
+# --------------------------------------------------------------------------
+# A6  ε-network DiffUNet1  (reference: model/diff3.py)
+# --------------------------------------------------------------------------
+def build_time_table(max_steps=50):
+    """reference: model/diff3.py:89-95 (fp32 torch arithmetic, sin‖cos)."""
+    steps = torch.arange(max_steps).unsqueeze(1)
+    dims = torch.arange(64).unsqueeze(0)
+    table = steps * 10.0 ** (dims * 4.0 / 63.0)
+    return torch.cat([torch.sin(table), torch.cos(table)], dim=1)
+
+
+def time_embedding(sd, t, table):
+    """reference: model/diff3.py:68-87 — int t indexes, float t lerps."""
+    if t.dtype in (torch.int32, torch.int64):
+        x = table[t]
+    else:
+        low_idx = torch.floor(t).long()
+        high_idx = torch.ceil(t).long()
+        low, high = table[low_idx], table[high_idx]
+        x = low + (high - low) * (t - low_idx).unsqueeze(1)
+    x = F.linear(x, sd["time_embedding.projection1.weight"], sd["time_embedding.projection1.bias"])
+    x = x * torch.sigmoid(x)
+    x = F.linear(x, sd["time_embedding.projection2.weight"], sd["time_embedding.projection2.bias"])
+    return x * torch.sigmoid(x)
+
+
+def biconvglu(sd, p, x):
+    """reference: model/diff3.py:307-326 (stride (1,2))."""
+    x = F.conv2d(x, sd[p + ".conv1.weight"], sd[p + ".conv1.bias"])
+    left = F.conv2d(x, sd[p + ".l.weight"], sd[p + ".l.bias"], stride=(1, 2))
+    right = F.conv2d(x, sd[p + ".r.weight"], sd[p + ".r.bias"], stride=(1, 2))
+    left_mask = torch.sigmoid(F.conv2d(left, sd[p + ".l_conv.weight"], sd[p + ".l_conv.bias"]))
+    right_mask = torch.sigmoid(F.conv2d(right, sd[p + ".r_conv.weight"], sd[p + ".r_conv.bias"]))
+    left, right = left * right_mask, right * left_mask
+    return F.conv2d(left + right, sd[p + ".conv2.weight"], sd[p + ".conv2.bias"])
+
+
+def biconvtransglu(sd, p, x, temb):
+    """reference: model/diff3.py:329-351 (stride (1,2)); temb None = prior DiffUNet."""
+    if temb is not None:
+        tp = F.linear(temb, sd[p + ".tp.weight"], sd[p + ".tp.bias"])
+        x = x + tp.unsqueeze(-1).unsqueeze(-1)
+    x = F.conv_transpose2d(x, sd[p + ".conv1.weight"], sd[p + ".conv1.bias"])
+    left = F.conv_transpose2d(x, sd[p + ".l.weight"], sd[p + ".l.bias"], stride=(1, 2))
+    right = F.conv_transpose2d(x, sd[p + ".r.weight"], sd[p + ".r.bias"], stride=(1, 2))
+    left_mask = torch.sigmoid(F.conv_transpose2d(left, sd[p + ".l_conv.weight"], sd[p + ".l_conv.bias"]))
+    right_mask = torch.sigmoid(F.conv_transpose2d(right, sd[p + ".r_conv.weight"], sd[p + ".r_conv.bias"]))
+    left, right = left * right_mask, right * left_mask
+    return F.conv_transpose2d(left + right, sd[p + ".conv2.weight"], sd[p + ".conv2.bias"])
+
+
+def unet_encoder(sd, x, temb):
+    """reference: model/diff3.py:144-166 — pad one frame on top, add the time
+    bias to the *padded* tensor (so the pad row equals the bias), BiConvGLU, BN, PReLU."""
+    en_list = []
+    for k in range(1, 6):
+        x = F.pad(x, (0, 0, 1, 0))
+        if temb is not None:
+            tp = F.linear(temb, sd["en.tp%d.weight" % k], sd["en.tp%d.bias" % k])
+            x = x + tp.unsqueeze(-1).unsqueeze(-1)
+        x = biconvglu(sd, "en.conv%d" % k, x)
+        x = _prelu(sd, "en.en%d.1" % k, _bn(sd, "en.en%d.0" % k, x))
+        en_list.append(x)
+    return x, en_list
+
+
+def tcm_residual(sd, p, x, dilation):
+    """reference: model/diff3.py:215-257."""
+    t = x
+    x = F.conv1d(x, sd[p + ".conv1.weight"], sd[p + ".conv1.bias"])
+
+    def branch(b):
+        y = _bn(sd, p + "." + b + ".1", _prelu(sd, p + "." + b + ".0", x))
+        return F.conv1d(y, sd[p + "." + b + ".2.weight"], sd[p + "." + b + ".2.bias"],
+                        padding=2 * dilation, dilation=dilation)
+
+    x = branch("mainbranch") * torch.sigmoid(branch("maskbranch"))
+    x = _bn(sd, p + ".conv2.1", _prelu(sd, p + ".conv2.0", x))
+    x = F.conv1d(x, sd[p + ".conv2.2.weight"], sd[p + ".conv2.2.bias"])
+    return x + t
+
+
+def tcms(sd, x):
+    """reference: model/diff3.py:260-277 — 3 × residual(d = 1,2,4,8,16,32)."""
+    for i in range(3):
+        for j, d in enumerate((1, 2, 4, 8, 16, 32)):
+            x = tcm_residual(sd, "TCMs.%d.residual%d" % (i, j + 1), x, d)
+    return x
+
+
+def unet_decoder(sd, de, x, en_list, temb):
+    """reference: model/diff3.py:205-212 + Chomp_T (:298-304), BN, PReLU."""
+    for k in (5, 4, 3, 2, 1):
+        x = torch.cat((x, en_list[k - 1]), dim=1)
+        x = biconvtransglu(sd, "%s.de%d.0" % (de, k), x, temb)
+        x = x[:, :, :-1, :]
+        if k > 1:
+            x = _prelu(sd, "%s.de%d.3" % (de, k), _bn(sd, "%s.de%d.2" % (de, k), x))
+    return x
+
+
+def _unet_trunk(sd, x, temb, taps=None):
+    x, en_list = unet_encoder(sd, x, temb)
+    b, _, t, _ = x.shape
+    x = x.permute(0, 2, 1, 3).reshape(b, t, -1).permute(0, 2, 1)  # [B, c*4+f, T]
+    x = tcms(sd, x).permute(0, 2, 1)
+    x = x.reshape(b, t, 64, 4).permute(0, 2, 1, 3)
+    if taps is not None:
+        taps["en_list"] = en_list
+        taps["tcm_out"] = x
+    x_real = unet_decoder(sd, "de_real", x, en_list, temb)
+    x_imag = unet_decoder(sd, "de_imag", x, en_list, temb)
+    return torch.cat((x_real, x_imag), dim=1)
+
+
+def diffunet1_forward(sd, x, x_init, t, table=None, taps=None):
+    """reference: model/diff3.py:37-57."""
+    if table is None:
+        table = build_time_table(50)
+    x = F.conv2d(torch.cat((x, x_init), dim=1), sd["preprocess.conv.weight"], sd["preprocess.conv.bias"])
+    temb = time_embedding(sd, t, table)
+    if taps is not None:
+        taps["pre"] = x
+        taps["temb"] = temb
+    return _unet_trunk(sd, x, temb, taps)
+
+
+def diffunet_forward(sd, x):
+    """Prior DiffUNet (reference: model/diff.py:23-33): same trunk, no time input."""
+    return _unet_trunk(sd, x, None)
+
+
+# --------------------------------------------------------------------------
+# A3  prior GCRN  (reference: model/gcrn.py)
+# --------------------------------------------------------------------------
+def lstm_layer(x, w_ih, w_hh, b_ih, b_hh):
+    """Single-layer batch_first nn.LSTM restated as an explicit loop
+    (gate order i,f,g,o; zero initial state)."""
+    b, t, _ = x.shape
+    hdim = w_hh.shape[1]
+    h = x.new_zeros(b, hdim)
+    c = x.new_zeros(b, hdim)
+    gx = F.linear(x, w_ih, b_ih)  # [B,T,4H]
+    out = []
+    for s in range(t):
+        g = gx[:, s] + F.linear(h, w_hh, b_hh)
+        i, f, gg, o = g.chunk(4, dim=1)
+        c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
+        h = torch.sigmoid(o) * torch.tanh(c)
+        out.append(h)
+    return torch.stack(out, dim=1)
+
+
+def glstm(sd, x):
+    """reference: model/gcrn.py:22-40 — layer 1 outputs are *interleaved*
+    (stack dim=-1 + flatten), layer 2 outputs are concatenated."""
+    out = x.transpose(1, 2).contiguous()
+    out = out.view(out.size(0), out.size(1), -1)
+
+    def run(layer, g, inp):
+        p = "glstm.%s.%d." % (layer, g)
+        return lstm_layer(inp, sd[p + "weight_ih_l0"], sd[p + "weight_hh_l0"],
+                          sd[p + "bias_ih_l0"], sd[p + "bias_hh_l0"])
+
+    ch = torch.chunk(out, 2, dim=-1)
+    out = torch.stack([run("lstm_list1", g, ch[g]) for g in range(2)], dim=-1)
+    out = torch.flatten(out, start_dim=-2, end_dim=-1)
+    out = F.layer_norm(out, (1024,), sd["glstm.ln1.weight"], sd["glstm.ln1.bias"], 1e-5)
+    ch = torch.chunk(out, 2, dim=-1)
+    out = torch.cat([run("lstm_list2", g, ch[g]) for g in range(2)], dim=-1)
+    out = F.layer_norm(out, (1024,), sd["glstm.ln2.weight"], sd["glstm.ln2.bias"], 1e-5)
+    out = out.view(out.size(0), out.size(1), x.size(1), -1)
+    return out.transpose(1, 2).contiguous()
+
+
+def _glu_conv(sd, p, x):
+    """reference: model/gcrn.py:43-61 (kernel (1,3), stride (1,2))."""
+    a = F.conv2d(x, sd[p + ".conv1.weight"], sd[p + ".conv1.bias"], stride=(1, 2))
+    g = torch.sigmoid(F.conv2d(x, sd[p + ".conv2.weight"], sd[p + ".conv2.bias"], stride=(1, 2)))
+    return a * g
+
+
+def _glu_convT(sd, p, x, output_padding=(0, 0)):
+    """reference: model/gcrn.py:64-84."""
+    a = F.conv_transpose2d(x, sd[p + ".conv1.weight"], sd[p + ".conv1.bias"], stride=(1, 2),
+                           output_padding=output_padding)
+    g = torch.sigmoid(F.conv_transpose2d(x, sd[p + ".conv2.weight"], sd[p + ".conv2.bias"],
+                                         stride=(1, 2), output_padding=output_padding))
+    return a * g
+
+
+def gcrn_forward(sd, x, taps=None):
+    """reference: model/gcrn.py:136-166.  ELU is re-applied to the skip tensors
+    inside every ``elu(cat(...))`` exactly as the reference does."""
+    e = []
+    out = x
+    for k in range(1, 6):
+        out = F.elu(_bn(sd, "bn%d" % k, _glu_conv(sd, "conv%d" % k, out)))
+        e.append(out)
+    e1, e2, e3, e4, e5 = e
+    out = glstm(sd, e5)
+    if taps is not None:
+        taps["e5"] = e5
+        taps["glstm"] = out
+    out = torch.cat((out, e5), dim=1)
+    res = []
+    for br in (1, 2):
+        d = out
+        for k, skip in ((5, e4), (4, e3), (3, e2), (2, e1)):
+            op = (0, 1) if k == 2 else (0, 0)
+            d = _bn(sd, "bn%d_t_%d" % (k, br), _glu_convT(sd, "conv%d_t_%d" % (k, br), d, op))
+            d = F.elu(torch.cat((d, skip), dim=1))
+        d = F.elu(_bn(sd, "bn1_t_%d" % br, _glu_convT(sd, "conv1_t_%d" % br, d)))
+        res.append(F.linear(d, sd["fc%d.weight" % br], sd["fc%d.bias" % br]))
+    return torch.cat(res, dim=1)
+
+
+PRIORS = {"GCRN": gcrn_forward, "DiffUNet": diffunet_forward}
+
+
+# --------------------------------------------------------------------------
+# A4 + A5  x_T scaling and the reverse loop
+#     (reference: trainer/complex_ddpm_trainer.py:939-998; batched twin :441-494)
+# --------------------------------------------------------------------------
+def sigma_mask(init):
+    """reference :951-956 — per-(b,ch) |init|/max/2 + 0.5."""
+    tmp = torch.flatten(torch.abs(init), start_dim=2)
+    tmp = tmp / torch.max(tmp, dim=2, keepdim=True).values
+    tmp = tmp / 2 + 0.5
+    return tmp.view(init.shape)
+
+
+def reverse_loop(ddpm_sd, init_scaled, x_T, alpha, beta, alpha_cum, sigmas, T, table=None,
+                 use_sigma=False, trace=None):
+    """Runs n = S-1 … 0 on ``audio = x_T`` with ``init_scaled = X_init / 11``.
+
+    The n>0 noise term is kept for fidelity: ``newsigma = max(0, σ - c1σ)`` is
+    identically 0 (reference :986-992), so no RNG draw changes the result.
+    """
+    if table is None:
+        table = build_time_table(50)
+    audio = x_T.clone()
+    if use_sigma:
+        mask = sigma_mask(init_scaled)
+        audio = audio * (mask ** 0.5)
+    N = audio.shape[0]
+    gamma = [sigmas[n] for n in range(len(alpha))]
+    gamma[0] = 0.2
+    for n in range(len(alpha) - 1, -1, -1):
+        c1 = 1 / alpha[n] ** 0.5
+        c2 = beta[n] / (1 - alpha_cum[n]) ** 0.5
+        eps = diffunet1_forward(ddpm_sd, audio, init_scaled, torch.tensor([T[n]]).repeat(N), table)
+        audio = float(c1) * (audio - float(c2) * eps)
+        if n > 0:
+            newsigma = max(0, gamma[n] - c1 * gamma[n])
+            assert newsigma == 0
+        if trace is not None:
+            trace.append(audio.clone())
+    return audio
+
+
+def sample(prior_name, prior_sd, ddpm_sd, feat, x_T, noise_schedule, inference_noise_schedule,
+           fast_sampling=True, use_sigma=False, trace=None):
+    """feat [B,2,T,F] (compressed spectrogram) -> enhanced compressed spectrogram.
+
+    reference: trainer/complex_ddpm_trainer.py:941-998.
+    """
+    alpha, beta, alpha_cum, sigmas, T = inference_schedule(noise_schedule, inference_noise_schedule,
+                                                           fast_sampling)
+    init = PRIORS[prior_name](prior_sd, feat)
+    init = init / C_SCALE
+    audio = reverse_loop(ddpm_sd, init, x_T, alpha, beta, alpha_cum, sigmas, T, use_sigma=use_sigma,
+                         trace=trace)
+    audio = audio + init
+    audio = audio * C_SCALE
+    return audio, init * C_SCALE
+
+
+def enhance(prior_name, prior_sd, ddpm_sd, wav, x_T, noise_schedule, inference_noise_schedule,
+            fast_sampling=True, use_sigma=False):
+    """wav [B,L] -> enhanced wav [B,L]: the whole of generate_wav's per-file body,
+    batched (reference: trainer/complex_ddpm_trainer.py:921-1016)."""
+    c = rms_scale(wav)
+    feat = compress_sqrt(stft_ri(wav / c[:, None]))
+    spec, _ = sample(prior_name, prior_sd, ddpm_sd, feat, x_T, noise_schedule,
+                     inference_noise_schedule, fast_sampling, use_sigma)
+    out = istft_ri(decompress_square(spec), wav.shape[-1])
+    return out * c[:, None], spec

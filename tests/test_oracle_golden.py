@@ -1,0 +1,175 @@
+"""CPU: the oracle restatement (oracle/restate.py) against the golden vectors recorded
+from the reference's real modules (oracle/make_golden.py).  fp32 on both sides, same
+torch build: tolerance 2e-6 rel-L2 (summation-order noise only); the schedule is
+bit-exact."""
+import numpy as np
+import torch
+
+from conftest import golden, pkg, rel_l2, seeded
+from oracle import restate as R
+
+TOL = 2e-6
+
+
+def test_schedule_bit_exact():
+    g = golden("schedule")
+    params = pkg("params").params
+    for name, fast in (("fast", True), ("full", False)):
+        for impl in (lambda f: R.inference_schedule(params.noise_schedule, params.inference_noise_schedule, f),
+                     lambda f: pkg("schedule").inference_schedule(params, f)):
+            alpha, beta, alpha_cum, sigmas, T = impl(fast)
+            assert np.array_equal(alpha, g[name + "_alpha"])
+            assert np.array_equal(beta, g[name + "_beta"])
+            assert np.array_equal(alpha_cum, g[name + "_alpha_cum"])
+            assert np.array_equal(np.array(sigmas, dtype=np.float64), g[name + "_sigmas"])
+            assert T.dtype == np.float32 and np.array_equal(T, g[name + "_T"])
+    # SURVEY §8 A1 values
+    assert np.allclose(g["fast_T"], [0, 0.8941341, 4.086654, 10.451817, 22.992493, 42.918644])
+    assert np.array_equal(g["full_T"], np.arange(50, dtype=np.float32))
+
+
+def test_newsigma_is_zero_for_every_step():
+    """reference :986-992 — the stochastic term never contributes."""
+    params = pkg("params").params
+    for fast in (True, False):
+        alpha, beta, alpha_cum, sigmas, T = R.inference_schedule(
+            params.noise_schedule, params.inference_noise_schedule, fast)
+        for n in range(1, len(alpha)):
+            c1 = 1 / alpha[n] ** 0.5
+            assert max(0, sigmas[n] - c1 * sigmas[n]) == 0
+
+
+def test_time_embedding(weights):
+    g = golden("time_embedding")
+    sd = weights("DiffUNet1")
+    table = R.build_time_table(50)
+    assert np.array_equal(table.numpy(), g["table"])
+    out_f = R.time_embedding(sd, torch.from_numpy(g["t_float"]), table)
+    out_i = R.time_embedding(sd, torch.from_numpy(g["t_int"]), table)
+    assert rel_l2(out_f, g["out_float"]) < TOL
+    assert rel_l2(out_i, g["out_int"]) < TOL
+
+
+def test_diffunet1_small_with_intermediates(weights):
+    g = golden("diffunet1_small")
+    sd = weights("DiffUNet1")
+    B, T = int(g["B"]), int(g["T"])
+    x = seeded((B, 2, T, 161), g["seed_x"])
+    x_init = seeded((B, 2, T, 161), g["seed_init"]) * float(g["init_scale"])
+    taps = {}
+    with torch.no_grad():
+        out = R.diffunet1_forward(sd, x, x_init, torch.from_numpy(g["t"]), taps=taps)
+        res1 = R.tcm_residual(sd, "TCMs.0.residual1",
+                              taps["en_list"][4].permute(0, 2, 1, 3).reshape(B, T, -1).permute(0, 2, 1), 1)
+    assert rel_l2(taps["pre"], g["pre"]) < TOL
+    assert rel_l2(taps["en_list"][0][:, ::4], g["en1_c4"]) < TOL
+    assert rel_l2(taps["en_list"][4], g["en5"]) < TOL
+    assert rel_l2(res1, g["res1"]) < TOL
+    tcm_ref = torch.from_numpy(g["tcm"]).permute(0, 2, 1).reshape(B, T, 64, 4).permute(0, 2, 1, 3)
+    assert rel_l2(taps["tcm_out"], tcm_ref) < TOL
+    assert rel_l2(out, g["out"]) < TOL
+
+
+def test_diffunet1_int_t(weights):
+    g0 = golden("diffunet1_small")
+    g = golden("diffunet1_int_t")
+    sd = weights("DiffUNet1")
+    x = seeded((2, 2, 20, 161), g0["seed_x"])
+    x_init = seeded((2, 2, 20, 161), g0["seed_init"]) * 0.3
+    with torch.no_grad():
+        out = R.diffunet1_forward(sd, x, x_init, torch.from_numpy(g["t"]))
+    assert rel_l2(out, g["out"]) < TOL
+
+
+def test_diffunet1_t401(weights):
+    g = golden("diffunet1_t401")
+    sd = weights("DiffUNet1")
+    x = seeded((1, 2, 401, 161), g["seed_x"])
+    x_init = seeded((1, 2, 401, 161), g["seed_init"]) * 0.3
+    with torch.no_grad():
+        out = R.diffunet1_forward(sd, x, x_init, torch.tensor([float(g["t"])]))
+    assert rel_l2(out[0, :, ::16, :], g["rows"]) < TOL
+    assert abs(out.double().pow(2).sum().item() - float(g["sumsq"])) / float(g["sumsq"]) < 1e-5
+
+
+def test_gcrn_small_and_t401(weights):
+    g = golden("gcrn_small")
+    sd = weights("GCRN")
+    x = seeded((2, 2, 20, 161), g["seed_x"])
+    taps = {}
+    with torch.no_grad():
+        out = R.gcrn_forward(sd, x, taps=taps)
+    assert rel_l2(taps["e5"], g["e5"]) < TOL
+    assert rel_l2(taps["glstm"], g["glstm"]) < 5e-6
+    assert rel_l2(out, g["out"]) < 5e-6
+    g = golden("gcrn_t401")
+    x = seeded((1, 2, 401, 161), g["seed_x"])
+    with torch.no_grad():
+        out = R.gcrn_forward(sd, x)
+    assert rel_l2(out[0, :, ::16, :], g["rows"]) < 5e-6
+
+
+def test_diffunet_prior(weights):
+    g = golden("diffunet_prior_small")
+    with torch.no_grad():
+        out = R.diffunet_forward(weights("DiffUNet"), seeded((2, 2, 20, 161), g["seed_x"]))
+    assert rel_l2(out, g["out"]) < TOL
+
+
+def _run_sample(weights, tag, prior, fast, sigma):
+    g = golden("sample_" + tag)
+    params = pkg("params").params
+    feat = seeded((2, 2, 16, 161), g["seed_feat"])
+    x_T = seeded((2, 2, 16, 161), g["seed_xT"])
+    trace = []
+    with torch.no_grad():
+        out, init = R.sample(prior, weights(prior), weights("DiffUNet1"), feat, x_T, params.noise_schedule,
+                             params.inference_noise_schedule, fast_sampling=fast, use_sigma=sigma, trace=trace)
+    return g, out, init, trace
+
+
+def test_sample_fast_trace(weights):
+    g, out, init, trace = _run_sample(weights, "gcrn_fast", "GCRN", True, False)
+    assert rel_l2(init, g["init"]) < 5e-6
+    for k in range(6):
+        assert rel_l2(trace[k], g["trace"][k]) < 2e-5, k
+    assert rel_l2(out, g["out"]) < 2e-5
+
+
+def test_sample_sigma_mask(weights):
+    g, out, init, trace = _run_sample(weights, "gcrn_fast_sigma", "GCRN", True, True)
+    assert rel_l2(out, g["out"]) < 2e-5
+
+
+def test_sample_diffunet_prior(weights):
+    g, out, init, trace = _run_sample(weights, "diffunet_fast", "DiffUNet", True, False)
+    assert rel_l2(out, g["out"]) < 2e-5
+
+
+def test_sample_full_50_steps(weights):
+    g, out, init, trace = _run_sample(weights, "gcrn_full", "GCRN", False, False)
+    assert rel_l2(out, g["out"]) < 1e-4
+
+
+def test_stft_convention_against_float64_dft():
+    """Pins the STFT/ISTFT restatement (the reference's legacy torch.stft call cannot run
+    under torch 2.10) with an explicit float64 DFT: periodic hann(320), hop 160,
+    center=True reflect padding, onesided, no normalisation."""
+    wav = seeded((2, 1600), 5)
+    ri = R.stft_ri(wav).numpy()  # [B,2,T,F]
+    x = wav.numpy().astype(np.float64)
+    xp = np.pad(x, ((0, 0), (160, 160)), mode="reflect")
+    n = np.arange(320)
+    w = 0.5 - 0.5 * np.cos(2 * np.pi * n / 320)
+    T = 1 + 1600 // 160
+    ref = np.zeros((2, 2, T, 161))
+    for t in range(T):
+        fr = xp[:, t * 160:t * 160 + 320] * w
+        spec = np.fft.rfft(fr, axis=-1)
+        ref[:, 0, t], ref[:, 1, t] = spec.real, spec.imag
+    assert ri.shape == ref.shape
+    assert rel_l2(ri, ref) < 1e-6
+    # round trip through compress/decompress/istft gives the waveform back
+    feat = R.compress_sqrt(torch.from_numpy(ri))
+    back = R.istft_ri(R.decompress_square(feat), 1600)
+    assert rel_l2(back, wav) < 1e-5
