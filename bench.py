@@ -1,0 +1,163 @@
+"""bench.py — the reference's headline workload on N MI355X GPUs of one node.
+
+Metric (BASELINE.json): enhanced-audio seconds per wall second (real-time factor) of
+6-step fast sampling; workload = configs[1] restated at the shapes the reference can
+actually run: B=32 utterances of 4 s at 16 kHz per GPU, spectrograms
+[32,2,401,161], GCRN prior + DiffUNet1 x 6, fp32 (the reference is fp32-only; bf16 has
+no reference counterpart and the 1e-4 tolerance is an fp32 statement).
+
+A "step" is one pass of the whole hot path over one batch: waveforms already resident in
+HBM -> STFT -> prior -> 6 reverse steps -> ISTFT -> waveforms in HBM, replayed from one
+hipGraph.  Multi-GPU: utterances are sharded over ranks (weak scaling, B=32 per rank), no
+data-path collective; the only collectives are the timing barrier and a max-reduce.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu-baseline]
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic work per utterance: flops of one eps-net forward at T=401
+EPS_GFLOP_PER_UTT_STEP = 10.29
+FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md, fp32 matrix = fp32 vector peak
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
+    ap.add_argument("--seconds", type=float, default=4.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+    dev = "cuda:%d" % local
+
+    import __graft_entry__ as ge
+
+    ge.build()
+    synth = importlib.import_module("prior-diffuse_amd.synth")
+    pipeline = importlib.import_module("prior-diffuse_amd.pipeline")
+    nets = importlib.import_module("prior-diffuse_amd.nets")
+    shard = importlib.import_module("prior-diffuse_amd.shard")
+
+    B, L_ = args.batch, int(args.seconds * 16000)
+    T = 1 + L_ // 160
+    gs, ds = synth.make_state_dict("GCRN"), synth.make_state_dict("DiffUNet1")
+    # the global batch is generated once from the seed and sliced, so results do not depend on N
+    lo, hi = shard.shard_range(B * world, world, rank)
+    wav, x_T = synth.synthetic_waveforms(B * world, L_, seed=1234)
+    wav, x_T = wav[lo:hi].to(dev), x_T[lo:hi].to(dev)
+
+    pipe = pipeline.SamplerPipeline(dev, "GCRN", gs, ds, B, L_=L_, fast_sampling=True)
+    use_graph = not args.no_graph
+
+    def step():
+        pipe.enhance(wav, x_T, graph=use_graph)
+
+    for _ in range(args.warmup):
+        step()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    audio_seconds = args.steps * B * world * args.seconds
+    rtf = audio_seconds / elapsed
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant kernel family: the fused BiConv(Trans)GLU blocks, live hipEvent timing
+    stream = torch.cuda.current_stream().cuda_stream
+    pipe.stft.wav.copy_(wav)
+    pipe.xT_in.copy_(x_T)
+    torch.cuda.synchronize()
+    per_tag = {}
+    for name, tag in (("eps_block", nets.TAG_EPS_BLOCK), ("eps_conv1", nets.TAG_EPS_CONV1), ("tcm", nets.TAG_TCM),
+                      ("prior_conv", nets.TAG_PRIOR), ("lstm", nets.TAG_LSTM), ("signal", nets.TAG_SIGNAL),
+                      ("elementwise", nets.TAG_EW)):
+        ms, cnt = pipe.plan.time_tag(tag, stream)
+        per_tag[name] = {"ms": round(ms, 4), "launches": cnt}
+    eps_ms = per_tag["eps_block"]["ms"] + per_tag["eps_conv1"]["ms"] + per_tag["tcm"]["ms"]
+    eps_flop = EPS_GFLOP_PER_UTT_STEP * 1e9 * (T / 401.0) * B * pipe.nsteps
+    achieved = eps_flop / (eps_ms * 1e-3) / 1e12
+    roofline = {"bound": "mfma", "kernel": "gconv_kernel (eps-net: BiConvGLU/BiConvTransGLU/TCM launches)",
+                "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "avg_launch_ms": round(eps_ms / max(1, sum(per_tag[k]["launches"] for k in ("eps_block", "eps_conv1", "tcm"))), 5),
+                "per_stage_ms": per_tag}
+
+    cpu = None
+    if not args.no_cpu_baseline:
+        from oracle import restate as R
+
+        params = importlib.import_module("prior-diffuse_amd.params").params
+        nthreads = os.cpu_count() or 1
+        torch.set_num_threads(nthreads)
+        cb = 2
+        w_cpu, x_cpu = synth.synthetic_waveforms(B * world, L_, seed=1234)
+        w_cpu, x_cpu = w_cpu[:cb], x_cpu[:cb]
+        with torch.no_grad():
+            R.enhance("GCRN", gs, ds, w_cpu[:1], x_cpu[:1], params.noise_schedule, params.inference_noise_schedule, True)
+            tc = time.perf_counter()
+            R.enhance("GCRN", gs, ds, w_cpu, x_cpu, params.noise_schedule, params.inference_noise_schedule, True)
+            tc = time.perf_counter() - tc
+        cpu = {"value": round(cb * args.seconds / tc, 3), "unit": "audio_s/s", "cores": nthreads, "kind": "port",
+               "sample": "oracle (torch-CPU fp32 restatement), %d of the %d utterances, full path incl. STFT/ISTFT, "
+                         "1 warm-up + 1 timed run" % (cb, B)}
+
+    out = {
+        "metric": "enhanced-audio sec/sec (RTF), 6-step fast sampling, B=32",
+        "value": round(rtf, 2), "unit": "audio_s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "frames_per_s_per_gpu": round(args.steps * B * T / elapsed, 1),
+        "config": {"workload": "B=%d x %.0f s 16 kHz utterances per GPU, [B,2,%d,161] spectrograms, GCRN prior + "
+                               "DiffUNet1 6-step fast sampling, STFT..ISTFT, seeded random weights" % (B, args.seconds, T),
+                   "global_batch": B * world, "frames": T, "parallelism": "batch-shard x%d" % world,
+                   "graph": use_graph},
+        "roofline": roofline, "cpu_baseline": cpu,
+    }
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

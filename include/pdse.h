@@ -1,0 +1,258 @@
+/* pdse.h — C-ABI of libpdse.so: the MI355X (gfx950) reverse-diffusion sampling path
+ * of Prior-DiffuSE.
+ *
+ * The reference has NO plugin / operator / FFI layer: its boundary is
+ * the Python surface
+ *     ComplexDDPMTrainer.inference_schedule / generate_wav
+ *                                   (trainer/complex_ddpm_trainer.py:105, :903)
+ *     self.model(feat) -> X_init              (trainer/complex_ddpm_trainer.py:941)
+ *     self.model_ddpm(audio, init, t) -> eps  (trainer/complex_ddpm_trainer.py:968)
+ * i.e. nn.Module.__call__ on contiguous fp32 [B,2,T,161] tensors.  This header is the
+ * build-defined C boundary underneath that surface: every entry point takes raw device
+ * pointers (tensor.data_ptr()), explicit sizes/strides and a hipStream_t, returns an
+ * int status (0 = ok) and never throws; the message of the last failure on the calling
+ * thread is available from pdse_last_error().
+ *
+ * Ownership: the caller owns every buffer named in a descriptor (inputs, outputs,
+ * packed weights, workspaces).  The library owns only plan objects.  No global mutable
+ * state, no device selection: kernels run on the device current on the calling thread.
+ * Threading: one host thread per plan; different plans are independent.
+ *
+ * Data layout: activations are "channel-major" [B, C, T, F] fp32 with F innermost (the
+ * reference's own NCHW layout), addressed through explicit element strides so that the
+ * same kernels serve Conv2d / ConvTranspose2d / Conv1d / Linear / STFT bases.
+ */
+#ifndef PDSE_H
+#define PDSE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PDSE_ABI_VERSION 1
+
+typedef void* pdse_stream_t; /* hipStream_t */
+
+enum pdse_act { PDSE_ACT_NONE = 0, PDSE_ACT_PRELU = 1, PDSE_ACT_ELU = 2, PDSE_ACT_SIGMOID = 3 };
+
+/* epilogue of the gather-GEMM convolution kernel */
+enum pdse_epi {
+  PDSE_EPI_LINEAR = 0, /* y = act(affine(acc0 + bias0)) (+ resid)                              */
+  PDSE_EPI_GLU = 1,    /* y = act(affine((acc0+bias0) * sigmoid(acc1+bias1)))  gcrn.py:43-84   */
+  PDSE_EPI_BIGLU = 2   /* L,R = acc0,acc1 (+bias); mL = s(Wlc L), mR = s(Wrc R);
+                          y = act(affine(Wc2 (L*mR + R*mL) + bc2))           diff3.py:316-326 */
+};
+
+/* One input source of a (possibly channel-concatenated) convolution input. */
+typedef struct pdse_src {
+  const float* ptr;
+  int64_t sb, sc, st, sf; /* element strides of batch, channel, frame (t), bin (f) */
+  int32_t C;              /* channels taken from this source                       */
+  int32_t act;            /* pdse_act applied on load (ELU on GCRN skip tensors)    */
+} pdse_src;
+
+/* Gather-GEMM convolution:
+ *   acc[co](b,t,j) = sum_tap sum_ci W[tap][ci][co] * IN(b, ci, t + dt[tap], j*sf_in + df[tap])
+ * IN is zero outside [0,Tin)x[0,Fin), except that frame -1 reads padrow[b][ci] when padrow
+ * is set (the ε-net encoder adds the time bias to the already padded tensor, diff3.py:146-147).
+ * Replaces, per layer: nn.Conv2d / nn.ConvTranspose2d (one launch per output phase) /
+ * nn.Conv1d / nn.Linear calls of model/diff3.py, model/gcrn.py, and the torch.stft /
+ * torch.istft DFTs of trainer/complex_ddpm_trainer.py:926-930, :1010-1015.
+ * Weights are pre-packed on the host into MFMA A-fragment order:
+ *   w[mtile][kstep][lane] = W[k = 2*kstep + (lane>>5)][co = 32*mtile + (lane&31)],
+ *   k = tap*Cin + ci.
+ */
+typedef struct pdse_gconv_desc {
+  pdse_src in0, in1; /* in1.C == 0: single source */
+  int32_t Tin, Fin;
+  const float* padrow; /* [B][Cin] value of frame -1, or NULL */
+  int64_t padrow_sb;
+  const int32_t* taps; /* device, [ntaps][2] = {dt, df} */
+  int32_t ntaps;
+  int32_t sf_in; /* input bin = j*sf_in + df */
+  /* optional transform on load: v = prelu(v, slope) * scale[ci] + shift[ci]   (diff3.py:221-246,
+     PReLU -> BatchNorm1d in front of a zero-padded Conv1d).  xf_mode 0: none, 1: set 0 feeds
+     both accumulators, 2: set 0 feeds acc0 and set 1 feeds acc1. */
+  const float* xf_scale0;
+  const float* xf_shift0;
+  const float* xf_scale1;
+  const float* xf_shift1;
+  float xf_slope0, xf_slope1;
+  int32_t xf_mode;
+  int32_t cin1; /* 1: Cin == 1, k enumerates taps (STFT / Linear-over-bins) */
+  const float* w0;
+  const float* w1;
+  int32_t ksteps; /* ceil(K/2) */
+  int32_t Cout;
+  const float* bias0;
+  const float* bias1;
+  int64_t bias0_sb, bias1_sb; /* batch stride of the bias (0: shared) */
+  int32_t epi;                /* pdse_epi */
+  int32_t act;                /* pdse_act */
+  float act_slope;
+  int32_t C2; /* BIGLU: channels after the closing 1x1 (64 or 1) */
+  const float* post_scale; /* folded eval-mode BatchNorm: y*scale[co] + shift[co], or NULL */
+  const float* post_shift;
+  const float* wlc; /* BIGLU chain fragments, [16][64] each; wc2 [C2 tiles][16][64] or [32] when C2==1 */
+  const float* wrc;
+  const float* blc;
+  const float* brc;
+  const float* wc2;
+  const float* bc2;
+  const float* resid; /* added after the activation, addressed like out, or NULL */
+  float* out;
+  int64_t out_sb, out_sc_hi, out_sc_lo, out_st, out_sf, out_off;
+  int32_t out_cr; /* co -> (co / out_cr)*out_sc_hi + (co % out_cr)*out_sc_lo */
+  int32_t B, Tout, Fout;
+} pdse_gconv_desc;
+
+/* Diffusion-step embedding + every per-stage time bias folded through the following 1x1
+ * convolution (model/diff3.py:62-95, :146-147, :343-344):
+ *   x = lerp(table, t); temb = silu(P2 silu(P1 x)); out[b][:] = WF temb + bf,
+ * WF = stacked (W1_k · Wtp_k), bf = stacked (b1_k + W1_k · btp_k) for the 15 stages. */
+typedef struct pdse_time_desc {
+  const float* t; /* [B] fractional (or integral) step */
+  const float* table; /* [max_steps][128] */
+  const float* p1T;   /* [128][512] */
+  const float* b1;
+  const float* p2T; /* [512][512] */
+  const float* b2;
+  const float* wfT; /* [512][NF] */
+  const float* bf;
+  float* out;  /* [B][NF] */
+  float* temb; /* [B][512] or NULL */
+  int32_t B, NF, max_steps, pad_;
+} pdse_time_desc;
+
+enum pdse_ew_op {
+  PDSE_EW_DIV = 0,          /* out = a / s0                       :942 init /= c            */
+  PDSE_EW_UPDATE = 1,       /* out = s0 * (a - s1 * b)            :977                      */
+  PDSE_EW_UPDATE_FINAL = 2, /* out = ((s0*(a - s1*b)) + c) * s2   :977 + :995-996           */
+  PDSE_EW_COPY = 3,
+  PDSE_EW_ADD_MUL = 4 /* out = (a + b) * s0 */
+};
+typedef struct pdse_ew_desc {
+  const float* a;
+  const float* b;
+  const float* c;
+  float* out;
+  int64_t n;
+  float s0, s1, s2;
+  int32_t op;
+} pdse_ew_desc;
+
+/* sqrt-compression / square-decompression of a [B,2,T,F] spectrogram
+ * (trainer/complex_ddpm_trainer.py:931-937 and :1004-1008):  power = 0.5 or 2. */
+typedef struct pdse_compand_desc {
+  const float* in;
+  float* out;
+  int64_t plane; /* T*F */
+  int32_t B;
+  int32_t mode; /* 0: mag**0.5 (compress), 1: mag**2 (decompress) */
+} pdse_compand_desc;
+
+/* waveform front-end: c[b] = sqrt(sum x^2 / L); xpad = reflect_pad(x / c, 160)   (:922-923, stft center=True) */
+typedef struct pdse_wavprep_desc {
+  const float* wav; /* [B][L] */
+  float* xpad;      /* [B][L + 2*pad] */
+  float* c;         /* [B] */
+  int32_t B, L, pad, normalize; /* normalize 0: c = 1 */
+} pdse_wavprep_desc;
+
+/* overlap-add of windowed inverse-DFT frames, window-envelope normalisation, trim, rescale
+ * (torch.istft semantics, :1010-1016): frames [B][n_fft][T] (T innermost). */
+typedef struct pdse_ola_desc {
+  const float* frames;
+  const float* win2; /* [n_fft] squared window */
+  const float* c;    /* [B] or NULL */
+  float* out;        /* [B][L] */
+  int32_t B, T, L, n_fft, hop, pad_;
+} pdse_ola_desc;
+
+/* per-(b,ch) abs-max mask of --sigma (:951-956): out = a * sqrt(|init|/max|init| / 2 + 0.5) */
+typedef struct pdse_sigma_desc {
+  const float* init;
+  const float* a;
+  float* out;
+  float* maxbuf; /* [B*2] scratch */
+  int64_t plane;
+  int32_t nplanes, pad_;
+} pdse_sigma_desc;
+
+/* LayerNorm over the last dim of [B][T][N] rows with a strided/transposed store
+ * (gcrn.py:31, :35): out[b*osb + (j / r)*os_hi + (j % r)*os_lo + t*os_t]. */
+typedef struct pdse_ln_desc {
+  const float* in;
+  const float* gamma;
+  const float* beta;
+  float* out;
+  int64_t osb, os_hi, os_lo, os_t;
+  int32_t B, T, N, r;
+  float eps;
+  int32_t pad_;
+} pdse_ln_desc;
+
+/* One LSTM layer of the grouped LSTM (gcrn.py:6-40), all T steps, G independent groups.
+ *   gx   [G][T][4H][Bp]   input projections + both biases (Bp = batch padded to 32)
+ *   whh  [G][H/8][H/2][64] recurrent weights in MFMA A-fragment order (8 hidden units x 4 gates per slice)
+ *   hT   [2][G][H][Bp], cst [G][H][Bp]   state, zeroed by the call
+ *   y    [B][T][ysz]; y[b][t][u*y_su + g*y_sg] = h_t                   */
+typedef struct pdse_lstm_desc {
+  const float* gx;
+  const float* whh;
+  float* hT;
+  float* cst;
+  float* y;
+  int64_t y_sb, y_st, y_su, y_sg;
+  int32_t B, Bp, T, H, G, pad_;
+} pdse_lstm_desc;
+
+enum pdse_op_kind {
+  PDSE_OP_GCONV = 0,
+  PDSE_OP_TIME = 1,
+  PDSE_OP_EW = 2,
+  PDSE_OP_COMPAND = 3,
+  PDSE_OP_WAVPREP = 4,
+  PDSE_OP_OLA = 5,
+  PDSE_OP_SIGMA = 6,
+  PDSE_OP_LN = 7,
+  PDSE_OP_LSTM = 8
+};
+
+int pdse_abi_version(void);
+const char* pdse_last_error(void);
+/* sizeof() of a descriptor as the library was compiled, for binding self-checks */
+int pdse_desc_size(int op_kind);
+
+/* direct launches (one operator) */
+int pdse_gconv_f32(const pdse_gconv_desc* d, pdse_stream_t s);
+int pdse_time_embed_f32(const pdse_time_desc* d, pdse_stream_t s);
+int pdse_ew_f32(const pdse_ew_desc* d, pdse_stream_t s);
+int pdse_compand_f32(const pdse_compand_desc* d, pdse_stream_t s);
+int pdse_wavprep_f32(const pdse_wavprep_desc* d, pdse_stream_t s);
+int pdse_ola_f32(const pdse_ola_desc* d, pdse_stream_t s);
+int pdse_sigma_mask_f32(const pdse_sigma_desc* d, pdse_stream_t s);
+int pdse_layernorm_f32(const pdse_ln_desc* d, pdse_stream_t s);
+int pdse_lstm_f32(const pdse_lstm_desc* d, pdse_stream_t s);
+
+/* plans: a recorded operator sequence replayed by one call (and capturable in a hipGraph) */
+typedef struct pdse_plan pdse_plan;
+int pdse_plan_create(pdse_plan** out);
+int pdse_plan_add(pdse_plan* p, int op_kind, const void* desc, int tag);
+int pdse_plan_size(const pdse_plan* p);
+int pdse_plan_run(pdse_plan* p, pdse_stream_t s);
+int pdse_plan_run_range(pdse_plan* p, int begin, int end, pdse_stream_t s);
+/* capture the whole plan into a hipGraph on stream s, then replay it with launch_graph */
+int pdse_plan_build_graph(pdse_plan* p, pdse_stream_t s);
+int pdse_plan_launch_graph(pdse_plan* p, pdse_stream_t s);
+/* time ops [begin,end) with hipEvents on stream s: ms_out[i] = elapsed ms of op begin+i */
+int pdse_plan_time_ops(pdse_plan* p, int begin, int end, pdse_stream_t s, float* ms_out);
+/* sum of elapsed ms of the ops carrying `tag`, hipEvents around each (bench roofline leg) */
+int pdse_plan_time_tag(pdse_plan* p, int tag, pdse_stream_t s, float* ms_out, int* count_out);
+void pdse_plan_destroy(pdse_plan* p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PDSE_H */

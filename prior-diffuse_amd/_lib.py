@@ -1,0 +1,221 @@
+"""ctypes binding of libpdse.so (the C-ABI declared in include/pdse.h).
+
+The product path has no CPU fallback: if the shared library is missing or does not
+match the header this module raises, and so does everything built on it.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpdse.so")
+
+ABI_VERSION = 1
+
+ACT_NONE, ACT_PRELU, ACT_ELU, ACT_SIGMOID = 0, 1, 2, 3
+EPI_LINEAR, EPI_GLU, EPI_BIGLU = 0, 1, 2
+EW_DIV, EW_UPDATE, EW_UPDATE_FINAL, EW_COPY, EW_ADD_MUL = 0, 1, 2, 3, 4
+(OP_GCONV, OP_TIME, OP_EW, OP_COMPAND, OP_WAVPREP, OP_OLA, OP_SIGMA, OP_LN, OP_LSTM) = range(9)
+
+_fp = C.c_void_p  # device pointers travel as integers
+_i32, _i64, _f32 = C.c_int32, C.c_int64, C.c_float
+
+
+class Src(C.Structure):
+    _fields_ = [("ptr", _fp), ("sb", _i64), ("sc", _i64), ("st", _i64), ("sf", _i64),
+                ("C", _i32), ("act", _i32)]
+
+
+class GconvDesc(C.Structure):
+    _fields_ = [
+        ("in0", Src), ("in1", Src),
+        ("Tin", _i32), ("Fin", _i32),
+        ("padrow", _fp), ("padrow_sb", _i64),
+        ("taps", _fp), ("ntaps", _i32), ("sf_in", _i32),
+        ("xf_scale0", _fp), ("xf_shift0", _fp), ("xf_scale1", _fp), ("xf_shift1", _fp),
+        ("xf_slope0", _f32), ("xf_slope1", _f32), ("xf_mode", _i32), ("cin1", _i32),
+        ("w0", _fp), ("w1", _fp), ("ksteps", _i32), ("Cout", _i32),
+        ("bias0", _fp), ("bias1", _fp), ("bias0_sb", _i64), ("bias1_sb", _i64),
+        ("epi", _i32), ("act", _i32), ("act_slope", _f32), ("C2", _i32),
+        ("post_scale", _fp), ("post_shift", _fp),
+        ("wlc", _fp), ("wrc", _fp), ("blc", _fp), ("brc", _fp), ("wc2", _fp), ("bc2", _fp),
+        ("resid", _fp), ("out", _fp),
+        ("out_sb", _i64), ("out_sc_hi", _i64), ("out_sc_lo", _i64), ("out_st", _i64),
+        ("out_sf", _i64), ("out_off", _i64),
+        ("out_cr", _i32), ("B", _i32), ("Tout", _i32), ("Fout", _i32),
+    ]
+
+
+class TimeDesc(C.Structure):
+    _fields_ = [("t", _fp), ("table", _fp), ("p1T", _fp), ("b1", _fp), ("p2T", _fp), ("b2", _fp),
+                ("wfT", _fp), ("bf", _fp), ("out", _fp), ("temb", _fp),
+                ("B", _i32), ("NF", _i32), ("max_steps", _i32), ("pad_", _i32)]
+
+
+class EwDesc(C.Structure):
+    _fields_ = [("a", _fp), ("b", _fp), ("c", _fp), ("out", _fp), ("n", _i64),
+                ("s0", _f32), ("s1", _f32), ("s2", _f32), ("op", _i32)]
+
+
+class CompandDesc(C.Structure):
+    _fields_ = [("in_", _fp), ("out", _fp), ("plane", _i64), ("B", _i32), ("mode", _i32)]
+
+
+class WavprepDesc(C.Structure):
+    _fields_ = [("wav", _fp), ("xpad", _fp), ("c", _fp),
+                ("B", _i32), ("L", _i32), ("pad", _i32), ("normalize", _i32)]
+
+
+class OlaDesc(C.Structure):
+    _fields_ = [("frames", _fp), ("win2", _fp), ("c", _fp), ("out", _fp),
+                ("B", _i32), ("T", _i32), ("L", _i32), ("n_fft", _i32), ("hop", _i32), ("pad_", _i32)]
+
+
+class SigmaDesc(C.Structure):
+    _fields_ = [("init", _fp), ("a", _fp), ("out", _fp), ("maxbuf", _fp), ("plane", _i64),
+                ("nplanes", _i32), ("pad_", _i32)]
+
+
+class LnDesc(C.Structure):
+    _fields_ = [("in_", _fp), ("gamma", _fp), ("beta", _fp), ("out", _fp),
+                ("osb", _i64), ("os_hi", _i64), ("os_lo", _i64), ("os_t", _i64),
+                ("B", _i32), ("T", _i32), ("N", _i32), ("r", _i32), ("eps", _f32), ("pad_", _i32)]
+
+
+class LstmDesc(C.Structure):
+    _fields_ = [("gx", _fp), ("whh", _fp), ("hT", _fp), ("cst", _fp), ("y", _fp),
+                ("y_sb", _i64), ("y_st", _i64), ("y_su", _i64), ("y_sg", _i64),
+                ("B", _i32), ("Bp", _i32), ("T", _i32), ("H", _i32), ("G", _i32), ("pad_", _i32)]
+
+
+DESC_TYPES = {OP_GCONV: GconvDesc, OP_TIME: TimeDesc, OP_EW: EwDesc, OP_COMPAND: CompandDesc,
+              OP_WAVPREP: WavprepDesc, OP_OLA: OlaDesc, OP_SIGMA: SigmaDesc, OP_LN: LnDesc,
+              OP_LSTM: LstmDesc}
+KIND_OF = {v: k for k, v in DESC_TYPES.items()}
+
+EXPORTS = [
+    "pdse_abi_version", "pdse_last_error", "pdse_desc_size",
+    "pdse_gconv_f32", "pdse_time_embed_f32", "pdse_ew_f32", "pdse_compand_f32", "pdse_wavprep_f32",
+    "pdse_ola_f32", "pdse_sigma_mask_f32", "pdse_layernorm_f32", "pdse_lstm_f32",
+    "pdse_plan_create", "pdse_plan_add", "pdse_plan_size", "pdse_plan_run", "pdse_plan_run_range",
+    "pdse_plan_build_graph", "pdse_plan_launch_graph", "pdse_plan_time_ops", "pdse_plan_time_tag",
+    "pdse_plan_destroy",
+]
+
+_DIRECT = {OP_GCONV: "pdse_gconv_f32", OP_TIME: "pdse_time_embed_f32", OP_EW: "pdse_ew_f32",
+           OP_COMPAND: "pdse_compand_f32", OP_WAVPREP: "pdse_wavprep_f32", OP_OLA: "pdse_ola_f32",
+           OP_SIGMA: "pdse_sigma_mask_f32", OP_LN: "pdse_layernorm_f32", OP_LSTM: "pdse_lstm_f32"}
+
+
+class PdseError(RuntimeError):
+    """Non-zero status from libpdse.so (the reference raises Python exceptions only)."""
+
+
+_lib = None
+
+
+def load():
+    """Load libpdse.so once; verify ABI version and descriptor sizes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PdseError(
+            "libpdse.so not found at %s — build it with `python -c 'import __graft_entry__ as g; g.build()'`"
+            " (hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name in EXPORTS:
+        if not hasattr(lib, name):
+            raise PdseError("libpdse.so lacks symbol %s declared in include/pdse.h" % name)
+    lib.pdse_last_error.restype = C.c_char_p
+    lib.pdse_abi_version.restype = C.c_int
+    lib.pdse_desc_size.argtypes = [C.c_int]
+    for kind, name in _DIRECT.items():
+        getattr(lib, name).argtypes = [C.POINTER(DESC_TYPES[kind]), C.c_void_p]
+        getattr(lib, name).restype = C.c_int
+    lib.pdse_plan_create.argtypes = [C.POINTER(C.c_void_p)]
+    lib.pdse_plan_add.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    lib.pdse_plan_size.argtypes = [C.c_void_p]
+    lib.pdse_plan_run.argtypes = [C.c_void_p, C.c_void_p]
+    lib.pdse_plan_run_range.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    lib.pdse_plan_build_graph.argtypes = [C.c_void_p, C.c_void_p]
+    lib.pdse_plan_launch_graph.argtypes = [C.c_void_p, C.c_void_p]
+    lib.pdse_plan_time_ops.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_float)]
+    lib.pdse_plan_time_tag.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_float),
+                                       C.POINTER(C.c_int)]
+    lib.pdse_plan_destroy.argtypes = [C.c_void_p]
+    lib.pdse_plan_destroy.restype = None
+    if lib.pdse_abi_version() != ABI_VERSION:
+        raise PdseError("libpdse.so ABI %d != binding ABI %d" % (lib.pdse_abi_version(), ABI_VERSION))
+    for kind, typ in DESC_TYPES.items():
+        if lib.pdse_desc_size(kind) != C.sizeof(typ):
+            raise PdseError("descriptor %s: library sizeof %d != binding sizeof %d"
+                            % (typ.__name__, lib.pdse_desc_size(kind), C.sizeof(typ)))
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise PdseError("%s failed: %s" % (what or "libpdse call", load().pdse_last_error().decode()))
+
+
+def launch(desc, stream=0):
+    """Launch one operator directly."""
+    lib = load()
+    kind = KIND_OF[type(desc)]
+    check(getattr(lib, _DIRECT[kind])(C.byref(desc), C.c_void_p(stream)), _DIRECT[kind])
+
+
+class Plan:
+    """Recorded operator sequence replayed by one C call (include/pdse.h, plans)."""
+
+    def __init__(self):
+        self._lib = load()
+        h = C.c_void_p()
+        check(self._lib.pdse_plan_create(C.byref(h)), "pdse_plan_create")
+        self._h = h
+        self._keep = []  # python-side owners of every buffer named by a descriptor
+        self.has_graph = False
+
+    def add(self, desc, tag=0, keep=()):
+        check(self._lib.pdse_plan_add(self._h, KIND_OF[type(desc)], C.byref(desc), int(tag)), "pdse_plan_add")
+        self._keep.extend(keep)
+        return len(self) - 1
+
+    def keep(self, *objs):
+        self._keep.extend(objs)
+
+    def __len__(self):
+        return self._lib.pdse_plan_size(self._h)
+
+    def run(self, stream=0):
+        check(self._lib.pdse_plan_run(self._h, C.c_void_p(stream)), "pdse_plan_run")
+
+    def run_range(self, begin, end, stream=0):
+        check(self._lib.pdse_plan_run_range(self._h, begin, end, C.c_void_p(stream)), "pdse_plan_run_range")
+
+    def build_graph(self, stream):
+        check(self._lib.pdse_plan_build_graph(self._h, C.c_void_p(stream)), "pdse_plan_build_graph")
+        self.has_graph = True
+
+    def launch_graph(self, stream):
+        check(self._lib.pdse_plan_launch_graph(self._h, C.c_void_p(stream)), "pdse_plan_launch_graph")
+
+    def time_ops(self, begin, end, stream=0):
+        buf = (C.c_float * (end - begin))()
+        check(self._lib.pdse_plan_time_ops(self._h, begin, end, C.c_void_p(stream), buf), "pdse_plan_time_ops")
+        return list(buf)
+
+    def time_tag(self, tag, stream=0):
+        ms, cnt = C.c_float(), C.c_int()
+        check(self._lib.pdse_plan_time_tag(self._h, tag, C.c_void_p(stream), C.byref(ms), C.byref(cnt)),
+              "pdse_plan_time_tag")
+        return ms.value, cnt.value
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._lib.pdse_plan_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass

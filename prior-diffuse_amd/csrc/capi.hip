@@ -1,0 +1,243 @@
+// capi.hip — the extern "C" surface of libpdse.so (include/pdse.h): argument checks,
+// per-thread error text, direct launches and recorded plans (replayable, graph-capturable).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <new>
+#include <string>
+#include <vector>
+
+#include "pdse.h"
+#include "pdse_internal.h"
+
+static thread_local std::string g_err;
+
+void pdse_set_error(const char* msg) { g_err = msg ? msg : "unknown error"; }
+
+int pdse_check_hip(hipError_t e, const char* what) {
+  if (e == hipSuccess) return 0;
+  g_err = std::string(what) + ": " + hipGetErrorString(e);
+  return 1;
+}
+
+int pdse_check_launch(const char* what) { return pdse_check_hip(hipGetLastError(), what); }
+
+union pdse_any_desc {
+  pdse_gconv_desc gconv;
+  pdse_time_desc time;
+  pdse_ew_desc ew;
+  pdse_compand_desc compand;
+  pdse_wavprep_desc wavprep;
+  pdse_ola_desc ola;
+  pdse_sigma_desc sigma;
+  pdse_ln_desc ln;
+  pdse_lstm_desc lstm;
+};
+
+struct pdse_op {
+  int kind;
+  int tag;
+  pdse_any_desc d;
+};
+
+struct pdse_plan {
+  std::vector<pdse_op> ops;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+};
+
+static int op_size(int kind) {
+  switch (kind) {
+    case PDSE_OP_GCONV: return (int)sizeof(pdse_gconv_desc);
+    case PDSE_OP_TIME: return (int)sizeof(pdse_time_desc);
+    case PDSE_OP_EW: return (int)sizeof(pdse_ew_desc);
+    case PDSE_OP_COMPAND: return (int)sizeof(pdse_compand_desc);
+    case PDSE_OP_WAVPREP: return (int)sizeof(pdse_wavprep_desc);
+    case PDSE_OP_OLA: return (int)sizeof(pdse_ola_desc);
+    case PDSE_OP_SIGMA: return (int)sizeof(pdse_sigma_desc);
+    case PDSE_OP_LN: return (int)sizeof(pdse_ln_desc);
+    case PDSE_OP_LSTM: return (int)sizeof(pdse_lstm_desc);
+    default: return -1;
+  }
+}
+
+static int launch_op(const pdse_op& op, hipStream_t s) {
+  switch (op.kind) {
+    case PDSE_OP_GCONV: return pdse_gconv_launch(&op.d.gconv, s);
+    case PDSE_OP_TIME: return pdse_time_launch(&op.d.time, s);
+    case PDSE_OP_EW: return pdse_ew_launch(&op.d.ew, s);
+    case PDSE_OP_COMPAND: return pdse_compand_launch(&op.d.compand, s);
+    case PDSE_OP_WAVPREP: return pdse_wavprep_launch(&op.d.wavprep, s);
+    case PDSE_OP_OLA: return pdse_ola_launch(&op.d.ola, s);
+    case PDSE_OP_SIGMA: return pdse_sigma_launch(&op.d.sigma, s);
+    case PDSE_OP_LN: return pdse_ln_launch(&op.d.ln, s);
+    case PDSE_OP_LSTM: return pdse_lstm_launch(&op.d.lstm, s);
+    default: pdse_set_error("plan: unknown op kind"); return 1;
+  }
+}
+
+extern "C" {
+
+int pdse_abi_version(void) { return PDSE_ABI_VERSION; }
+const char* pdse_last_error(void) { return g_err.c_str(); }
+int pdse_desc_size(int op_kind) { return op_size(op_kind); }
+
+int pdse_gconv_f32(const pdse_gconv_desc* d, pdse_stream_t s) { return pdse_gconv_launch(d, (hipStream_t)s); }
+int pdse_time_embed_f32(const pdse_time_desc* d, pdse_stream_t s) { return pdse_time_launch(d, (hipStream_t)s); }
+int pdse_ew_f32(const pdse_ew_desc* d, pdse_stream_t s) { return pdse_ew_launch(d, (hipStream_t)s); }
+int pdse_compand_f32(const pdse_compand_desc* d, pdse_stream_t s) { return pdse_compand_launch(d, (hipStream_t)s); }
+int pdse_wavprep_f32(const pdse_wavprep_desc* d, pdse_stream_t s) { return pdse_wavprep_launch(d, (hipStream_t)s); }
+int pdse_ola_f32(const pdse_ola_desc* d, pdse_stream_t s) { return pdse_ola_launch(d, (hipStream_t)s); }
+int pdse_sigma_mask_f32(const pdse_sigma_desc* d, pdse_stream_t s) { return pdse_sigma_launch(d, (hipStream_t)s); }
+int pdse_layernorm_f32(const pdse_ln_desc* d, pdse_stream_t s) { return pdse_ln_launch(d, (hipStream_t)s); }
+int pdse_lstm_f32(const pdse_lstm_desc* d, pdse_stream_t s) { return pdse_lstm_launch(d, (hipStream_t)s); }
+
+int pdse_plan_create(pdse_plan** out) {
+  if (!out) {
+    pdse_set_error("plan_create: null out");
+    return 1;
+  }
+  *out = new (std::nothrow) pdse_plan();
+  if (!*out) {
+    pdse_set_error("plan_create: out of memory");
+    return 1;
+  }
+  return 0;
+}
+
+int pdse_plan_add(pdse_plan* p, int op_kind, const void* desc, int tag) {
+  const int sz = op_size(op_kind);
+  if (!p || !desc || sz < 0) {
+    pdse_set_error("plan_add: bad argument");
+    return 1;
+  }
+  if (p->exec) {
+    pdse_set_error("plan_add: plan already captured into a graph");
+    return 1;
+  }
+  pdse_op op;
+  op.kind = op_kind;
+  op.tag = tag;
+  memcpy(&op.d, desc, (size_t)sz);
+  p->ops.push_back(op);
+  return 0;
+}
+
+int pdse_plan_size(const pdse_plan* p) { return p ? (int)p->ops.size() : -1; }
+
+int pdse_plan_run_range(pdse_plan* p, int begin, int end, pdse_stream_t s) {
+  if (!p || begin < 0 || end > (int)p->ops.size() || begin > end) {
+    pdse_set_error("plan_run_range: bad range");
+    return 1;
+  }
+  for (int i = begin; i < end; ++i)
+    if (int rc = launch_op(p->ops[i], (hipStream_t)s)) return rc;
+  return 0;
+}
+
+int pdse_plan_run(pdse_plan* p, pdse_stream_t s) { return pdse_plan_run_range(p, 0, p ? (int)p->ops.size() : 0, s); }
+
+int pdse_plan_build_graph(pdse_plan* p, pdse_stream_t s) {
+  if (!p || !s) {
+    pdse_set_error("plan_build_graph: needs a plan and a non-default stream");
+    return 1;
+  }
+  if (p->exec) return 0;
+  hipStream_t st = (hipStream_t)s;
+  if (pdse_check_hip(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal), "begin capture")) return 1;
+  int rc = pdse_plan_run(p, s);
+  hipGraph_t g = nullptr;
+  hipError_t e = hipStreamEndCapture(st, &g);
+  if (rc) {
+    if (g) (void)hipGraphDestroy(g);
+    return rc;
+  }
+  if (pdse_check_hip(e, "end capture")) return 1;
+  hipGraphExec_t ex = nullptr;
+  if (pdse_check_hip(hipGraphInstantiate(&ex, g, nullptr, nullptr, 0), "graph instantiate")) {
+    (void)hipGraphDestroy(g);
+    return 1;
+  }
+  p->graph = g;
+  p->exec = ex;
+  return 0;
+}
+
+int pdse_plan_launch_graph(pdse_plan* p, pdse_stream_t s) {
+  if (!p || !p->exec) {
+    pdse_set_error("plan_launch_graph: no captured graph");
+    return 1;
+  }
+  return pdse_check_hip(hipGraphLaunch(p->exec, (hipStream_t)s), "graph launch");
+}
+
+int pdse_plan_time_ops(pdse_plan* p, int begin, int end, pdse_stream_t s, float* ms_out) {
+  if (!p || !ms_out || begin < 0 || end > (int)p->ops.size() || begin > end) {
+    pdse_set_error("plan_time_ops: bad argument");
+    return 1;
+  }
+  hipStream_t st = (hipStream_t)s;
+  const int n = end - begin;
+  std::vector<hipEvent_t> ev((size_t)n + 1);
+  for (auto& e : ev)
+    if (pdse_check_hip(hipEventCreate(&e), "event create")) return 1;
+  int rc = 0;
+  (void)hipEventRecord(ev[0], st);
+  for (int i = 0; i < n && !rc; ++i) {
+    rc = launch_op(p->ops[begin + i], st);
+    (void)hipEventRecord(ev[i + 1], st);
+  }
+  if (!rc) rc = pdse_check_hip(hipEventSynchronize(ev[n]), "event sync");
+  for (int i = 0; i < n && !rc; ++i) rc = pdse_check_hip(hipEventElapsedTime(&ms_out[i], ev[i], ev[i + 1]), "elapsed");
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  return rc;
+}
+
+int pdse_plan_time_tag(pdse_plan* p, int tag, pdse_stream_t s, float* ms_out, int* count_out) {
+  if (!p || !ms_out || !count_out) {
+    pdse_set_error("plan_time_tag: bad argument");
+    return 1;
+  }
+  hipStream_t st = (hipStream_t)s;
+  std::vector<hipEvent_t> ev;
+  int rc = 0, cnt = 0;
+  for (size_t i = 0; i < p->ops.size() && !rc; ++i) {
+    const bool hit = p->ops[i].tag == tag;
+    if (hit) {
+      hipEvent_t a, b;
+      if (pdse_check_hip(hipEventCreate(&a), "event create") || pdse_check_hip(hipEventCreate(&b), "event create")) {
+        rc = 1;
+        break;
+      }
+      (void)hipEventRecord(a, st);
+      rc = launch_op(p->ops[i], st);
+      (void)hipEventRecord(b, st);
+      ev.push_back(a);
+      ev.push_back(b);
+      ++cnt;
+    } else {
+      rc = launch_op(p->ops[i], st);
+    }
+  }
+  if (!rc) rc = pdse_check_hip(hipStreamSynchronize(st), "stream sync");
+  float total = 0.f;
+  for (size_t i = 0; i + 1 < ev.size() && !rc; i += 2) {
+    float ms = 0.f;
+    rc = pdse_check_hip(hipEventElapsedTime(&ms, ev[i], ev[i + 1]), "elapsed");
+    total += ms;
+  }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  *ms_out = total;
+  *count_out = cnt;
+  return rc;
+}
+
+void pdse_plan_destroy(pdse_plan* p) {
+  if (!p) return;
+  if (p->exec) (void)hipGraphExecDestroy(p->exec);
+  if (p->graph) (void)hipGraphDestroy(p->graph);
+  delete p;
+}
+
+}  // extern "C"

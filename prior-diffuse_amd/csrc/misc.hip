@@ -1,0 +1,321 @@
+// misc.hip — the HBM-bound and small kernels around the convolution stack:
+// diffusion-step embedding, reverse-step update, sqrt/square companding, waveform
+// front-end, overlap-add back-end, --sigma mask, LayerNorm.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pdse.h"
+#include "pdse_internal.h"
+
+#define REQ(cond, msg)          \
+  do {                          \
+    if (!(cond)) {              \
+      pdse_set_error(msg);      \
+      return 1;                 \
+    }                           \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------
+// Diffusion-step embedding (model/diff3.py:62-95) and the 15 folded per-stage time biases.
+// One 512-thread workgroup per batch item; the three matrices are stored transposed so that
+// thread j streams column j with coalesced reads.  Tiny (1.3 MFLOP per item): latency only.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float silu_f(float x) { return x * (1.0f / (1.0f + expf(-x))); }
+
+__global__ __launch_bounds__(512) void time_embed_kernel(const pdse_time_desc d) {
+  __shared__ float x0[128];
+  __shared__ float y1[512];
+  __shared__ float y2[512];
+  const int b = blockIdx.x, j = threadIdx.x;
+  const float t = d.t[b];
+  if (j < 128) {
+    // low + (high - low) * (t - floor(t)); an integral t reads one table row exactly
+    float fl = floorf(t), ce = ceilf(t);
+    int lo = (int)fl, hi = (int)ce;
+    lo = min(max(lo, 0), d.max_steps - 1);
+    hi = min(max(hi, 0), d.max_steps - 1);
+    const float low = d.table[lo * 128 + j], high = d.table[hi * 128 + j];
+    x0[j] = low + (high - low) * (t - fl);
+  }
+  __syncthreads();
+  float s = d.b1[j];
+  for (int i = 0; i < 128; ++i) s += d.p1T[i * 512 + j] * x0[i];
+  y1[j] = silu_f(s);
+  __syncthreads();
+  s = d.b2[j];
+  for (int i = 0; i < 512; ++i) s += d.p2T[i * 512 + j] * y1[i];
+  s = silu_f(s);
+  y2[j] = s;
+  if (d.temb) d.temb[(size_t)b * 512 + j] = s;
+  __syncthreads();
+  for (int o = j; o < d.NF; o += 512) {
+    float a = d.bf[o];
+    for (int i = 0; i < 512; ++i) a += d.wfT[(size_t)i * d.NF + o] * y2[i];
+    d.out[(size_t)b * d.NF + o] = a;
+  }
+}
+
+int pdse_time_launch(const pdse_time_desc* d, hipStream_t s) {
+  REQ(d && d->t && d->table && d->p1T && d->b1 && d->p2T && d->b2 && d->out, "time_embed: null pointer");
+  REQ(d->B > 0 && d->max_steps > 0 && d->NF >= 0, "time_embed: bad sizes");
+  REQ(d->NF == 0 || (d->wfT && d->bf), "time_embed: folded weights missing");
+  hipLaunchKernelGGL(time_embed_kernel, dim3(d->B), dim3(512), 0, s, *d);
+  return pdse_check_launch("time_embed");
+}
+
+// ---------------------------------------------------------------------------------------
+// Reverse-step arithmetic (trainer/complex_ddpm_trainer.py:942, :977, :995-996).  Every
+// product/sum is rounded separately (no fma contraction) so the update is bit-identical to
+// the reference's chain of fp32 tensor ops.  HBM-bound: 16-byte accesses when aligned.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float ew_one(int op, float a, float b, float c, float s0, float s1, float s2) {
+  switch (op) {
+    case PDSE_EW_DIV: return __fdiv_rn(a, s0);
+    case PDSE_EW_UPDATE: return __fmul_rn(s0, __fsub_rn(a, __fmul_rn(s1, b)));
+    case PDSE_EW_UPDATE_FINAL:
+      return __fmul_rn(__fadd_rn(__fmul_rn(s0, __fsub_rn(a, __fmul_rn(s1, b))), c), s2);
+    case PDSE_EW_ADD_MUL: return __fmul_rn(__fadd_rn(a, b), s0);
+    default: return a;
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void ew_kernel(const pdse_ew_desc d) {
+  const int64_t nv = d.n / VEC;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
+    if constexpr (VEC == 4) {
+      const float4 a = reinterpret_cast<const float4*>(d.a)[i];
+      float4 b = make_float4(0, 0, 0, 0), c = make_float4(0, 0, 0, 0);
+      if (d.b) b = reinterpret_cast<const float4*>(d.b)[i];
+      if (d.c) c = reinterpret_cast<const float4*>(d.c)[i];
+      float4 o;
+      o.x = ew_one(d.op, a.x, b.x, c.x, d.s0, d.s1, d.s2);
+      o.y = ew_one(d.op, a.y, b.y, c.y, d.s0, d.s1, d.s2);
+      o.z = ew_one(d.op, a.z, b.z, c.z, d.s0, d.s1, d.s2);
+      o.w = ew_one(d.op, a.w, b.w, c.w, d.s0, d.s1, d.s2);
+      reinterpret_cast<float4*>(d.out)[i] = o;
+    } else {
+      d.out[i] = ew_one(d.op, d.a[i], d.b ? d.b[i] : 0.f, d.c ? d.c[i] : 0.f, d.s0, d.s1, d.s2);
+    }
+  }
+  if constexpr (VEC == 4) {
+    // scalar tail
+    const int64_t i = nv * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < d.n) d.out[i] = ew_one(d.op, d.a[i], d.b ? d.b[i] : 0.f, d.c ? d.c[i] : 0.f, d.s0, d.s1, d.s2);
+  }
+}
+
+int pdse_ew_launch(const pdse_ew_desc* d, hipStream_t s) {
+  REQ(d && d->a && d->out && d->n > 0, "ew: null pointer or empty");
+  REQ(d->op >= PDSE_EW_DIV && d->op <= PDSE_EW_ADD_MUL, "ew: unknown op");
+  REQ(d->op != PDSE_EW_UPDATE || d->b, "ew: UPDATE needs b");
+  REQ(d->op != PDSE_EW_UPDATE_FINAL || (d->b && d->c), "ew: UPDATE_FINAL needs b and c");
+  REQ(d->op != PDSE_EW_ADD_MUL || d->b, "ew: ADD_MUL needs b");
+  const uintptr_t al = (uintptr_t)d->a | (uintptr_t)d->b | (uintptr_t)d->c | (uintptr_t)d->out;
+  const bool vec = (al & 15) == 0;
+  const int64_t work = vec ? (d->n + 3) / 4 : d->n;
+  int64_t blocks = (work + 255) / 256;
+  if (blocks > 2048) blocks = 2048;  // 256 CUs x 8 blocks, grid-stride the rest
+  if (blocks < 1) blocks = 1;
+  if (vec)
+    hipLaunchKernelGGL(ew_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, *d);
+  else
+    hipLaunchKernelGGL(ew_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, *d);
+  return pdse_check_launch("ew");
+}
+
+// ---------------------------------------------------------------------------------------
+// Companding of [B,2,T,F]: phase kept, magnitude raised to 0.5 (front-end, :931-937) or 2
+// (back-end, :1004-1008).  cos/sin(atan2(im,re)) is evaluated as re/|X|, im/|X| (1,0 at 0).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void compand_kernel(const pdse_compand_desc d) {
+  const int64_t total = (int64_t)d.B * d.plane;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t b = i / d.plane, q = i - b * d.plane;
+    const int64_t ire = (2 * b) * d.plane + q, iim = ire + d.plane;
+    const float re = d.in[ire], im = d.in[iim];
+    const float mag = sqrtf(__fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im)));
+    float cr = 1.f, sr = 0.f;
+    if (mag > 0.f) {
+      cr = re / mag;
+      sr = im / mag;
+    }
+    const float m2 = d.mode == 0 ? sqrtf(mag) : mag * mag;
+    d.out[ire] = m2 * cr;
+    d.out[iim] = m2 * sr;
+  }
+}
+
+int pdse_compand_launch(const pdse_compand_desc* d, hipStream_t s) {
+  REQ(d && d->in && d->out && d->B > 0 && d->plane > 0, "compand: bad descriptor");
+  REQ(d->mode == 0 || d->mode == 1, "compand: mode must be 0 or 1");
+  int64_t blocks = ((int64_t)d->B * d->plane + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(compand_kernel, dim3((unsigned)blocks), dim3(256), 0, s, *d);
+  return pdse_check_launch("compand");
+}
+
+// ---------------------------------------------------------------------------------------
+// Waveform front-end (:922-923 + torch.stft center=True reflect padding): one workgroup per
+// utterance computes c = sqrt(sum x^2 / L), then writes reflect_pad(x / c).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void wavprep_kernel(const pdse_wavprep_desc d) {
+  __shared__ float red[16];
+  __shared__ float cval;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* x = d.wav + (size_t)b * d.L;
+  float c = 1.f;
+  if (d.normalize) {
+    float ss = 0.f;
+    for (int i = tid; i < d.L; i += 1024) ss += x[i] * x[i];
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_down(ss, o);
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    if (tid == 0) {
+      float tot = 0.f;
+      for (int w = 0; w < 16; ++w) tot += red[w];
+      cval = sqrtf(tot / (float)d.L);
+    }
+    __syncthreads();
+    c = cval;
+  }
+  if (tid == 0 && d.c) d.c[b] = c;
+  const int Lp = d.L + 2 * d.pad;
+  float* o = d.xpad + (size_t)b * Lp;
+  for (int i = tid; i < Lp; i += 1024) {
+    int k = i - d.pad;
+    if (k < 0) k = -k;
+    if (k >= d.L) k = 2 * (d.L - 1) - k;
+    o[i] = x[k] / c;
+  }
+}
+
+int pdse_wavprep_launch(const pdse_wavprep_desc* d, hipStream_t s) {
+  REQ(d && d->wav && d->xpad && d->B > 0 && d->L > 0 && d->pad >= 0, "wavprep: bad descriptor");
+  REQ(d->pad < d->L, "wavprep: reflect padding needs pad < L");
+  hipLaunchKernelGGL(wavprep_kernel, dim3(d->B), dim3(1024), 0, s, *d);
+  return pdse_check_launch("wavprep");
+}
+
+// ---------------------------------------------------------------------------------------
+// Overlap-add + envelope normalisation + centre trim + rescale (torch.istft, :1010-1016).
+// frames[b][n][t] already carry the synthesis window; every output sample sums two frames.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ola_kernel(const pdse_ola_desc d) {
+  const int64_t total = (int64_t)d.B * d.L;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int half = d.n_fft / 2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int b = (int)(i / d.L);
+    const int n = (int)(i - (int64_t)b * d.L) + half;  // index in the un-trimmed signal
+    float acc = 0.f, env = 0.f;
+    // frames t with 0 <= n - t*hop < n_fft
+    const int t_hi = n / d.hop;
+    for (int t = t_hi; t >= 0 && n - t * d.hop < d.n_fft; --t) {
+      if (t < d.T) {
+        const int r = n - t * d.hop;
+        acc += d.frames[((size_t)b * d.n_fft + r) * d.T + t];
+        env += d.win2[r];
+      }
+    }
+    float y = env > 1e-11f ? acc / env : 0.f;
+    if (d.c) y *= d.c[b];
+    d.out[i] = y;
+  }
+}
+
+int pdse_ola_launch(const pdse_ola_desc* d, hipStream_t s) {
+  REQ(d && d->frames && d->win2 && d->out, "ola: null pointer");
+  REQ(d->B > 0 && d->T > 0 && d->L > 0 && d->n_fft > 0 && d->hop > 0, "ola: bad sizes");
+  int64_t blocks = ((int64_t)d->B * d->L + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(ola_kernel, dim3((unsigned)blocks), dim3(256), 0, s, *d);
+  return pdse_check_launch("ola");
+}
+
+// ---------------------------------------------------------------------------------------
+// --sigma mask (:951-956): per-(b,ch) plane m = |init| / max|init| / 2 + 0.5; out = a*sqrt(m).
+// |x| >= 0, so the float bit pattern orders like an unsigned integer: atomicMax on the bits.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sigma_max_kernel(const pdse_sigma_desc d) {
+  const int pl = blockIdx.y;
+  const float* x = d.init + (size_t)pl * d.plane;
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < d.plane; i += (int64_t)gridDim.x * 256)
+    m = fmaxf(m, fabsf(x[i]));
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o));
+  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int*>(d.maxbuf) + pl, __float_as_uint(m));
+}
+
+__global__ __launch_bounds__(256) void sigma_apply_kernel(const pdse_sigma_desc d) {
+  const int pl = blockIdx.y;
+  const float mx = d.maxbuf[pl];
+  const size_t base = (size_t)pl * d.plane;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < d.plane; i += (int64_t)gridDim.x * 256) {
+    float m = __fdiv_rn(fabsf(d.init[base + i]), mx);
+    m = __fadd_rn(__fdiv_rn(m, 2.0f), 0.5f);
+    d.out[base + i] = __fmul_rn(d.a[base + i], sqrtf(m));
+  }
+}
+
+int pdse_sigma_launch(const pdse_sigma_desc* d, hipStream_t s) {
+  REQ(d && d->init && d->a && d->out && d->maxbuf, "sigma: null pointer");
+  REQ(d->nplanes > 0 && d->nplanes <= 65535 && d->plane > 0, "sigma: bad sizes");
+  if (pdse_check_hip(hipMemsetAsync(d->maxbuf, 0, sizeof(float) * d->nplanes, s), "sigma memset")) return 1;
+  int bx = (int)((d->plane + 255) / 256);
+  if (bx > 64) bx = 64;
+  hipLaunchKernelGGL(sigma_max_kernel, dim3(bx, d->nplanes), dim3(256), 0, s, *d);
+  hipLaunchKernelGGL(sigma_apply_kernel, dim3(bx, d->nplanes), dim3(256), 0, s, *d);
+  return pdse_check_launch("sigma");
+}
+
+// ---------------------------------------------------------------------------------------
+// LayerNorm over rows of N <= 1024 (gcrn.py:31,35); one wavefront per row, values held in
+// registers, wave-shuffle reductions, strided (transposing) store.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ln_kernel(const pdse_ln_desc d) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t rows = (int64_t)d.B * d.T;
+  if (row >= rows) return;
+  const int b = (int)(row / d.T), t = (int)(row - (int64_t)b * d.T);
+  const float* x = d.in + row * d.N;
+  float v[16];
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int i = k * 64 + lane;
+    v[k] = i < d.N ? x[i] : 0.f;
+    sum += v[k];
+  }
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  const float mean = sum / (float)d.N;
+  float sq = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int i = k * 64 + lane;
+    const float e = i < d.N ? v[k] - mean : 0.f;
+    sq += e * e;
+  }
+  for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+  const float rstd = 1.0f / sqrtf(sq / (float)d.N + d.eps);
+  const int64_t ob = (int64_t)b * d.osb + (int64_t)t * d.os_t;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int i = k * 64 + lane;
+    if (i < d.N) {
+      const float y = (v[k] - mean) * rstd * d.gamma[i] + d.beta[i];
+      d.out[ob + (int64_t)(i / d.r) * d.os_hi + (int64_t)(i % d.r) * d.os_lo] = y;
+    }
+  }
+}
+
+int pdse_ln_launch(const pdse_ln_desc* d, hipStream_t s) {
+  REQ(d && d->in && d->gamma && d->beta && d->out, "layernorm: null pointer");
+  REQ(d->B > 0 && d->T > 0 && d->N > 0 && d->N <= 1024 && d->r > 0, "layernorm: bad sizes (N <= 1024)");
+  const int64_t rows = (int64_t)d->B * d->T;
+  hipLaunchKernelGGL(ln_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, *d);
+  return pdse_check_launch("layernorm");
+}

@@ -1,0 +1,22 @@
+// internal helpers shared by the translation units of libpdse.so (not part of the ABI)
+#ifndef PDSE_INTERNAL_H
+#define PDSE_INTERNAL_H
+#include <hip/hip_runtime.h>
+
+#include "pdse.h"
+
+void pdse_set_error(const char* msg);
+// returns 0 when the last launch was accepted, else records "<what>: <hip error>" and returns 1
+int pdse_check_launch(const char* what);
+int pdse_check_hip(hipError_t e, const char* what);
+
+int pdse_gconv_launch(const pdse_gconv_desc* d, hipStream_t s);
+int pdse_time_launch(const pdse_time_desc* d, hipStream_t s);
+int pdse_ew_launch(const pdse_ew_desc* d, hipStream_t s);
+int pdse_compand_launch(const pdse_compand_desc* d, hipStream_t s);
+int pdse_wavprep_launch(const pdse_wavprep_desc* d, hipStream_t s);
+int pdse_ola_launch(const pdse_ola_desc* d, hipStream_t s);
+int pdse_sigma_launch(const pdse_sigma_desc* d, hipStream_t s);
+int pdse_ln_launch(const pdse_ln_desc* d, hipStream_t s);
+int pdse_lstm_launch(const pdse_lstm_desc* d, hipStream_t s);
+#endif

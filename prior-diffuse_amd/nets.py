@@ -1,0 +1,576 @@
+"""Plan builders: turn reference ``state_dict``s into recorded operator sequences
+(include/pdse.h plans) for the networks and signal-processing stages on the path.
+
+  EpsNetPlan     DiffUNet1.forward(x, x_init, t)        model/diff3.py:37-57
+  (same builder, ``time_cond=False``)  prior DiffUNet   model/diff.py:23-33
+  GcrnPlan       GCRN.forward                           model/gcrn.py:136-166
+  StftPlan / IstftPlan   front/back end                 trainer/complex_ddpm_trainer.py:921-937, :1004-1016
+
+Every tensor lives in HBM for the lifetime of the plan (weights packed once, workspaces
+allocated once per (B, T)); a plan run is a pure sequence of kernel launches with no
+allocation and no host synchronisation, so it can be captured into a hipGraph.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import packing as P
+
+F0 = 161
+BIG = 1 << 30
+
+# tags for bench/roofline attribution
+TAG_NONE, TAG_EPS_BLOCK, TAG_EPS_CONV1, TAG_TCM, TAG_PRIOR, TAG_LSTM, TAG_SIGNAL, TAG_EW = range(8)
+
+
+class Ctx:
+    """Device-memory helper: torch tensors for storage, raw pointers for the ABI."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.keep = []
+
+    def alloc(self, *shape, zero=False):
+        t = (torch.zeros if zero else torch.empty)(*shape, dtype=torch.float32, device=self.device)
+        self.keep.append(t)
+        return t
+
+    def up(self, arr, dtype=np.float32):
+        t = torch.from_numpy(np.ascontiguousarray(arr, dtype=dtype)).to(self.device)
+        self.keep.append(t)
+        return t
+
+    @staticmethod
+    def ptr(t, off=0):
+        return 0 if t is None else t.data_ptr() + 4 * int(off)
+
+
+class PlanBase:
+    def __init__(self, ctx, plan=None):
+        self.ctx = ctx
+        self.descs = []  # python-side copy of every descriptor (tests replay these on the CPU emulator)
+        self.plan = plan if plan is not None else (L.Plan() if ctx.device.type == "cuda" else None)
+
+    def add(self, desc, tag=TAG_NONE):
+        self.descs.append((desc, tag))
+        if self.plan is not None:
+            self.plan.add(desc, tag)
+
+    def finish(self):
+        if self.plan is not None:
+            self.plan.keep(self.ctx.keep)
+
+    # ---- descriptor helpers -------------------------------------------------
+    def src(self, t, C_, sb, sc, st, sf, off=0, act=L.ACT_NONE):
+        return L.Src(Ctx.ptr(t, off), sb, sc, st, sf, C_, act)
+
+    def gconv(self, *, in0, in1=None, Tin, Fin, taps, sf_in, wk0, wk1=None, Cout, bias0=None, bias0_sb=0,
+              bias1=None, bias1_sb=0, epi=L.EPI_LINEAR, act=L.ACT_NONE, act_slope=0.0, post=None,
+              padrow=None, padrow_sb=0, padrow_off=0, xf=None, cin1=False, chain=None, resid=None, out,
+              out_strides, out_off=0, out_cr=1, B, Tout, Fout, tag=TAG_NONE, bias0_off=0):
+        """wk0/wk1: [K, Cout] float64 k-major matrices (packed here); biases/post: numpy or device tensors."""
+        ctx = self.ctx
+        d = L.GconvDesc()
+        d.in0 = in0
+        d.in1 = in1 if in1 is not None else L.Src(0, 0, 0, 0, 0, 0, 0)
+        d.Tin, d.Fin = Tin, Fin
+        d.padrow, d.padrow_sb = Ctx.ptr(padrow, padrow_off), padrow_sb
+        tp = ctx.up(P.taps_array(taps), np.int32)
+        d.taps, d.ntaps, d.sf_in = tp.data_ptr(), len(taps), sf_in
+        if xf is not None:
+            d.xf_mode = xf["mode"]
+            d.xf_scale0, d.xf_shift0 = ctx.up(xf["scale0"]).data_ptr(), ctx.up(xf["shift0"]).data_ptr()
+            d.xf_slope0 = float(xf["slope0"])
+            if xf["mode"] == 2:
+                d.xf_scale1, d.xf_shift1 = ctx.up(xf["scale1"]).data_ptr(), ctx.up(xf["shift1"]).data_ptr()
+                d.xf_slope1 = float(xf["slope1"])
+        d.cin1 = 1 if cin1 else 0
+        w0 = P.pack_a(wk0)
+        d.w0, d.ksteps, d.Cout = ctx.up(w0).data_ptr(), w0.shape[1], Cout
+        if wk1 is not None:
+            d.w1 = ctx.up(P.pack_a(wk1)).data_ptr()
+
+        def dev(x):
+            if x is None:
+                return None
+            return x if torch.is_tensor(x) else ctx.up(x)
+
+        d.bias0, d.bias0_sb = Ctx.ptr(dev(bias0), bias0_off), bias0_sb
+        d.bias1, d.bias1_sb = Ctx.ptr(dev(bias1)), bias1_sb
+        d.epi, d.act, d.act_slope = epi, act, float(act_slope)
+        if post is not None:
+            d.post_scale, d.post_shift = ctx.up(post[0]).data_ptr(), ctx.up(post[1]).data_ptr()
+        if chain is not None:
+            d.C2 = chain["C2"]
+            d.wlc, d.wrc = ctx.up(P.pack_chain(chain["wlc"])).data_ptr(), ctx.up(P.pack_chain(chain["wrc"])).data_ptr()
+            d.blc, d.brc = ctx.up(chain["blc"]).data_ptr(), ctx.up(chain["brc"]).data_ptr()
+            if chain["C2"] == 1:
+                d.wc2 = ctx.up(np.asarray(chain["wc2"], np.float64).reshape(32)).data_ptr()
+            else:
+                d.wc2 = ctx.up(P.pack_chain(chain["wc2"])).data_ptr()
+            d.bc2 = ctx.up(chain["bc2"]).data_ptr()
+        d.resid = Ctx.ptr(resid)
+        d.out = Ctx.ptr(out)
+        d.out_sb, d.out_sc_hi, d.out_sc_lo, d.out_st, d.out_sf = out_strides
+        d.out_off, d.out_cr = out_off, out_cr
+        d.B, d.Tout, d.Fout = B, Tout, Fout
+        self.add(d, tag)
+        return d
+
+
+def nchw(C_, T, F):
+    """(sb, sc, st, sf) of a contiguous [B, C, T, F] tensor."""
+    return C_ * T * F, T * F, F, 1
+
+
+def nchw_out(C_, T, F):
+    """(out_sb, out_sc_hi, out_sc_lo, out_st, out_sf) of a contiguous [B, C, T, F] output."""
+    return C_ * T * F, T * F, 0, F, 1
+
+
+# ==========================================================================
+# DiffUNet1 / DiffUNet
+# ==========================================================================
+class EpsNetPlan(PlanBase):
+    """ε-network (``time_cond=True``) or prior DiffUNet (``time_cond=False``).
+
+    Buffers: x, x_init (inputs, [B,2,T,161]); t ([nsteps][B] steps); eps / out ([B,2,T,161]).
+    ``build_step(i)`` appends the operators of one forward at diffusion step row i.
+    """
+
+    ENC_F = [161, 79, 39, 19, 9, 4]
+    NSLOT = 16  # 15 stages + en1 real-row bias
+
+    def __init__(self, ctx, sd, B, T, time_cond=True, nsteps=1, plan=None, table=None):
+        super().__init__(ctx, plan)
+        self.sd, self.B, self.T, self.time_cond, self.nsteps = sd, B, T, time_cond, nsteps
+        a = ctx.alloc
+        self.x = a(B, 2, T, F0)
+        self.x_init = a(B, 2, T, F0) if time_cond else None
+        self.out = a(B, 2, T, F0)
+        self.H = a(B, 32, T, F0)                     # conv1 output of the current block (largest: F=161)
+        self.en = [a(B, 64, T, f) for f in self.ENC_F[1:5]] + [a(B, 64, 4, T)]  # en5 stored [B,64,4,T]
+        self.tcm_a, self.tcm_b = a(B, 256, T), a(B, 256, T)
+        self.tcm_h, self.tcm_g = a(B, 64, T), a(B, 64, T)
+        self.dec = [a(B, 64, T, 79), a(B, 64, T, 79)]  # ping-pong decoder activations (largest F=79)
+        if time_cond:
+            self.tsteps = a(nsteps, B, zero=True)
+            self.tbias = a(nsteps, B, self.NSLOT * 32)
+            self.temb = a(nsteps, B, 512)
+            self._prep_time(table)
+
+    # ---- weights helpers ------------------------------------------------
+    def w(self, k):
+        return P._np(self.sd[k])
+
+    def _stage_fold(self):
+        """Per stage k: (W1 [32,Cin], b1 [32], Wtp [Cin,512], btp [Cin])."""
+        st = []
+        for k in range(1, 6):
+            W1 = self.w("en.conv%d.conv1.weight" % k)[:, :, 0, 0]
+            st.append((W1, self.w("en.conv%d.conv1.bias" % k), "en.tp%d" % k))
+        for de in ("de_real", "de_imag"):
+            for k in (5, 4, 3, 2, 1):
+                p = "%s.de%d.0" % (de, k)
+                W1 = self.w(p + ".conv1.weight")[:, :, 0, 0].T
+                st.append((W1, self.w(p + ".conv1.bias"), p + ".tp"))
+        return st
+
+    def _prep_time(self, table):
+        ctx = self.ctx
+        if table is None:
+            # non-persistent buffer of the reference, rebuilt exactly as model/diff3.py:89-93 does (fp32 torch ops)
+            steps = torch.arange(50).unsqueeze(1)
+            dims = torch.arange(64).unsqueeze(0)
+            tb = steps * 10.0 ** (dims * 4.0 / 63.0)
+            table = torch.cat([torch.sin(tb), torch.cos(tb)], dim=1)
+        self.table = ctx.up(table.numpy())
+        wf, bf = [], []
+        for W1, b1, tp in self._stage_fold():
+            Wtp, btp = self.w(tp + ".weight"), self.w(tp + ".bias")
+            wf.append(W1 @ Wtp)
+            bf.append(b1 + W1 @ btp)
+        # slot 15: en1 real rows also carry W1 · b_preprocess (the pad row does not, diff3.py:145-147)
+        W1 = self.w("en.conv1.conv1.weight")[:, :, 0, 0]
+        wf.append(wf[0])
+        bf.append(bf[0] + W1 @ self.w("preprocess.conv.bias"))
+        WF, BF = np.concatenate(wf, 0), np.concatenate(bf, 0)      # [512, 512], [512]
+        self.t_p1T = ctx.up(self.w("time_embedding.projection1.weight").T)
+        self.t_b1 = ctx.up(self.w("time_embedding.projection1.bias"))
+        self.t_p2T = ctx.up(self.w("time_embedding.projection2.weight").T)
+        self.t_b2 = ctx.up(self.w("time_embedding.projection2.bias"))
+        self.t_wfT, self.t_bf = ctx.up(WF.T), ctx.up(BF)
+
+    def build_time(self):
+        """One launch computes the folded biases of all recorded diffusion steps."""
+        d = L.TimeDesc()
+        d.t, d.table = self.tsteps.data_ptr(), self.table.data_ptr()
+        d.p1T, d.b1, d.p2T, d.b2 = (self.t_p1T.data_ptr(), self.t_b1.data_ptr(), self.t_p2T.data_ptr(),
+                                    self.t_b2.data_ptr())
+        d.wfT, d.bf = self.t_wfT.data_ptr(), self.t_bf.data_ptr()
+        d.out, d.temb = self.tbias.data_ptr(), self.temb.data_ptr()
+        d.B, d.NF, d.max_steps = self.nsteps * self.B, self.NSLOT * 32, 50
+        self.add(d, TAG_EW)
+
+    # ---- blocks -----------------------------------------------------------
+    def _bias_for(self, step, slot):
+        """(tensor-or-array, element offset, batch stride) of a stage's conv1 bias."""
+        return self.tbias, (step * self.B) * self.NSLOT * 32 + slot * 32, self.NSLOT * 32
+
+    def _biconvglu(self, step, k, src_x, src_init, Fin, out_t, out_strides):
+        """Encoder stage k (model/diff3.py:144-166 + :307-326 + BN + PReLU)."""
+        B, T = self.B, self.T
+        p = "en.conv%d" % k
+        kw = 5 if k == 1 else 3
+        Fout = (Fin - kw) // 2 + 1
+        W1 = self.w(p + ".conv1.weight")[:, :, 0, 0]                       # [32, Cin]
+        if k == 1 and self.time_cond:
+            Wp = self.w("preprocess.conv.weight")[:, :, 0, 0]               # [2, 4]: fold Preprocess into conv1
+            W1 = W1 @ Wp
+        if self.time_cond:
+            tb, off_real, sbb = self._bias_for(step, 15 if k == 1 else k - 1)
+            _, off_pad, _ = self._bias_for(step, k - 1)
+            bias0, pad = tb, tb
+        else:
+            b1 = self.ctx.up(self.w(p + ".conv1.bias"))
+            bias0, pad, off_real, off_pad, sbb = b1, b1, 0, 0, 0
+        self.gconv(in0=src_x, in1=src_init, Tin=T, Fin=Fin, taps=[(0, 0)], sf_in=1, wk0=W1.T, Cout=32,
+                   bias0=bias0, bias0_off=off_real, bias0_sb=sbb, out=self.H, out_strides=nchw_out(32, T, Fin),
+                   B=B, Tout=T, Fout=Fin, tag=TAG_EPS_CONV1)
+        kk, taps = P.conv_taps(2, kw, 1)
+        post = P.bn_fold(self.sd, "en.en%d.0" % k)
+        chain = dict(C2=64, wlc=self.w(p + ".l_conv.weight")[:, :, 0, 0], blc=self.w(p + ".l_conv.bias"),
+                     wrc=self.w(p + ".r_conv.weight")[:, :, 0, 0], brc=self.w(p + ".r_conv.bias"),
+                     wc2=self.w(p + ".conv2.weight")[:, :, 0, 0], bc2=self.w(p + ".conv2.bias"))
+        self.gconv(in0=self.src(self.H, 32, *nchw(32, T, Fin)), Tin=T, Fin=Fin, taps=taps, sf_in=2,
+                   wk0=P.conv_kmat(self.sd[p + ".l.weight"], kk), wk1=P.conv_kmat(self.sd[p + ".r.weight"], kk),
+                   Cout=32, bias0=self.w(p + ".l.bias"), bias1=self.w(p + ".r.bias"), epi=L.EPI_BIGLU,
+                   act=L.ACT_PRELU, act_slope=float(self.w("en.en%d.1.weight" % k)[0]), post=post,
+                   padrow=pad, padrow_off=off_pad, padrow_sb=sbb, chain=chain, out=out_t,
+                   out_strides=out_strides, B=B, Tout=T, Fout=Fout, tag=TAG_EPS_BLOCK)
+        return Fout
+
+    def _biconvtransglu(self, step, slot, p, k, in0, in1, Fin, out_t, out_strides_fn, bn_prefix, prelu_key):
+        """Decoder stage (model/diff3.py:205-212 + :329-351, last frame chomped, BN, PReLU)."""
+        B, T = self.B, self.T
+        kw = 5 if k == 1 else 3
+        Fout = 2 * (Fin - 1) + kw
+        W1 = self.w(p + ".conv1.weight")[:, :, 0, 0].T                      # [32, 128]
+        if self.time_cond:
+            tb, off, sbb = self._bias_for(step, slot)
+            bias0 = tb
+        else:
+            bias0, off, sbb = self.w(p + ".conv1.bias"), 0, 0
+        self.gconv(in0=in0, in1=in1, Tin=T, Fin=Fin, taps=[(0, 0)], sf_in=1, wk0=W1.T, Cout=32, bias0=bias0,
+                   bias0_off=off, bias0_sb=sbb, out=self.H, out_strides=nchw_out(32, T, Fin), B=B, Tout=T,
+                   Fout=Fin, tag=TAG_EPS_CONV1)
+        C2 = 64 if k > 1 else 1
+        post = P.bn_fold(self.sd, bn_prefix) if bn_prefix else None
+        wc2 = self.w(p + ".conv2.weight")[:, :, 0, 0].T                     # [C2, 32]
+        chain = dict(C2=C2, wlc=self.w(p + ".l_conv.weight")[:, :, 0, 0].T, blc=self.w(p + ".l_conv.bias"),
+                     wrc=self.w(p + ".r_conv.weight")[:, :, 0, 0].T, brc=self.w(p + ".r_conv.bias"),
+                     wc2=wc2, bc2=self.w(p + ".conv2.bias"))
+        for phase in (0, 1):
+            kk, taps = P.convT_phase_taps(2, kw, phase)
+            Fo = (Fout - phase + 1) // 2
+            osb, osc, _, ost, osf = out_strides_fn(Fout)
+            self.gconv(in0=self.src(self.H, 32, *nchw(32, T, Fin)), Tin=T, Fin=Fin, taps=taps, sf_in=1,
+                       wk0=P.convT_kmat(self.sd[p + ".l.weight"], kk), wk1=P.convT_kmat(self.sd[p + ".r.weight"], kk),
+                       Cout=32, bias0=self.w(p + ".l.bias"), bias1=self.w(p + ".r.bias"), epi=L.EPI_BIGLU,
+                       act=L.ACT_PRELU if prelu_key else L.ACT_NONE,
+                       act_slope=float(self.w(prelu_key)[0]) if prelu_key else 0.0, post=post, chain=chain,
+                       out=out_t, out_strides=(osb, osc, 0, ost, 2 * osf), out_off=phase * osf + self._out_off,
+                       B=B, Tout=T, Fout=Fo, tag=TAG_EPS_BLOCK)
+        return Fout
+
+    def _residual(self, p, dil, xin, xout):
+        """TCM residual block (model/diff3.py:215-257) over [B,256,T] (T on the lanes)."""
+        B, T = self.B, self.T
+        s256 = (256 * T, T, 0, 1)       # sb, sc, st, sf  ("bin" axis = time)
+        s64 = (64 * T, T, 0, 1)
+        o256 = (256 * T, T, 0, 0, 1)    # out_sb, sc_hi, sc_lo, st, sf
+        o64 = (64 * T, T, 0, 0, 1)
+        self.gconv(in0=self.src(xin, 256, *s256), Tin=1, Fin=T, taps=[(0, 0)], sf_in=1,
+                   wk0=self.w(p + ".conv1.weight")[:, :, 0].T, Cout=64, bias0=self.w(p + ".conv1.bias"),
+                   out=self.tcm_h, out_strides=o64, B=B, Tout=1, Fout=T, tag=TAG_TCM)
+        taps = [(0, (k - 2) * dil) for k in range(5)]
+
+        def km(br):
+            w = self.w(p + "." + br + ".2.weight")                          # [64, 64, 5]
+            return np.concatenate([w[:, :, k].T for k in range(5)], axis=0)
+
+        sm, hm = P.bn_fold(self.sd, p + ".mainbranch.1")
+        sk, hk = P.bn_fold(self.sd, p + ".maskbranch.1")
+        xf = dict(mode=2, scale0=sm, shift0=hm, slope0=self.w(p + ".mainbranch.0.weight")[0],
+                  scale1=sk, shift1=hk, slope1=self.w(p + ".maskbranch.0.weight")[0])
+        self.gconv(in0=self.src(self.tcm_h, 64, *s64), Tin=1, Fin=T, taps=taps, sf_in=1, wk0=km("mainbranch"),
+                   wk1=km("maskbranch"), Cout=64, bias0=self.w(p + ".mainbranch.2.bias"),
+                   bias1=self.w(p + ".maskbranch.2.bias"), epi=L.EPI_GLU, xf=xf, out=self.tcm_g,
+                   out_strides=o64, B=B, Tout=1, Fout=T, tag=TAG_TCM)
+        s2, h2 = P.bn_fold(self.sd, p + ".conv2.1")
+        xf2 = dict(mode=1, scale0=s2, shift0=h2, slope0=self.w(p + ".conv2.0.weight")[0])
+        self.gconv(in0=self.src(self.tcm_g, 64, *s64), Tin=1, Fin=T, taps=[(0, 0)], sf_in=1,
+                   wk0=self.w(p + ".conv2.2.weight")[:, :, 0].T, Cout=256, bias0=self.w(p + ".conv2.2.bias"),
+                   xf=xf2, resid=xin, out=xout, out_strides=o256, B=B, Tout=1, Fout=T, tag=TAG_TCM)
+
+    def build_step(self, step=0, x=None, x_init=None, out=None):
+        """Append one forward.  x / x_init / out default to the plan's own buffers.
+
+        The first call packs and uploads the weights; later calls with the same buffers
+        re-use those descriptors and only re-point the per-step time biases."""
+        B, T = self.B, self.T
+        x = self.x if x is None else x
+        out = self.out if out is None else out
+        x_init = self.x_init if x_init is None else x_init
+        key = (x.data_ptr(), 0 if x_init is None else x_init.data_ptr(), out.data_ptr())
+        tmpl = getattr(self, "_tmpl", None)
+        if tmpl is not None and tmpl[0] == key and self.time_cond:
+            _, step0, items = tmpl
+            lo = self.tbias.data_ptr()
+            hi = lo + self.tbias.numel() * 4
+            delta = (step - step0) * B * self.NSLOT * 32 * 4
+            for d, tag in items:
+                d2 = type(d).from_buffer_copy(d)
+                if isinstance(d2, L.GconvDesc):
+                    for f in ("bias0", "padrow"):
+                        v = getattr(d2, f)
+                        if v and lo <= v < hi:
+                            setattr(d2, f, v + delta)
+                self.add(d2, tag)
+            return out
+        begin = len(self.descs)
+        self._build_step(step, x, x_init, out)
+        self._tmpl = (key, step, list(self.descs[begin:]))
+        return out
+
+    def _build_step(self, step, x, x_init, out):
+        B, T = self.B, self.T
+        s2 = nchw(2, T, F0)
+        # encoder: stage 1 reads (x, x_init) through the folded Preprocess 1x1
+        src_x = self.src(x, 2, *s2)
+        src_i = self.src(x_init, 2, *s2) if self.time_cond else None
+        Fin = F0
+        for k in range(1, 6):
+            if k < 5:
+                o, ostr = self.en[k - 1], nchw_out(64, T, self.ENC_F[k])
+            else:
+                o, ostr = self.en[4], (64 * 4 * T, 4 * T, 0, 1, T)           # [B,64,4,T]: channel c*4+f of [B,256,T]
+            Fin = self._biconvglu(step, k, src_x, src_i, Fin, o, ostr)
+            src_x, src_i = self.src(o, 64, *nchw(64, T, Fin)), None
+        # TCMs over [B,256,T]
+        cur, nxt = self.en[4], self.tcm_a
+        for i in range(3):
+            for j, dil in enumerate((1, 2, 4, 8, 16, 32)):
+                self._residual("TCMs.%d.residual%d" % (i, j + 1), dil, cur, nxt)
+                cur, nxt = nxt, (self.tcm_b if nxt is self.tcm_a else self.tcm_a)
+        tcm_out = cur
+        # decoders
+        for di, de in enumerate(("de_real", "de_imag")):
+            in0 = self.src(tcm_out, 64, 256 * T, 4 * T, 1, T)               # [B,64,4,T] viewed as [B,64,T,4]
+            Fin = 4
+            for n, k in enumerate((5, 4, 3, 2, 1)):
+                skip = self.en[k - 1]
+                if k == 5:
+                    in1 = self.src(skip, 64, 256 * T, 4 * T, 1, T)
+                else:
+                    in1 = self.src(skip, 64, *nchw(64, T, self.ENC_F[k]))
+                p = "%s.de%d.0" % (de, k)
+                if k > 1:
+                    o = self.dec[n & 1]
+                    self._out_off = 0
+                    fn = lambda Fo: nchw_out(64, T, Fo)  # noqa: E731
+                    bn, pr = "%s.de%d.2" % (de, k), "%s.de%d.3.weight" % (de, k)
+                else:
+                    o = out
+                    self._out_off = di * T * F0
+                    fn = lambda Fo: nchw_out(2, T, Fo)   # noqa: E731
+                    bn, pr = None, None
+                Fin = self._biconvtransglu(step, 5 + 5 * di + n, p, k, in0, in1, Fin, o, fn, bn, pr)
+                in0 = self.src(o, 64, *nchw(64, T, Fin))
+        return out
+
+
+# ==========================================================================
+# GCRN prior
+# ==========================================================================
+class GcrnPlan(PlanBase):
+    ENC_C = [2, 16, 32, 64, 128, 256]
+    ENC_F = [161, 80, 39, 19, 9, 4]
+
+    def __init__(self, ctx, sd, B, T, plan=None):
+        super().__init__(ctx, plan)
+        self.sd, self.B, self.T = sd, B, T
+        a = ctx.alloc
+        self.Bp = (B + 31) // 32 * 32
+        self.x = a(B, 2, T, F0)
+        self.out = a(B, 2, T, F0)
+        self.e = [a(B, self.ENC_C[i + 1], T, self.ENC_F[i + 1]) for i in range(5)]
+        self.gx = a(2, T, 2048, self.Bp, zero=True)
+        self.hT = a(2, 2, 512, self.Bp, zero=True)
+        self.cst = a(2, 512, self.Bp, zero=True)
+        self.y = a(B, T, 1024)
+        self.yn = a(B, 1024, T)
+        self.glstm = a(B, 256, T, 4)
+        self.d = [a(B, 128, T, 9), a(B, 64, T, 19), a(B, 32, T, 39), a(B, 16, T, 80), a(B, 1, T, 161)]
+
+    def w(self, k):
+        return P._np(self.sd[k])
+
+    def _lstm_layer(self, layer, xproj_src_fn, y_su, y_sg):
+        B, T, Bp = self.B, self.T, self.Bp
+        whh = np.empty((2, 64, 256, 64), np.float32)
+        for g in range(2):
+            p = "glstm.%s.%d." % (layer, g)
+            in0, Tin, Fin, taps, wk, Tout, Fout, ost, osf = xproj_src_fn(g, self.w(p + "weight_ih_l0"))
+            self.gconv(in0=in0, Tin=Tin, Fin=Fin, taps=taps, sf_in=1, wk0=wk, Cout=2048,
+                       bias0=self.w(p + "bias_ih_l0") + self.w(p + "bias_hh_l0"), out=self.gx,
+                       out_strides=(1, Bp, 0, ost, osf), out_off=g * T * 2048 * Bp, B=B, Tout=Tout, Fout=Fout,
+                       tag=TAG_PRIOR)
+            W = self.w(p + "weight_hh_l0")                                   # [2048, 512], gate order i,f,g,o
+            # slice s owns hidden units 8s..8s+7: tile row i = q*8 + u  <->  W row q*512 + 8s + u
+            rows = (np.arange(4)[:, None] * 512 + np.arange(8)[None, :]).reshape(-1)   # [32]
+            for s in range(64):
+                whh[g, s] = P.pack_a(W[rows + 8 * s, :].T)[0]
+        d = L.LstmDesc()
+        d.gx, d.whh = self.gx.data_ptr(), self.ctx.up(whh).data_ptr()
+        d.hT, d.cst, d.y = self.hT.data_ptr(), self.cst.data_ptr(), self.y.data_ptr()
+        d.y_sb, d.y_st, d.y_su, d.y_sg = T * 1024, 1024, y_su, y_sg
+        d.B, d.Bp, d.T, d.H, d.G = B, Bp, T, 512, 2
+        self.add(d, TAG_LSTM)
+
+    def _ln(self, name, out_t, osb, os_hi, os_lo, os_t, r):
+        d = L.LnDesc()
+        d.in_, d.out = self.y.data_ptr(), out_t.data_ptr()
+        d.gamma, d.beta = self.ctx.up(self.w(name + ".weight")).data_ptr(), self.ctx.up(self.w(name + ".bias")).data_ptr()
+        d.osb, d.os_hi, d.os_lo, d.os_t = osb, os_hi, os_lo, os_t
+        d.B, d.T, d.N, d.r, d.eps = self.B, self.T, 1024, r, 1e-5
+        self.add(d, TAG_PRIOR)
+
+    def build(self, x=None, out=None):
+        B, T, Bp = self.B, self.T, self.Bp
+        x = self.x if x is None else x
+        out = self.out if out is None else out
+        # encoder: GluConv2d k(1,3) s(1,2) + BN + ELU (gcrn.py:138-142)
+        src = self.src(x, 2, *nchw(2, T, F0))
+        for k in range(1, 6):
+            ci, co, Fin, Fout = self.ENC_C[k - 1], self.ENC_C[k], self.ENC_F[k - 1], self.ENC_F[k]
+            kk, taps = P.conv_taps(1, 3, 0)
+            p = "conv%d" % k
+            self.gconv(in0=src, Tin=T, Fin=Fin, taps=taps, sf_in=2, wk0=P.conv_kmat(self.sd[p + ".conv1.weight"], kk),
+                       wk1=P.conv_kmat(self.sd[p + ".conv2.weight"], kk), Cout=co, bias0=self.w(p + ".conv1.bias"),
+                       bias1=self.w(p + ".conv2.bias"), epi=L.EPI_GLU, act=L.ACT_ELU, post=P.bn_fold(self.sd, "bn%d" % k),
+                       out=self.e[k - 1], out_strides=nchw_out(co, T, Fout), B=B, Tout=T, Fout=Fout, tag=TAG_PRIOR)
+            src = self.src(self.e[k - 1], co, *nchw(co, T, Fout))
+
+        # grouped LSTM (gcrn.py:22-40)
+        def proj1(g, Wih):
+            # group g = channels 128g..128g+127 of e5 [B,256,T,4]; k = f*128 + c'  <->  W_ih column c'*4 + f
+            wk = np.concatenate([Wih[:, f::4].T for f in range(4)], axis=0)
+            s = self.src(self.e[4], 128, *nchw(256, T, 4), off=128 * g * T * 4)
+            return s, T, 4, [(0, f) for f in range(4)], wk, T, 1, 2048 * Bp, 0
+
+        self._lstm_layer("lstm_list1", proj1, y_su=2, y_sg=1)               # stack(dim=-1)+flatten: index u*2+g
+        self._ln("glstm.ln1", self.yn, 1024 * T, T, 0, 1, 1)                 # -> [B,1024,T]
+
+        def proj2(g, Wih):
+            s = self.src(self.yn, 512, 1024 * T, T, 0, 1, off=512 * g * T)
+            return s, 1, T, [(0, 0)], Wih.T, 1, T, 0, 2048 * Bp
+
+        self._lstm_layer("lstm_list2", proj2, y_su=1, y_sg=512)              # cat: index g*512+u
+        self._ln("glstm.ln2", self.glstm, 256 * T * 4, T * 4, 1, 4, 4)       # j = c*4+f -> [B,256,T,4]
+
+        # two decoders (gcrn.py:150-164)
+        dec = [(5, 512, 128), (4, 256, 64), (3, 128, 32), (2, 64, 16), (1, 32, 1)]
+        for br in (1, 2):
+            in0 = self.src(self.glstm, 256, *nchw(256, T, 4))
+            in1 = self.src(self.e[4], 256, *nchw(256, T, 4))
+            Fin = 4
+            for n, (k, ci, co) in enumerate(dec):
+                p = "conv%d_t_%d" % (k, br)
+                Fout = 2 * (Fin - 1) + 3 + (1 if k == 2 else 0)
+                osb, osc, _, ost, osf = nchw_out(co, T, Fout)
+                for phase in (0, 1):
+                    kk, taps = P.convT_phase_taps(1, 3, phase)
+                    self.gconv(in0=in0, in1=in1, Tin=T, Fin=Fin, taps=taps, sf_in=1,
+                               wk0=P.convT_kmat(self.sd[p + ".conv1.weight"], kk),
+                               wk1=P.convT_kmat(self.sd[p + ".conv2.weight"], kk), Cout=co,
+                               bias0=self.w(p + ".conv1.bias"), bias1=self.w(p + ".conv2.bias"), epi=L.EPI_GLU,
+                               act=L.ACT_ELU, post=P.bn_fold(self.sd, "bn%d_t_%d" % (k, br)), out=self.d[n],
+                               out_strides=(osb, osc, 0, ost, 2 * osf), out_off=phase, B=B, Tout=T,
+                               Fout=(Fout - phase + 1) // 2, tag=TAG_PRIOR)
+                Fin = Fout
+                if k > 1:
+                    in0 = self.src(self.d[n], co, *nchw(co, T, Fout))
+                    skip = self.e[k - 2]
+                    in1 = self.src(skip, co, *nchw(co, T, Fout), act=L.ACT_ELU)   # elu(cat(.., skip)) re-applies ELU
+            # Linear(161,161) over the bins (gcrn.py:162-163): taps enumerate the input bin
+            self.gconv(in0=self.src(self.d[4], 1, *nchw(1, T, F0)), Tin=T, Fin=F0, taps=[(0, f) for f in range(F0)],
+                       sf_in=1, wk0=self.w("fc%d.weight" % br).T, Cout=F0, bias0=self.w("fc%d.bias" % br), cin1=True,
+                       out=out, out_strides=(2 * T * F0, 1, 0, F0, 0), out_off=(br - 1) * T * F0, B=B, Tout=T, Fout=1,
+                       tag=TAG_PRIOR)
+        return out
+
+
+# ==========================================================================
+# signal front / back end
+# ==========================================================================
+class StftPlan(PlanBase):
+    """wav [B,L] -> c [B], compressed spectrogram [B,2,T,161]
+    (trainer/complex_ddpm_trainer.py:921-937)."""
+
+    def __init__(self, ctx, B, L_, plan=None, normalize=True):
+        super().__init__(ctx, plan)
+        self.B, self.L = B, L_
+        self.T = 1 + L_ // 160
+        self.wav = ctx.alloc(B, L_)
+        self.xpad = ctx.alloc(B, L_ + 320)
+        self.c = ctx.alloc(B)
+        self.feat = ctx.alloc(B, 2, self.T, F0)
+        self.normalize = normalize
+
+    def build(self, feat=None):
+        B, L_, T = self.B, self.L, self.T
+        feat = self.feat if feat is None else feat
+        d = L.WavprepDesc()
+        d.wav, d.xpad, d.c = self.wav.data_ptr(), self.xpad.data_ptr(), self.c.data_ptr()
+        d.B, d.L, d.pad, d.normalize = B, L_, 160, 1 if self.normalize else 0
+        self.add(d, TAG_SIGNAL)
+        Lp = L_ + 320
+        self.gconv(in0=self.src(self.xpad, 1, Lp, 0, 0, 1), Tin=1, Fin=Lp, taps=[(0, n) for n in range(320)],
+                   sf_in=160, wk0=P.stft_kmat(320), Cout=2 * F0, cin1=True, out=feat,
+                   out_strides=(2 * T * F0, T * F0, 1, 0, F0), out_cr=F0, B=B, Tout=1, Fout=T, tag=TAG_SIGNAL)
+        c = L.CompandDesc()
+        c.in_, c.out, c.plane, c.B, c.mode = feat.data_ptr(), feat.data_ptr(), T * F0, B, 0
+        self.add(c, TAG_SIGNAL)
+        return feat
+
+
+class IstftPlan(PlanBase):
+    """compressed spectrogram [B,2,T,161] -> wav [B,L] * c
+    (trainer/complex_ddpm_trainer.py:1004-1016)."""
+
+    def __init__(self, ctx, B, T, L_, plan=None):
+        super().__init__(ctx, plan)
+        self.B, self.T, self.L = B, T, L_
+        self.spec = ctx.alloc(B, 2, T, F0)
+        self.dec = ctx.alloc(B, 2, T, F0)
+        self.frames = ctx.alloc(B, 320, T)
+        self.wav = ctx.alloc(B, L_)
+        self.win2 = ctx.up(P.hann_periodic(320) ** 2)
+
+    def build(self, spec=None, c=None):
+        B, T = self.B, self.T
+        spec = self.spec if spec is None else spec
+        cd = L.CompandDesc()
+        cd.in_, cd.out, cd.plane, cd.B, cd.mode = spec.data_ptr(), self.dec.data_ptr(), T * F0, B, 1
+        self.add(cd, TAG_SIGNAL)
+        self.gconv(in0=self.src(self.dec, 2, *nchw(2, T, F0)), Tin=T, Fin=F0, taps=[(0, f) for f in range(F0)],
+                   sf_in=1, wk0=P.istft_kmat(320), Cout=320, out=self.frames, out_strides=(320 * T, T, 0, 1, 0),
+                   B=B, Tout=T, Fout=1, tag=TAG_SIGNAL)
+        o = L.OlaDesc()
+        o.frames, o.win2, o.c, o.out = (self.frames.data_ptr(), self.win2.data_ptr(), Ctx.ptr(c), self.wav.data_ptr())
+        o.B, o.T, o.L, o.n_fft, o.hop = B, T, self.L, 320, 160
+        self.add(o, TAG_SIGNAL)
+        return self.wav

@@ -1,0 +1,129 @@
+"""Host-side weight preparation: BatchNorm folding, time-bias folding and packing of
+every weight matrix into the MFMA A-fragment order the kernels stream
+(include/pdse.h, ``pdse_gconv_desc``).  Pure numpy, float64 folding, float32 result.
+
+Fragment order (v_mfma_f32_32x32x2_f32, weights = A operand):
+    w[mtile][kstep][lane] = W[k = 2*kstep + (lane >> 5)][co = 32*mtile + (lane & 31)]
+and for a chained 1x1 product that consumes an accumulator tile as its B operand the
+k order follows the accumulator rows:  k = rho(r, lane >> 5),
+rho(r, h) = (r & 3) + 8*(r >> 2) + 4*h.
+"""
+import numpy as np
+
+BN_EPS = 1e-5
+
+_LANE = np.arange(64)
+_COL = _LANE & 31
+_H = _LANE >> 5
+RHO = np.array([[(r & 3) + 8 * (r >> 2) + 4 * h for h in (0, 1)] for r in range(16)])  # [16][2]
+
+
+def _np(x):
+    return x.detach().cpu().numpy().astype(np.float64) if hasattr(x, "detach") else np.asarray(x, np.float64)
+
+
+def pack_a(wk):
+    """wk [K, M] (k-major) -> float32 [mtiles, ksteps, 64]."""
+    wk = np.asarray(wk, np.float64)
+    K, M = wk.shape
+    ksteps, mtiles = (K + 1) // 2, (M + 31) // 32
+    pad = np.zeros((ksteps * 2, mtiles * 32))
+    pad[:K, :M] = wk
+    k_idx = 2 * np.arange(ksteps)[:, None] + _H[None, :]            # [ksteps, 64]
+    out = np.empty((mtiles, ksteps, 64), np.float32)
+    for mt in range(mtiles):
+        out[mt] = pad[k_idx, 32 * mt + _COL[None, :]]
+    return out
+
+
+def pack_chain(w):
+    """w [Mout, 32] (out x in) for a 1x1 product fed from an accumulator tile
+    -> float32 [mtiles, 16, 64] with k ordered by rho."""
+    w = np.asarray(w, np.float64)
+    M, K = w.shape
+    assert K == 32
+    mtiles = (M + 31) // 32
+    pad = np.zeros((mtiles * 32, 32))
+    pad[:M] = w
+    k_idx = RHO[:, _H]                                              # [16, 64]
+    out = np.empty((mtiles, 16, 64), np.float32)
+    for mt in range(mtiles):
+        out[mt] = pad[32 * mt + _COL[None, :], k_idx]
+    return out
+
+
+def bn_fold(sd, prefix):
+    """Eval-mode BatchNorm -> (scale, shift) with y*scale + shift."""
+    w, b = _np(sd[prefix + ".weight"]), _np(sd[prefix + ".bias"])
+    m, v = _np(sd[prefix + ".running_mean"]), _np(sd[prefix + ".running_var"])
+    scale = w / np.sqrt(v + BN_EPS)
+    return scale.astype(np.float32), (b - m * scale).astype(np.float32)
+
+
+def conv_kmat(w, taps_kk):
+    """Conv weight [Cout, Cin, kh, kw] + list of (kt, kf) -> [ntaps*Cin, Cout], k = tap*Cin + ci."""
+    w = _np(w)
+    return np.concatenate([w[:, :, kt, kf].T for kt, kf in taps_kk], axis=0)
+
+
+def convT_kmat(w, taps_kk):
+    """ConvTranspose weight [Cin, Cout, kh, kw] + (kt, kf) list -> [ntaps*Cin, Cout]."""
+    w = _np(w)
+    return np.concatenate([w[:, :, kt, kf] for kt, kf in taps_kk], axis=0)
+
+
+def conv_taps(kh, kw, top_pad):
+    """Strided Conv2d k=(kh,kw) on an input padded by ``top_pad`` frames on top:
+    weight index (kt,kf) reads frame t + kt - top_pad, bin j*stride + kf."""
+    kk = [(kt, kf) for kt in range(kh) for kf in range(kw)]
+    taps = [(kt - top_pad, kf) for kt, kf in kk]
+    return kk, taps
+
+
+def convT_phase_taps(kh, kw, phase):
+    """Stride-(1,2) ConvTranspose2d, output bins f_o = 2j + phase: weight (kt,kf) with
+    kf ≡ phase (mod 2) reads frame t - kt, bin j - (kf - phase)/2."""
+    kk = [(kt, kf) for kt in range(kh) for kf in range(phase, kw, 2)]
+    taps = [(-kt, -(kf - phase) // 2) for kt, kf in kk]
+    return kk, taps
+
+
+def taps_array(taps):
+    return np.asarray(taps, np.int32).reshape(-1, 2)
+
+
+# --------------------------------------------------------------------------
+# STFT / inverse STFT bases (torch.stft / torch.istft conventions of
+# trainer/complex_ddpm_trainer.py:926-930, :1010-1015): n_fft = win = 320, hop 160,
+# periodic hann, onesided, no normalisation.
+# --------------------------------------------------------------------------
+def hann_periodic(n):
+    k = np.arange(n, dtype=np.float64)
+    return 0.5 - 0.5 * np.cos(2.0 * np.pi * k / n)
+
+
+def stft_kmat(n_fft=320):
+    """[n_fft taps, 2*F] : co = ri*F + f."""
+    F = n_fft // 2 + 1
+    n = np.arange(n_fft, dtype=np.float64)[:, None]
+    f = np.arange(F, dtype=np.float64)[None, :]
+    w = hann_periodic(n_fft)[:, None]
+    ang = 2.0 * np.pi * n * f / n_fft
+    return np.concatenate([w * np.cos(ang), -w * np.sin(ang)], axis=1)
+
+
+def istft_kmat(n_fft=320):
+    """[(f, ri) = F*2 rows, n_fft] windowed inverse real DFT, k = f*2 + ri."""
+    F = n_fft // 2 + 1
+    n = np.arange(n_fft, dtype=np.float64)[None, :]
+    f = np.arange(F, dtype=np.float64)[:, None]
+    a = np.full((F, 1), 2.0)
+    a[0, 0] = a[F - 1, 0] = 1.0
+    w = hann_periodic(n_fft)[None, :]
+    ang = 2.0 * np.pi * f * n / n_fft
+    re = a * np.cos(ang) * w / n_fft
+    im = -a * np.sin(ang) * w / n_fft
+    out = np.empty((F * 2, n_fft))
+    out[0::2] = re
+    out[1::2] = im
+    return out

@@ -1,0 +1,158 @@
+"""The whole sampling path as ONE recorded plan:
+
+    [wav -> RMS normalise -> STFT -> sqrt-compress]            :921-937
+    prior(feat) -> X_init; init = X_init / 11                   :939-942
+    [--sigma: x_T *= sqrt(mask(init))]                          :951-956
+    for n = S-1 .. 0: eps = DiffUNet1(audio, init, T[n]);
+                      audio = c1 (audio - c2 eps)               :964-992
+    spec = (audio + init) * 11                                  :995-996
+    [square-decompress -> ISTFT -> * c]                         :1004-1016
+
+(line numbers: reference trainer/complex_ddpm_trainer.py).  Once built for a (B, T) the
+plan owns every buffer in HBM; ``run()`` is a single C call that issues the launches, or
+a single hipGraph replay.
+"""
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import nets
+from .params import PRIOR_SCALE_C, params as default_params
+from .schedule import inference_schedule, step_coefficients
+
+F0 = 161
+
+
+class SamplerPipeline:
+    def __init__(self, device, prior_name, prior_sd, ddpm_sd, B, T=None, L_=None, fast_sampling=True,
+                 use_sigma=False, params=default_params, with_signal=None):
+        if L_ is not None:
+            T = 1 + L_ // 160
+        if with_signal is None:
+            with_signal = L_ is not None
+        self.B, self.T, self.L = B, T, L_
+        self.device = torch.device(device)
+        self.ctx = ctx = nets.Ctx(device)
+        self.plan = L.Plan() if self.device.type == "cuda" else None
+        alpha, beta, alpha_cum, sigmas, Tarr = inference_schedule(params, fast_sampling)
+        self.schedule = (alpha, beta, alpha_cum, sigmas, Tarr)
+        c1, c2 = step_coefficients(alpha, beta, alpha_cum)
+        S = len(alpha)
+        self.nsteps = S
+        self.ranges = {}
+        self.descs = []
+
+        # ---- builders share one plan object and one descriptor list
+        def adopt(pb):
+            pb.descs = self.descs
+            return pb
+
+        self.stft = adopt(nets.StftPlan(ctx, B, L_, plan=self.plan)) if with_signal else None
+        if prior_name == "GCRN":
+            self.prior = adopt(nets.GcrnPlan(ctx, prior_sd, B, T, plan=self.plan))
+        elif prior_name == "DiffUNet":
+            self.prior = adopt(nets.EpsNetPlan(ctx, prior_sd, B, T, time_cond=False, plan=self.plan))
+        else:
+            raise ValueError("prior %r not built yet (GCRN, DiffUNet)" % prior_name)
+        self.eps = adopt(nets.EpsNetPlan(ctx, ddpm_sd, B, T, time_cond=True, nsteps=S, plan=self.plan))
+        self.istft = adopt(nets.IstftPlan(ctx, B, T, L_, plan=self.plan)) if with_signal else None
+
+        self.feat = self.prior.x                     # prior input = compressed spectrogram
+        self.init = self.eps.x_init                  # X_init / 11
+        self.audio = self.eps.x                      # x_t, updated in place
+        self.spec = self.istft.spec if with_signal else ctx.alloc(B, 2, T, F0)
+        self.xT_in = ctx.alloc(B, 2, T, F0)          # injected x_T (kept so a replay starts from it)
+        n = B * 2 * T * F0
+
+        def mark(name, fn):
+            b = len(self.descs)
+            fn()
+            self.ranges[name] = (b, len(self.descs))
+
+        if with_signal:
+            mark("stft", lambda: self.stft.build(feat=self.feat))
+        if prior_name == "GCRN":
+            mark("prior", lambda: self.prior.build(x=self.feat, out=self.prior.out))
+        else:
+            mark("prior", lambda: self.prior.build_step(0, x=self.feat, out=self.prior.out))
+
+        def ew(op, a, b=None, c=None, out=None, s0=0.0, s1=0.0, s2=0.0):
+            d = L.EwDesc()
+            d.a, d.b, d.c, d.out = a.data_ptr(), nets.Ctx.ptr(b), nets.Ctx.ptr(c), out.data_ptr()
+            d.n, d.s0, d.s1, d.s2, d.op = n, s0, s1, s2, op
+            self.eps.add(d, nets.TAG_EW)
+
+        def prologue():
+            ew(L.EW_DIV, self.prior.out, out=self.init, s0=PRIOR_SCALE_C)
+            if use_sigma:
+                d = L.SigmaDesc()
+                d.init, d.a, d.out = self.init.data_ptr(), self.xT_in.data_ptr(), self.audio.data_ptr()
+                d.maxbuf = ctx.alloc(B * 2).data_ptr()
+                d.plane, d.nplanes = T * F0, B * 2
+                self.eps.add(d, nets.TAG_EW)
+            else:
+                ew(L.EW_COPY, self.xT_in, out=self.audio)
+            self.eps.build_time()
+
+        mark("prologue", prologue)
+        # diffusion-step rows are stored in loop order: row i is step n = S-1-i
+        self.eps.tsteps.copy_(torch.from_numpy(np.ascontiguousarray(Tarr[::-1]))[:, None].expand(S, B))
+        for i in range(S):
+            nstep = S - 1 - i
+
+            def one(i=i, nstep=nstep):
+                self.eps.build_step(i, x=self.audio, x_init=self.init, out=self.eps.out)
+                if nstep > 0:
+                    ew(L.EW_UPDATE, self.audio, b=self.eps.out, out=self.audio, s0=float(c1[nstep]), s1=float(c2[nstep]))
+                else:
+                    ew(L.EW_UPDATE_FINAL, self.audio, b=self.eps.out, c=self.init, out=self.spec,
+                       s0=float(c1[0]), s1=float(c2[0]), s2=PRIOR_SCALE_C)
+
+            mark("step%d" % nstep, one)
+        if with_signal:
+            mark("istft", lambda: self.istft.build(spec=self.spec, c=self.stft.c))
+        if self.plan is not None:
+            self.plan.keep(ctx.keep)
+        self._graph_stream = None
+
+    # ------------------------------------------------------------------
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def run(self, first=None, last=None, graph=False):
+        """Run ranges first..last (names from ``self.ranges``), whole plan by default."""
+        if self.plan is None:
+            raise L.PdseError("SamplerPipeline built on a CPU context cannot run: there is no CPU fallback")
+        if graph:
+            if first is not None or last is not None:
+                raise ValueError("graph replay always runs the whole plan")
+            if not self.plan.has_graph:
+                self._graph_stream = torch.cuda.Stream(self.device)
+                with torch.cuda.stream(self._graph_stream):
+                    self.plan.build_graph(self._graph_stream.cuda_stream)
+                self._graph_stream.synchronize()
+            self.plan.launch_graph(self._stream())
+            return
+        b = self.ranges[first][0] if first else 0
+        e = self.ranges[last][1] if last else len(self.descs)
+        self.plan.run_range(b, e, self._stream())
+
+    def sample(self, feat, x_T, graph=False):
+        """feat, x_T [B,2,T,161] -> (enhanced compressed spectrogram, X_init); the
+        spectrogram-level body of generate_wav (:939-998)."""
+        self.feat.copy_(feat)
+        self.xT_in.copy_(x_T)
+        if graph and self.stft is None:
+            self.run(graph=True)
+        else:
+            self.run("prior", "step0")
+        return self.spec.clone(), self.prior.out.clone()
+
+    def enhance(self, wav, x_T, graph=False):
+        """wav [B,L], x_T [B,2,T,161] -> (enhanced wav [B,L], spectrogram [B,2,T,161])."""
+        if self.stft is None:
+            raise ValueError("pipeline was built without the signal front/back end (pass L_)")
+        self.stft.wav.copy_(wav)
+        self.xT_in.copy_(x_T)
+        self.run(graph=graph)
+        return self.istft.wav.clone(), self.spec.clone()

@@ -1,0 +1,309 @@
+"""TEST INFRASTRUCTURE: a numpy interpreter of the libpdse.so operator descriptors
+(include/pdse.h) over CPU tensors.
+
+It executes the *same descriptors* the plan builders record — same packed weights, tap
+tables, strides, folded biases — with the semantics the header documents, so the host
+logic (weight folding/packing, stride algebra, plan construction) is checked against
+the oracle on the CPU-only build container.  It is never used by the product path and
+says nothing about the HIP kernels themselves; those are checked on the GPU (-m gpu).
+"""
+import importlib
+
+import numpy as np
+import torch
+
+L = importlib.import_module("prior-diffuse_amd._lib")
+
+RHO = np.array([[(r & 3) + 8 * (r >> 2) + 4 * h for h in (0, 1)] for r in range(16)])
+
+
+class Mem:
+    """Resolve raw pointers to flat float32/int32 numpy views of the tensors a Ctx keeps."""
+
+    def __init__(self, tensors):
+        self.regions = []
+        for t in tensors:
+            if torch.is_tensor(t) and t.device.type == "cpu" and t.numel() > 0:
+                self.regions.append((t.data_ptr(), t.data_ptr() + t.numel() * t.element_size(), t))
+        self.regions.sort(key=lambda r: r[0])
+
+    def view(self, ptr, dtype=np.float32):
+        """(flat array of the owning tensor, element offset of ptr)."""
+        if not ptr:
+            return None, 0
+        for lo, hi, t in self.regions:
+            if lo <= ptr < hi:
+                flat = t.view(-1).numpy()
+                assert flat.dtype == dtype, (flat.dtype, dtype)
+                return flat, (ptr - lo) // 4
+        raise KeyError("pointer %x not inside any known tensor" % ptr)
+
+    def arr(self, ptr, n, dtype=np.float32):
+        flat, off = self.view(ptr, dtype)
+        return flat[off:off + n]
+
+
+def _act(v, act, slope=0.0):
+    if act == L.ACT_PRELU:
+        return np.where(v > 0, v, np.float32(slope) * v)
+    if act == L.ACT_ELU:
+        return np.where(v > 0, v, np.expm1(np.minimum(v, 0)))
+    if act == L.ACT_SIGMOID:
+        return 1.0 / (1.0 + np.exp(-v))
+    return v
+
+
+def _sig(v):
+    return 1.0 / (1.0 + np.exp(-v))
+
+
+def _unpack_a(w, mtiles, ksteps):
+    w = w.reshape(mtiles, ksteps, 2, 32)            # [mt, ks, h, col]
+    return w.transpose(1, 2, 0, 3).reshape(2 * ksteps, mtiles * 32)   # [k, co]
+
+
+def _unpack_chain(w, mtiles):
+    w = w.reshape(mtiles, 16, 2, 32)                # [mt, r, h, col(out)]
+    out = np.zeros((mtiles * 32, 32), np.float32)   # [out, in]
+    for r in range(16):
+        for h in (0, 1):
+            out[:, RHO[r, h]] = w[:, r, h, :].reshape(-1)
+    return out
+
+
+def run_gconv(d, mem):
+    B, To, Fo = d.B, d.Tout, d.Fout
+    Cin = d.in0.C + d.in1.C
+    mtiles = (d.Cout + 31) // 32
+    dual = d.epi != L.EPI_LINEAR
+    W0 = _unpack_a(mem.arr(d.w0, mtiles * d.ksteps * 64), mtiles, d.ksteps)
+    W1 = _unpack_a(mem.arr(d.w1, mtiles * d.ksteps * 64), mtiles, d.ksteps) if dual else None
+    taps = mem.arr(d.taps, 2 * d.ntaps, np.int32).reshape(-1, 2)
+    bI = np.arange(B)[:, None, None, None]
+    tI = np.arange(To)[None, None, :, None]
+    jI = np.arange(Fo)[None, None, None, :]
+    acc0 = np.zeros((B, mtiles * 32, To, Fo), np.float32)
+    acc1 = np.zeros_like(acc0) if dual else None
+    srcs = [(d.in0, 0)] + ([(d.in1, d.in0.C)] if d.in1.C else [])
+    pad_flat, pad_off = mem.view(d.padrow)
+    xs0 = mem.arr(d.xf_scale0, Cin) if d.xf_mode else None
+    xh0 = mem.arr(d.xf_shift0, Cin) if d.xf_mode else None
+    xs1 = mem.arr(d.xf_scale1, Cin) if d.xf_mode == 2 else None
+    xh1 = mem.arr(d.xf_shift1, Cin) if d.xf_mode == 2 else None
+    for ti, (dt, df) in enumerate(taps):
+        tin, fin = tI + dt, jI * d.sf_in + df
+        fok = (fin >= 0) & (fin < d.Fin)
+        inb = fok & (tin >= 0) & (tin < d.Tin)
+        isp = fok & (tin == -1) & bool(d.padrow)
+        for S, cbase in srcs:
+            flat, off = mem.view(S.ptr)
+            cI = np.arange(S.C)[None, :, None, None]
+            idx = off + bI * S.sb + cI * S.sc + tin * S.st + fin * S.sf
+            idx = np.where(inb, idx, 0)
+            v = flat[np.broadcast_to(idx, (B, S.C, To, Fo))]
+            v = _act(v, S.act)
+            v = np.where(inb, v, 0.0).astype(np.float32)
+            if d.padrow:
+                pv = pad_flat[pad_off + bI * d.padrow_sb + cbase + cI]
+                v = np.where(np.broadcast_to(isp, v.shape), np.broadcast_to(pv, v.shape), v)
+            v0 = v1 = v
+            if d.xf_mode:
+                sl = slice(cbase, cbase + S.C)
+                u = np.where(v > 0, v, np.float32(d.xf_slope0) * v)
+                v0 = np.where(inb, u * xs0[sl][None, :, None, None] + xh0[sl][None, :, None, None], v)
+                if d.xf_mode == 2:
+                    u1 = np.where(v > 0, v, np.float32(d.xf_slope1) * v)
+                    v1 = np.where(inb, u1 * xs1[sl][None, :, None, None] + xh1[sl][None, :, None, None], v)
+                else:
+                    v1 = v0
+            if d.cin1:
+                k0 = ti
+            else:
+                k0 = ti * Cin + cbase
+            acc0 += np.einsum("km,bktf->bmtf", W0[k0:k0 + S.C], v0.astype(np.float32), optimize=True)
+            if dual:
+                acc1 += np.einsum("km,bktf->bmtf", W1[k0:k0 + S.C], v1.astype(np.float32), optimize=True)
+
+    out_flat, out_off = mem.view(d.out)
+
+    def bias(ptr, sb, n):
+        if not ptr:
+            return np.zeros((1, n, 1, 1), np.float32)
+        flat, off = mem.view(ptr)
+        return flat[off + np.arange(B)[:, None] * sb + np.arange(n)[None, :]][:, :, None, None]
+
+    def store(y, C_):
+        co = np.arange(C_)[None, :, None, None]
+        idx = (out_off + bI * d.out_sb + (co // d.out_cr) * d.out_sc_hi + (co % d.out_cr) * d.out_sc_lo
+               + tI * d.out_st + jI * d.out_sf + d.out_off)
+        idx = np.broadcast_to(idx, y.shape)
+        if d.resid:
+            rflat, roff = mem.view(d.resid)
+            y = y + rflat[idx - out_off + roff]
+        out_flat[idx] = y
+
+    def post(y, C_):
+        if d.post_scale:
+            y = y * mem.arr(d.post_scale, C_)[None, :, None, None] + mem.arr(d.post_shift, C_)[None, :, None, None]
+        return _act(y, d.act, d.act_slope).astype(np.float32)
+
+    if d.epi in (L.EPI_LINEAR, L.EPI_GLU):
+        y = acc0[:, :d.Cout] + bias(d.bias0, d.bias0_sb, d.Cout)
+        if d.epi == L.EPI_GLU:
+            y = y * _sig(acc1[:, :d.Cout] + bias(d.bias1, d.bias1_sb, d.Cout))
+        store(post(y, d.Cout), d.Cout)
+    else:
+        Lh = acc0[:, :32] + mem.arr(d.bias0, 32)[None, :, None, None]
+        Rh = acc1[:, :32] + mem.arr(d.bias1, 32)[None, :, None, None]
+        Wlc = _unpack_chain(mem.arr(d.wlc, 16 * 64), 1)
+        Wrc = _unpack_chain(mem.arr(d.wrc, 16 * 64), 1)
+        mL = _sig(np.einsum("oc,bctf->botf", Wlc, Lh) + mem.arr(d.blc, 32)[None, :, None, None])
+        mR = _sig(np.einsum("oc,bctf->botf", Wrc, Rh) + mem.arr(d.brc, 32)[None, :, None, None])
+        G = Lh * mR + Rh * mL
+        if d.C2 == 1:
+            y = np.einsum("c,bctf->btf", mem.arr(d.wc2, 32), G)[:, None] + mem.arr(d.bc2, 1)[0]
+        else:
+            t2 = (d.C2 + 31) // 32
+            Wc2 = _unpack_chain(mem.arr(d.wc2, t2 * 16 * 64), t2)[:d.C2]
+            y = np.einsum("oc,bctf->botf", Wc2, G) + mem.arr(d.bc2, d.C2)[None, :, None, None]
+        store(post(y.astype(np.float32), d.C2), d.C2)
+
+
+def run_time(d, mem):
+    B, NF = d.B, d.NF
+    t = mem.arr(d.t, B)
+    table = mem.arr(d.table, d.max_steps * 128).reshape(d.max_steps, 128)
+    lo = np.clip(np.floor(t).astype(int), 0, d.max_steps - 1)
+    hi = np.clip(np.ceil(t).astype(int), 0, d.max_steps - 1)
+    x = table[lo] + (table[hi] - table[lo]) * (t - np.floor(t))[:, None]
+    p1T = mem.arr(d.p1T, 128 * 512).reshape(128, 512)
+    p2T = mem.arr(d.p2T, 512 * 512).reshape(512, 512)
+    y = x @ p1T + mem.arr(d.b1, 512)
+    y = y * _sig(y)
+    y = y @ p2T + mem.arr(d.b2, 512)
+    y = (y * _sig(y)).astype(np.float32)
+    if d.temb:
+        mem.arr(d.temb, B * 512)[:] = y.reshape(-1)
+    wfT = mem.arr(d.wfT, 512 * NF).reshape(512, NF)
+    mem.arr(d.out, B * NF)[:] = (y @ wfT + mem.arr(d.bf, NF)).astype(np.float32).reshape(-1)
+
+
+def run_ew(d, mem):
+    a = mem.arr(d.a, d.n)
+    b = mem.arr(d.b, d.n) if d.b else None
+    c = mem.arr(d.c, d.n) if d.c else None
+    s0, s1, s2 = np.float32(d.s0), np.float32(d.s1), np.float32(d.s2)
+    if d.op == L.EW_DIV:
+        y = a / s0
+    elif d.op == L.EW_UPDATE:
+        y = s0 * (a - s1 * b)
+    elif d.op == L.EW_UPDATE_FINAL:
+        y = ((s0 * (a - s1 * b)) + c) * s2
+    elif d.op == L.EW_ADD_MUL:
+        y = (a + b) * s0
+    else:
+        y = a.copy()
+    mem.arr(d.out, d.n)[:] = y.astype(np.float32)
+
+
+def run_compand(d, mem):
+    n = d.B * 2 * d.plane
+    x = mem.arr(d.in_, n).reshape(d.B, 2, d.plane).copy()
+    mag = np.sqrt(x[:, 0] * x[:, 0] + x[:, 1] * x[:, 1])
+    safe = np.where(mag > 0, mag, 1)
+    cr, sr = np.where(mag > 0, x[:, 0] / safe, 1.0), np.where(mag > 0, x[:, 1] / safe, 0.0)
+    m2 = np.sqrt(mag) if d.mode == 0 else mag * mag
+    out = np.stack([m2 * cr, m2 * sr], axis=1).astype(np.float32)
+    mem.arr(d.out, n)[:] = out.reshape(-1)
+
+
+def run_wavprep(d, mem):
+    x = mem.arr(d.wav, d.B * d.L).reshape(d.B, d.L)
+    c = np.sqrt((x.astype(np.float32) ** 2).sum(1) / np.float32(d.L)) if d.normalize else np.ones(d.B, np.float32)
+    if d.c:
+        mem.arr(d.c, d.B)[:] = c
+    xp = np.pad(x / c[:, None], ((0, 0), (d.pad, d.pad)), mode="reflect")
+    mem.arr(d.xpad, d.B * (d.L + 2 * d.pad))[:] = xp.astype(np.float32).reshape(-1)
+
+
+def run_ola(d, mem):
+    fr = mem.arr(d.frames, d.B * d.n_fft * d.T).reshape(d.B, d.n_fft, d.T)
+    w2 = mem.arr(d.win2, d.n_fft)
+    full = d.n_fft + d.hop * (d.T - 1)
+    y = np.zeros((d.B, max(full, d.n_fft // 2 + d.L)), np.float32)
+    env = np.zeros(y.shape[1], np.float32)
+    for t in range(d.T):
+        y[:, t * d.hop:t * d.hop + d.n_fft] += fr[:, :, t]
+        env[t * d.hop:t * d.hop + d.n_fft] += w2
+    h = d.n_fft // 2
+    out = np.where(env[h:h + d.L] > 1e-11, y[:, h:h + d.L] / np.maximum(env[h:h + d.L], 1e-30), 0)
+    if d.c:
+        out = out * mem.arr(d.c, d.B)[:, None]
+    mem.arr(d.out, d.B * d.L)[:] = out.astype(np.float32).reshape(-1)
+
+
+def run_sigma(d, mem):
+    n = d.nplanes * d.plane
+    init = mem.arr(d.init, n).reshape(d.nplanes, d.plane)
+    a = mem.arr(d.a, n).reshape(d.nplanes, d.plane)
+    m = np.abs(init) / np.abs(init).max(1, keepdims=True)
+    m = m / np.float32(2) + np.float32(0.5)
+    mem.arr(d.out, n)[:] = (a * np.sqrt(m)).astype(np.float32).reshape(-1)
+
+
+def run_ln(d, mem):
+    x = mem.arr(d.in_, d.B * d.T * d.N).reshape(d.B, d.T, d.N)
+    mu = x.mean(-1, keepdims=True)
+    var = ((x - mu) ** 2).mean(-1, keepdims=True)
+    y = ((x - mu) / np.sqrt(var + np.float32(d.eps)) * mem.arr(d.gamma, d.N) + mem.arr(d.beta, d.N)).astype(np.float32)
+    flat, off = mem.view(d.out)
+    b = np.arange(d.B)[:, None, None]
+    t = np.arange(d.T)[None, :, None]
+    j = np.arange(d.N)[None, None, :]
+    flat[off + b * d.osb + (j // d.r) * d.os_hi + (j % d.r) * d.os_lo + t * d.os_t] = y
+
+
+def run_lstm(d, mem):
+    H, G, T, Bp, B = d.H, d.G, d.T, d.Bp, d.B
+    gx = mem.arr(d.gx, G * T * 4 * H * Bp).reshape(G, T, 4 * H, Bp)
+    whh = mem.arr(d.whh, G * (H // 8) * (H // 2) * 64).reshape(G, H // 8, H // 2, 2, 32)
+    yflat, yoff = mem.view(d.y)
+    for g in range(G):
+        # rebuild W_hh [4H, H] from the slice fragments: tile row i = q*8+u <-> row q*H + 8s + u
+        W = np.zeros((4 * H, H), np.float32)
+        for s in range(H // 8):
+            frag = whh[g, s]                                  # [ks, h, i]
+            wk = frag.reshape(H // 2 * 2, 32)                 # k = 2ks + h
+            for i in range(32):
+                W[(i // 8) * H + 8 * s + (i % 8)] = wk[:, i]
+        h = np.zeros((B, H), np.float32)
+        c = np.zeros((B, H), np.float32)
+        for t in range(T):
+            gate = gx[g, t, :, :B].T + h @ W.T
+            i_, f_, g_, o_ = np.split(gate, 4, axis=1)
+            c = _sig(f_) * c + _sig(i_) * np.tanh(g_)
+            h = (_sig(o_) * np.tanh(c)).astype(np.float32)
+            idx = (yoff + np.arange(B)[:, None] * d.y_sb + t * d.y_st + np.arange(H)[None, :] * d.y_su + g * d.y_sg)
+            yflat[idx] = h
+
+
+RUNNERS = {L.GconvDesc: run_gconv, L.TimeDesc: run_time, L.EwDesc: run_ew, L.CompandDesc: run_compand,
+           L.WavprepDesc: run_wavprep, L.OlaDesc: run_ola, L.SigmaDesc: run_sigma, L.LnDesc: run_ln,
+           L.LstmDesc: run_lstm}
+
+
+def run(descs, keep, begin=0, end=None):
+    """Execute descriptors [begin, end) (as recorded by a PlanBase on a CPU Ctx)."""
+    mem = Mem(_flatten(keep))
+    for d, _tag in descs[begin:end]:
+        RUNNERS[type(d)](d, mem)
+
+
+def _flatten(x):
+    out = []
+    for it in x:
+        if isinstance(it, (list, tuple)):
+            out.extend(_flatten(it))
+        else:
+            out.append(it)
+    return out

@@ -1,0 +1,279 @@
+"""GPU parity tests proper: the HIP path (through the C-ABI of libpdse.so) against the
+oracle on the same seeded inputs, against the committed golden fixtures, and — at
+BASELINE.json's full sizes — through size-independent properties (batch invariance,
+graph replay == eager, STFT->ISTFT round trip).
+
+Tolerances (fp32 both sides; only summation order differs: MFMA fmaf chains vs oneDNN):
+  single network forward        rel-L2 <= 2e-5
+  6-step / 50-step sampling     rel-L2 <= 1e-4   (north-star tolerance)
+  reverse-step arithmetic       bit-exact
+"""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, pkg, rel_l2, seeded
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def R():
+    from oracle import restate
+
+    return restate
+
+
+@pytest.fixture(scope="module")
+def L():
+    lib = pkg("_lib")
+    lib.load()
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return lib
+
+
+def _sync():
+    torch.cuda.synchronize()
+
+
+# ---------------------------------------------------------------- elementwise, bit-exact
+def test_reverse_step_arithmetic_bit_exact(L):
+    n = 2 * 2 * 401 * 161 + 3   # not a multiple of 4: exercises the vector body + scalar tail
+    g = torch.Generator().manual_seed(0)
+    a, b, c = (torch.randn(n, generator=g) for _ in range(3))
+    params = pkg("params").params
+    alpha, beta, alpha_cum, sigmas, T = pkg("schedule").inference_schedule(params, True)
+    c1, c2 = pkg("schedule").step_coefficients(alpha, beta, alpha_cum)
+    for off in (0, 1):          # off=1: pointers only 4-byte aligned -> scalar kernel
+        ad, bd, cd = (x.to(DEV)[off:] for x in (a, b, c))
+        out = torch.empty_like(ad)
+        for nstep in range(6):
+            d = L.EwDesc()
+            d.a, d.b, d.out, d.n = ad.data_ptr(), bd.data_ptr(), out.data_ptr(), ad.numel()
+            d.s0, d.s1, d.op = float(c1[nstep]), float(c2[nstep]), L.EW_UPDATE
+            L.launch(d)
+            _sync()
+            ref = float(1 / alpha[nstep] ** 0.5) * (a[off:] - float(beta[nstep] / (1 - alpha_cum[nstep]) ** 0.5) * b[off:])
+            assert torch.equal(out.cpu(), ref), nstep
+        d = L.EwDesc()
+        d.a, d.b, d.c, d.out, d.n = ad.data_ptr(), bd.data_ptr(), cd.data_ptr(), out.data_ptr(), ad.numel()
+        d.s0, d.s1, d.s2, d.op = float(c1[0]), float(c2[0]), 11.0, L.EW_UPDATE_FINAL
+        L.launch(d)
+        _sync()
+        ref = float(1 / alpha[0] ** 0.5) * (a[off:] - float(beta[0] / (1 - alpha_cum[0]) ** 0.5) * b[off:])
+        ref = (ref + c[off:]) * 11
+        assert torch.equal(out.cpu(), ref)
+        d = L.EwDesc()
+        d.a, d.out, d.n, d.s0, d.op = ad.data_ptr(), out.data_ptr(), ad.numel(), 11.0, L.EW_DIV
+        L.launch(d)
+        _sync()
+        assert torch.equal(out.cpu(), a[off:] / 11)
+
+
+def test_error_reporting(L):
+    d = L.EwDesc()
+    with pytest.raises(L.PdseError, match="ew"):
+        L.launch(d)
+    g = L.GconvDesc()
+    with pytest.raises(L.PdseError, match="gconv"):
+        L.launch(g)
+
+
+# ---------------------------------------------------------------- networks vs golden + oracle
+def test_time_embedding_golden(L, weights):
+    g = golden("time_embedding")
+    nets = pkg("nets")
+    for key_t, key_o in (("t_float", "out_float"), ("t_int", "out_int")):
+        t = torch.from_numpy(g[key_t].astype(np.float32))
+        net = nets.EpsNetPlan(nets.Ctx(DEV), weights("DiffUNet1"), len(t), 4, time_cond=True, nsteps=1)
+        net.build_time()
+        net.finish()
+        net.tsteps.copy_(t.view(1, -1))
+        net.plan.run()
+        _sync()
+        assert rel_l2(net.temb[0].cpu(), g[key_o]) < 2e-6
+    assert np.array_equal(net.table.cpu().numpy(), g["table"])
+
+
+def test_diffunet1_golden_small(L, weights):
+    g = golden("diffunet1_small")
+    op = pkg("ops").DiffUNet1Op(weights("DiffUNet1"), DEV)
+    B, T = int(g["B"]), int(g["T"])
+    x = seeded((B, 2, T, 161), g["seed_x"])
+    xi = seeded((B, 2, T, 161), g["seed_init"]) * float(g["init_scale"])
+    out = op(x.to(DEV), xi.to(DEV), torch.from_numpy(g["t"]).to(DEV))
+    net = op._plans[(B, T)]
+    _sync()
+    assert rel_l2(net.en[0].cpu()[:, ::4], g["en1_c4"]) < 2e-5
+    assert rel_l2(net.en[4].cpu().permute(0, 1, 3, 2), g["en5"]) < 2e-5
+    assert rel_l2(out.cpu(), g["out"]) < 2e-5
+    gi = golden("diffunet1_int_t")
+    out_i = op(x.to(DEV), xi.to(DEV), torch.from_numpy(gi["t"]).to(DEV))
+    assert rel_l2(out_i.cpu(), gi["out"]) < 2e-5
+
+
+def test_diffunet1_golden_t401(L, weights):
+    g = golden("diffunet1_t401")
+    op = pkg("ops").DiffUNet1Op(weights("DiffUNet1"), DEV)
+    x = seeded((1, 2, 401, 161), g["seed_x"])
+    xi = seeded((1, 2, 401, 161), g["seed_init"]) * 0.3
+    out = op(x.to(DEV), xi.to(DEV), torch.tensor([float(g["t"])], device=DEV)).cpu()
+    assert rel_l2(out[0, :, ::16, :], g["rows"]) < 2e-5
+    assert abs(out.double().pow(2).sum().item() - float(g["sumsq"])) / float(g["sumsq"]) < 1e-4
+
+
+def test_gcrn_golden(L, weights):
+    g = golden("gcrn_small")
+    op = pkg("ops").GCRNOp(weights("GCRN"), DEV)
+    out = op(seeded((2, 2, 20, 161), g["seed_x"]).to(DEV))
+    net = op._plans[(2, 20)]
+    _sync()
+    assert rel_l2(net.e[4].cpu(), g["e5"]) < 2e-5
+    assert rel_l2(net.glstm.cpu(), g["glstm"]) < 2e-5
+    assert rel_l2(out.cpu(), g["out"]) < 2e-5
+    g = golden("gcrn_t401")
+    out = op(seeded((1, 2, 401, 161), g["seed_x"]).to(DEV)).cpu()
+    assert rel_l2(out[0, :, ::16, :], g["rows"]) < 5e-5
+
+
+def test_diffunet_prior_golden(L, weights):
+    g = golden("diffunet_prior_small")
+    op = pkg("ops").DiffUNetOp(weights("DiffUNet"), DEV)
+    out = op(seeded((2, 2, 20, 161), g["seed_x"]).to(DEV))
+    assert rel_l2(out.cpu(), g["out"]) < 2e-5
+
+
+def test_operator_input_checks(L, weights):
+    op = pkg("ops").DiffUNet1Op(weights("DiffUNet1"), DEV)
+    x = torch.zeros(1, 2, 8, 161, device=DEV)
+    with pytest.raises(ValueError):
+        op(torch.zeros(1, 2, 8, 257, device=DEV), x, torch.zeros(1, device=DEV))   # F=257 cannot run
+    with pytest.raises(IndexError):
+        op(x, x, torch.tensor([50.0], device=DEV))
+    with pytest.raises(L.PdseError):
+        pkg("ops").GCRNOp(weights("GCRN"), "cpu")
+
+
+# ---------------------------------------------------------------- sampling vs golden
+@pytest.mark.parametrize("tag,prior,fast,sigma,tol", [
+    ("gcrn_fast", "GCRN", True, False, 1e-4),
+    ("gcrn_fast_sigma", "GCRN", True, True, 1e-4),
+    ("diffunet_fast", "DiffUNet", True, False, 1e-4),
+    ("gcrn_full", "GCRN", False, False, 1e-4),
+])
+def test_sample_golden(L, weights, tag, prior, fast, sigma, tol):
+    g = golden("sample_" + tag)
+    feat = seeded((2, 2, 16, 161), g["seed_feat"])
+    x_T = seeded((2, 2, 16, 161), g["seed_xT"])
+    pipe = pkg("pipeline").SamplerPipeline(DEV, prior, weights(prior), weights("DiffUNet1"), 2, T=16,
+                                           fast_sampling=fast, use_sigma=sigma)
+    spec, init = pipe.sample(feat.to(DEV), x_T.to(DEV))
+    _sync()
+    assert rel_l2(init.cpu(), g["init"]) < 2e-5
+    assert rel_l2(spec.cpu(), g["out"]) < tol
+    if fast and not sigma and prior == "GCRN":
+        # per-step trace: run the plan range by range
+        pipe.feat.copy_(feat.to(DEV))
+        pipe.xT_in.copy_(x_T.to(DEV))
+        pipe.run("prior", "prologue")
+        for k, n in enumerate(range(5, 0, -1)):
+            pipe.run("step%d" % n, "step%d" % n)
+            _sync()
+            assert rel_l2(pipe.audio.cpu(), g["trace"][k]) < tol, n
+        # hipGraph replay of the whole plan gives the same bits as the eager launches
+        spec_g, _ = pipe.sample(feat.to(DEV), x_T.to(DEV), graph=True)
+        _sync()
+        assert torch.equal(spec_g, spec)
+
+
+# ---------------------------------------------------------------- whole path vs oracle
+def test_enhance_vs_oracle(L, weights, R):
+    params = pkg("params").params
+    B, L_ = 3, 4000                     # ragged: L not a multiple of the hop
+    wav, x_T = pkg("synth").synthetic_waveforms(B, L_, seed=5)
+    wav = wav * torch.tensor([0.05, 1.0, 7.0])[:, None]       # the RMS normalisation must cancel the scale
+    x_T = x_T[:, :, : 1 + L_ // 160]
+    pipe = pkg("pipeline").SamplerPipeline(DEV, "GCRN", weights("GCRN"), weights("DiffUNet1"), B, L_=L_)
+    out, spec = pipe.enhance(wav.to(DEV), x_T.to(DEV))
+    _sync()
+    with torch.no_grad():
+        ref_wav, ref_spec = R.enhance("GCRN", weights("GCRN"), weights("DiffUNet1"), wav, x_T,
+                                      params.noise_schedule, params.inference_noise_schedule, True, False)
+    assert rel_l2(pipe.feat.cpu(), R.compress_sqrt(R.stft_ri(wav / R.rms_scale(wav)[:, None]))) < 2e-6
+    assert rel_l2(spec.cpu(), ref_spec) < 1e-4
+    assert rel_l2(out.cpu(), ref_wav) < 1e-4
+
+
+def test_stft_istft_round_trip_full_size(L):
+    """size-independent property at the BASELINE size (B=32, 4 s): ISTFT(STFT(x)) == x."""
+    nets = pkg("nets")
+    B, L_ = 32, 64000
+    ctx = nets.Ctx(DEV)
+    s = nets.StftPlan(ctx, B, L_, normalize=False)
+    s.build()
+    i = nets.IstftPlan(ctx, B, s.T, L_, plan=s.plan)
+    i.descs = s.descs
+    i.build(spec=s.feat)
+    s.finish()
+    wav, _ = pkg("synth").synthetic_waveforms(B, L_, seed=9)
+    s.wav.copy_(wav)
+    s.plan.run()
+    _sync()
+    assert s.T == 401
+    assert rel_l2(i.wav.cpu(), wav) < 2e-6
+
+
+def test_batch_invariance_full_size(L, weights, R):
+    """B=32, T=401 (BASELINE config): every utterance of the batched run equals its own
+    B=1 run bit for bit (tiling never crosses a batch item), and utterance 0 matches the
+    oracle at full T.  This is also what makes the multi-GPU batch split exact."""
+    params = pkg("params").params
+    B, T = 32, 401
+    feat, x_T = pkg("synth").synthetic_spectrogram(B, T, seed=1234)
+    P = pkg("pipeline").SamplerPipeline
+    big = P(DEV, "GCRN", weights("GCRN"), weights("DiffUNet1"), B, T=T)
+    spec, init = big.sample(feat.to(DEV), x_T.to(DEV))
+    one = P(DEV, "GCRN", weights("GCRN"), weights("DiffUNet1"), 1, T=T)
+    for b in (0, 17, 31):
+        s1, i1 = one.sample(feat[b:b + 1].to(DEV), x_T[b:b + 1].to(DEV))
+        assert torch.equal(i1[0], init[b]), b
+        assert torch.equal(s1[0], spec[b]), b
+    assert torch.isfinite(spec).all()
+    with torch.no_grad():
+        ref, _ = R.sample("GCRN", weights("GCRN"), weights("DiffUNet1"), feat[:1], x_T[:1], params.noise_schedule,
+                          params.inference_noise_schedule, True, False)
+    assert rel_l2(spec[0].cpu(), ref[0]) < 1e-4
+
+
+def test_trainer_surface(L, weights, tmp_path):
+    """The drop-in class: constructor args, inference_schedule tuple, generate_wav on a directory."""
+    import argparse
+
+    tr = pkg("trainer")
+    args = argparse.Namespace(retrain=False, joint=True, draw=False, sigma=False,
+                              checkpoint=str(tmp_path / "ck"), generated_wav=str(tmp_path / "out"))
+    config = argparse.Namespace(model=argparse.Namespace(name="GCRN"),
+                                train=argparse.Namespace(fft_num=320, win_size=320, win_shift=160, feat_type="sqrt",
+                                                         batch_size=8))
+    t = tr.ComplexDDPMTrainer(args, config, device=DEV, prior_state_dict=weights("GCRN"),
+                              ddpm_state_dict=weights("DiffUNet1"))
+    alpha, beta, alpha_cum, sigmas, T = t.inference_schedule(fast_sampling=True)
+    assert np.array_equal(T, golden("schedule")["fast_T"])
+    data = tmp_path / "noisy"
+    data.mkdir()
+    wavio = pkg("wavio")
+    rng = np.random.default_rng(0)
+    for i, n in enumerate((3200, 5000)):
+        wavio.write_wav(str(data / ("p%d.wav" % i)), 0.1 * rng.standard_normal(n))
+    torch.manual_seed(1234)
+    written = t.generate_wav(load_pre_train=False, data_path=str(data))
+    assert len(written) == 2
+    for p, n in zip(sorted(written), (3200, 5000)):
+        y = wavio.read_wav(p)
+        assert y.shape == (n,) and np.isfinite(y).all()
+    with pytest.raises(NotImplementedError):
+        t.train_ddpm()
