@@ -53,6 +53,11 @@ def main():
     torch.cuda.set_device(local)
     dev = "cuda:%d" % local
 
+    def note(msg):
+        if rank == 0:
+            print("[bench %.1fs] %s" % (time.perf_counter() - t_start, msg), file=sys.stderr, flush=True)
+
+    t_start = time.perf_counter()
     import __graft_entry__ as ge
 
     ge.build()
@@ -75,8 +80,11 @@ def main():
     def step():
         pipe.enhance(wav, x_T, graph=use_graph)
 
+    note("plan built: %d operators; warm-up (graph=%s)" % (len(pipe.descs), use_graph))
     for _ in range(args.warmup):
         step()
+    torch.cuda.synchronize()
+    note("warm-up done; timing %d steps" % args.steps)
 
     def barrier():
         torch.cuda.synchronize()
@@ -103,6 +111,7 @@ def main():
             dist.destroy_process_group()
         return
 
+    note("timed region: %.3f ms/step; per-stage hipEvent timing" % ms_per_step)
     # ---- roofline of the dominant kernel family: the fused BiConv(Trans)GLU blocks, live hipEvent timing
     stream = torch.cuda.current_stream().cuda_stream
     pipe.stft.wav.copy_(wav)
@@ -128,9 +137,11 @@ def main():
         from oracle import restate as R
 
         params = importlib.import_module("prior-diffuse_amd.params").params
-        nthreads = os.cpu_count() or 1
+        # the GPU box gives one GPU a 16-core share of the host; never oversubscribe it
+        nthreads = max(1, min(16, len(os.sched_getaffinity(0))))
         torch.set_num_threads(nthreads)
         cb = 2
+        note("cpu baseline: oracle on %d host threads, %d utterances" % (nthreads, cb))
         w_cpu, x_cpu = synth.synthetic_waveforms(B * world, L_, seed=1234)
         w_cpu, x_cpu = w_cpu[:cb], x_cpu[:cb]
         with torch.no_grad():

@@ -118,6 +118,11 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own libamdhip64 (soname libamdhip64.so.7, the soname libpdse.so needs):
+    # it must be in the process first so that both share ONE HIP/HSA runtime — two runtimes
+    # in one process lose the device ("no ROCm-capable device is detected").
+    import torch  # noqa: F401
+
     if not os.path.exists(LIB_PATH):
         raise PdseError(
             "libpdse.so not found at %s — build it with `python -c 'import __graft_entry__ as g; g.build()'`"

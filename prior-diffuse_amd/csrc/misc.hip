@@ -69,12 +69,27 @@ int pdse_time_launch(const pdse_time_desc* d, hipStream_t s) {
 // the reference's chain of fp32 tensor ops.  HBM-bound: 16-byte accesses when aligned.
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ float ew_one(int op, float a, float b, float c, float s0, float s1, float s2) {
+  // plain operators under contract(off): the __f*_rn wrappers of the HIP headers carry the
+  // translation unit's default contraction and still fuse into v_fma_f32
+#pragma clang fp contract(off)
   switch (op) {
-    case PDSE_EW_DIV: return __fdiv_rn(a, s0);
-    case PDSE_EW_UPDATE: return __fmul_rn(s0, __fsub_rn(a, __fmul_rn(s1, b)));
-    case PDSE_EW_UPDATE_FINAL:
-      return __fmul_rn(__fadd_rn(__fmul_rn(s0, __fsub_rn(a, __fmul_rn(s1, b))), c), s2);
-    case PDSE_EW_ADD_MUL: return __fmul_rn(__fadd_rn(a, b), s0);
+    case PDSE_EW_DIV: return a / s0;
+    case PDSE_EW_UPDATE: {
+      const float p = s1 * b;
+      const float q = a - p;
+      return s0 * q;
+    }
+    case PDSE_EW_UPDATE_FINAL: {
+      const float p = s1 * b;
+      const float q = a - p;
+      const float r = s0 * q;
+      const float u = r + c;
+      return u * s2;
+    }
+    case PDSE_EW_ADD_MUL: {
+      const float u = a + b;
+      return u * s0;
+    }
     default: return a;
   }
 }
@@ -133,10 +148,12 @@ __global__ __launch_bounds__(256) void compand_kernel(const pdse_compand_desc d)
   const int64_t total = (int64_t)d.B * d.plane;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+#pragma clang fp contract(off)
     const int64_t b = i / d.plane, q = i - b * d.plane;
     const int64_t ire = (2 * b) * d.plane + q, iim = ire + d.plane;
     const float re = d.in[ire], im = d.in[iim];
-    const float mag = sqrtf(__fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im)));
+    const float rr = re * re, ii = im * im;
+    const float mag = sqrtf(rr + ii);
     float cr = 1.f, sr = 0.f;
     if (mag > 0.f) {
       cr = re / mag;
@@ -254,9 +271,11 @@ __global__ __launch_bounds__(256) void sigma_apply_kernel(const pdse_sigma_desc 
   const float mx = d.maxbuf[pl];
   const size_t base = (size_t)pl * d.plane;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < d.plane; i += (int64_t)gridDim.x * 256) {
-    float m = __fdiv_rn(fabsf(d.init[base + i]), mx);
-    m = __fadd_rn(__fdiv_rn(m, 2.0f), 0.5f);
-    d.out[base + i] = __fmul_rn(d.a[base + i], sqrtf(m));
+#pragma clang fp contract(off)
+    float m = fabsf(d.init[base + i]) / mx;
+    m = m * 0.5f;
+    m = m + 0.5f;
+    d.out[base + i] = d.a[base + i] * sqrtf(m);
   }
 }
 
