@@ -1,0 +1,138 @@
+"""CPU: the host side of the product — weight folding/packing, stride algebra and plan
+construction — replayed descriptor by descriptor on the numpy interpreter of the ABI
+semantics (tests/emu.py) and compared with the oracle.  No HIP kernel runs here; the
+kernels themselves are checked on the GPU (test_gpu_parity.py)."""
+import numpy as np
+import pytest
+import torch
+
+import emu
+from conftest import pkg, rel_l2, seeded
+from oracle import restate as R
+
+TOL = 5e-6
+
+
+def test_pack_roundtrip():
+    P = pkg("packing")
+    rng = np.random.default_rng(0)
+    wk = rng.standard_normal((37, 70))
+    packed = P.pack_a(wk)
+    assert packed.shape == (3, 19, 64)
+    back = emu._unpack_a(packed.reshape(-1), 3, 19)
+    assert np.allclose(back[:37, :70], wk.astype(np.float32))
+    assert np.all(back[37:] == 0) and np.all(back[:, 70:] == 0)
+    w = rng.standard_normal((64, 32))
+    assert np.allclose(emu._unpack_chain(P.pack_chain(w).reshape(-1), 2), w.astype(np.float32))
+    # rho enumerates every accumulator row exactly once per lane half pair
+    assert sorted(P.RHO.reshape(-1).tolist()) == list(range(32))
+
+
+def test_eps_net_plan_vs_oracle(weights):
+    nets = pkg("nets")
+    B, T = 2, 12
+    sd = weights("DiffUNet1")
+    ctx = nets.Ctx("cpu")
+    net = nets.EpsNetPlan(ctx, sd, B, T, time_cond=True, nsteps=1)
+    net.build_time()
+    net.build_step(0)
+    x, xi = seeded((B, 2, T, 161), 3), seeded((B, 2, T, 161), 4) * 0.3
+    t = torch.tensor([4.086654, 22.992493])
+    net.x.copy_(x)
+    net.x_init.copy_(xi)
+    net.tsteps.copy_(t.view(1, B))
+    emu.run(net.descs, ctx.keep)
+    taps = {}
+    with torch.no_grad():
+        ref = R.diffunet1_forward(sd, x, xi, t, taps=taps)
+    assert rel_l2(net.temb[0], taps["temb"]) < TOL
+    assert rel_l2(net.en[0], taps["en_list"][0]) < TOL
+    assert rel_l2(net.en[4].permute(0, 1, 3, 2), taps["en_list"][4]) < TOL
+    assert rel_l2(net.out, ref) < TOL
+
+
+def test_gcrn_and_diffunet_prior_plans_vs_oracle(weights):
+    nets = pkg("nets")
+    B, T = 2, 10
+    x = seeded((B, 2, T, 161), 5)
+    ctx = nets.Ctx("cpu")
+    net = nets.GcrnPlan(ctx, weights("GCRN"), B, T)
+    net.build()
+    net.x.copy_(x)
+    emu.run(net.descs, ctx.keep)
+    taps = {}
+    with torch.no_grad():
+        ref = R.gcrn_forward(weights("GCRN"), x, taps=taps)
+    assert rel_l2(net.e[4], taps["e5"]) < TOL
+    assert rel_l2(net.glstm, taps["glstm"]) < TOL
+    assert rel_l2(net.out, ref) < TOL
+    ctx2 = nets.Ctx("cpu")
+    p = nets.EpsNetPlan(ctx2, weights("DiffUNet"), B, T, time_cond=False)
+    p.build_step(0)
+    p.x.copy_(x)
+    emu.run(p.descs, ctx2.keep)
+    with torch.no_grad():
+        refp = R.diffunet_forward(weights("DiffUNet"), x)
+    assert rel_l2(p.out, refp) < TOL
+
+
+@pytest.mark.parametrize("sigma", [False, True])
+def test_whole_pipeline_plan_vs_oracle(weights, sigma):
+    """wav -> STFT -> GCRN -> 6 reverse steps -> ISTFT as ONE recorded plan (614 operators),
+    ragged length (L % hop != 0), three different input scales."""
+    params = pkg("params").params
+    B, L_ = 2, 1700
+    P = pkg("pipeline").SamplerPipeline("cpu", "GCRN", weights("GCRN"), weights("DiffUNet1"), B, L_=L_,
+                                        fast_sampling=True, use_sigma=sigma)
+    assert list(P.ranges)[:3] == ["stft", "prior", "prologue"] and "step0" in P.ranges and "istft" in P.ranges
+    wav, x_T = pkg("synth").synthetic_waveforms(B, L_, seed=7)
+    wav = wav * torch.tensor([0.1, 3.0])[:, None]
+    P.stft.wav.copy_(wav)
+    P.xT_in.copy_(x_T)
+    emu.run(P.descs, P.ctx.keep)
+    with torch.no_grad():
+        ref_wav, ref_spec = R.enhance("GCRN", weights("GCRN"), weights("DiffUNet1"), wav, x_T, params.noise_schedule,
+                                      params.inference_noise_schedule, True, sigma)
+    assert rel_l2(P.spec, ref_spec) < 2e-5
+    assert rel_l2(P.istft.wav, ref_wav) < 2e-5
+    with pytest.raises(pkg("_lib").PdseError):
+        P.run()  # a CPU-built pipeline must refuse to run: there is no CPU product path
+
+
+def test_step_descriptors_are_cloned_not_repacked(weights):
+    """Later diffusion steps re-use the packed weights of the first and only re-point the
+    per-step time biases."""
+    nets = pkg("nets")
+    ctx = nets.Ctx("cpu")
+    net = nets.EpsNetPlan(ctx, weights("DiffUNet1"), 1, 8, time_cond=True, nsteps=3)
+    net.build_step(0)
+    n_keep = len(ctx.keep)
+    first = [d for d, _ in net.descs]
+    net.build_step(2)
+    assert len(ctx.keep) == n_keep
+    second = [d for d, _ in net.descs[len(first):]]
+    assert len(second) == len(first)
+    delta = 2 * 1 * net.NSLOT * 32 * 4
+    moved = 0
+    for a, b in zip(first, second):
+        assert a.w0 == b.w0 and a.out == b.out
+        if a.bias0 != b.bias0:
+            assert b.bias0 - a.bias0 == delta
+            moved += 1
+        if a.padrow != b.padrow:
+            assert b.padrow - a.padrow == delta
+    assert moved == 15
+
+
+def test_stft_bases_against_numpy_fft():
+    P = pkg("packing")
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal(320)
+    spec = np.fft.rfft(x * P.hann_periodic(320))
+    got = x @ P.stft_kmat(320)
+    assert np.allclose(got[:161], spec.real) and np.allclose(got[161:], spec.imag)
+    z = rng.standard_normal(161) + 1j * rng.standard_normal(161)
+    frame = np.fft.irfft(z, 320) * P.hann_periodic(320)
+    k = np.empty(322)
+    k[0::2], k[1::2] = z.real, z.imag
+    assert np.allclose(k @ P.istft_kmat(320), frame)
