@@ -61,7 +61,7 @@ typedef struct pdse_src {
  * torch.istft DFTs of trainer/complex_ddpm_trainer.py:926-930, :1010-1015.
  * Weights are pre-packed on the host into MFMA A-fragment order:
  *   w[mtile][kstep][lane] = W[k = 2*kstep + (lane>>5)][co = 32*mtile + (lane&31)],
- *   k = tap*Cin + ci.
+ *   k = tap*Cin + ci  (korder 0)   or   kstep = (ci/2)*ntaps + tap  (korder 1).
  */
 typedef struct pdse_gconv_desc {
   pdse_src in0, in1; /* in1.C == 0: single source */
@@ -105,6 +105,10 @@ typedef struct pdse_gconv_desc {
   int64_t out_sb, out_sc_hi, out_sc_lo, out_st, out_sf, out_off;
   int32_t out_cr; /* co -> (co / out_cr)*out_sc_hi + (co % out_cr)*out_sc_lo */
   int32_t B, Tout, Fout;
+  /* K order of the packed weights: 0: k = tap*Cin + ci (generic kernel); 1: k-step =
+     (ci/2)*ntaps + tap, k = 2*kstep + (ci&1) (pipelined kernel: taps innermost, unrolled) */
+  int32_t korder;
+  int32_t pad_;
 } pdse_gconv_desc;
 
 /* Diffusion-step embedding + every per-stage time bias folded through the following 1x1

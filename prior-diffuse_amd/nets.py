@@ -48,6 +48,8 @@ class Ctx:
 
 
 class PlanBase:
+    force_generic = False   # tests: route every convolution through the un-pipelined kernel
+
     def __init__(self, ctx, plan=None):
         self.ctx = ctx
         self.descs = []  # python-side copy of every descriptor (tests replay these on the CPU emulator)
@@ -87,6 +89,12 @@ class PlanBase:
                 d.xf_scale1, d.xf_shift1 = ctx.up(xf["scale1"]).data_ptr(), ctx.up(xf["shift1"]).data_ptr()
                 d.xf_slope1 = float(xf["slope1"])
         d.cin1 = 1 if cin1 else 0
+        wk0 = np.asarray(wk0)
+        if P.v2_supported(epi, len(taps), d.in1.C > 0, d.xf_mode, cin1) and not self.force_generic:
+            rows = P.korder1_rows(len(taps), d.in0.C + d.in1.C)      # pipelined kernel: taps innermost
+            wk0 = wk0[rows]
+            wk1 = None if wk1 is None else np.asarray(wk1)[rows]
+            d.korder = 1
         w0 = P.pack_a(wk0)
         d.w0, d.ksteps, d.Cout = ctx.up(w0).data_ptr(), w0.shape[1], Cout
         if wk1 is not None:

@@ -36,6 +36,27 @@ def pack_a(wk):
     return out
 
 
+# (epilogue, taps, two sources, load transform) combinations that have a pipelined
+# (korder 1) instantiation in csrc/gconv2.hip::pdse_gconv2_launch — keep in sync.
+_V2 = {
+    (0, 1, False, 0), (0, 1, False, 1), (0, 1, True, 0), (0, 4, False, 0),
+    (1, 1, True, 0), (1, 2, True, 0), (1, 3, False, 0), (1, 5, False, 2),
+    (2, 2, False, 0), (2, 4, False, 0), (2, 6, False, 0), (2, 10, False, 0),
+}
+
+
+def v2_supported(epi, ntaps, two_src, xf_mode, cin1):
+    return (not cin1) and (epi, ntaps, bool(two_src), xf_mode) in _V2
+
+
+def korder1_rows(ntaps, cin):
+    """Row permutation tap-major (k = tap*Cin + ci) -> pair-major (kstep = (ci/2)*ntaps + tap)."""
+    gp = np.arange(cin // 2)[:, None, None]
+    tap = np.arange(ntaps)[None, :, None]
+    hh = np.arange(2)[None, None, :]
+    return (tap * cin + 2 * gp + hh).reshape(-1)
+
+
 def pack_chain(w):
     """w [Mout, 32] (out x in) for a 1x1 product fed from an accumulator tile
     -> float32 [mtiles, 16, 64] with k ordered by rho."""

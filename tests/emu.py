@@ -13,6 +13,7 @@ import numpy as np
 import torch
 
 L = importlib.import_module("prior-diffuse_amd._lib")
+P = importlib.import_module("prior-diffuse_amd.packing")
 
 RHO = np.array([[(r & 3) + 8 * (r >> 2) + 4 * h for h in (0, 1)] for r in range(16)])
 
@@ -79,6 +80,12 @@ def run_gconv(d, mem):
     W0 = _unpack_a(mem.arr(d.w0, mtiles * d.ksteps * 64), mtiles, d.ksteps)
     W1 = _unpack_a(mem.arr(d.w1, mtiles * d.ksteps * 64), mtiles, d.ksteps) if dual else None
     taps = mem.arr(d.taps, 2 * d.ntaps, np.int32).reshape(-1, 2)
+    if d.korder == 1:   # rows are (channel pair, tap, parity): bring them back to tap-major
+        rows = P.korder1_rows(d.ntaps, Cin)
+        inv = np.empty_like(rows)
+        inv[rows] = np.arange(len(rows))
+        W0 = W0[inv]
+        W1 = W1[inv] if dual else None
     bI = np.arange(B)[:, None, None, None]
     tI = np.arange(To)[None, None, :, None]
     jI = np.arange(Fo)[None, None, None, :]

@@ -277,3 +277,22 @@ def test_trainer_surface(L, weights, tmp_path):
         assert y.shape == (n,) and np.isfinite(y).all()
     with pytest.raises(NotImplementedError):
         t.train_ddpm()
+
+
+def test_pipelined_kernel_agrees_with_generic_kernel(L, weights, monkeypatch):
+    """Both forms of the gather-GEMM (korder 0: tap-major generic loop, korder 1: pipelined,
+    taps innermost) compute the same layers; only the K summation order differs."""
+    nets = pkg("nets")
+    x = seeded((2, 2, 40, 161), 77).to(DEV)
+    xi = (seeded((2, 2, 40, 161), 78) * 0.3).to(DEV)
+    t = torch.tensor([10.451817, 0.8941341], device=DEV)
+    fast = pkg("ops").DiffUNet1Op(weights("DiffUNet1"), DEV)(x, xi, t)
+    g_fast = pkg("ops").GCRNOp(weights("GCRN"), DEV)(x)
+    monkeypatch.setattr(nets.PlanBase, "force_generic", True)
+    op = pkg("ops").DiffUNet1Op(weights("DiffUNet1"), DEV)
+    slow = op(x, xi, t)
+    assert all(d.korder == 0 for d, _ in op._plans[(2, 40)].descs if isinstance(d, L.GconvDesc))
+    g_slow = pkg("ops").GCRNOp(weights("GCRN"), DEV)(x)
+    _sync()
+    assert rel_l2(fast.cpu(), slow.cpu()) < 1e-5
+    assert rel_l2(g_fast.cpu(), g_slow.cpu()) < 1e-5
