@@ -163,7 +163,8 @@ int pdse_gconv_launch(const pdse_gconv_desc* d, hipStream_t s) {
   } else {
     PDSE_REQUIRE(Cin >= 2 && (d->in0.C % 2) == 0 && (d->in1.C % 2) == 0, "channel counts must be even");
     PDSE_REQUIRE(d->in1.C == 0 || d->in1.ptr, "in1 has channels but no pointer");
-    PDSE_REQUIRE(d->ksteps == d->ntaps * (Cin / 2), "ksteps != ntaps*Cin/2");
+    if (d->korder == 0) PDSE_REQUIRE(d->ksteps == d->ntaps * (Cin / 2), "ksteps != ntaps*Cin/2");
+    else PDSE_REQUIRE(d->ksteps >= d->ntaps * (Cin / 2), "ksteps < ntaps*Cin/2");
   }
   if (d->xf_mode) {
     PDSE_REQUIRE(d->xf_scale0 && d->xf_shift0, "xf_mode set without scale/shift");

@@ -10,6 +10,11 @@
 //   * the loop walks channel-pair chunks of CP pairs = CP*NT k-steps; the activation values
 //     and all A fragments of chunk i+1 are issued before the MFMAs of chunk i (two register
 //     sets, ping-pong), so loads overlap the 64-cycle MFMAs instead of preceding each one;
+//   * the second profile (profiles/r01_pmc_sq_v2.txt) showed the MFMA pipe 40 % busy with the
+//     waves stalled at issue: two global_load_dword per MFMA saturate the vector-memory path.
+//     Weight fragments are therefore packed 4 k-steps deep and fetched with one 16-byte load
+//     per lane, and the encoder's pad frame is materialised in the input instead of being
+//     patched in by a second load per tap (0.75 load instructions per MFMA instead of 2);
 //   * the launcher splits output-channel tiles over more waves when a layer has few
 //     positions (TCM: 13 tiles per utterance), trading activation re-reads for occupancy.
 #include <hip/hip_runtime.h>
@@ -20,19 +25,26 @@
 
 #include "gconv_common.h"
 
-template <int N, int CP>
+template <int N, int CP, int MT>
 struct Chunk {
-  float v[N];       // raw activation per k-step (lane = position, half = channel parity)
-  float a0[N][4];   // A fragments, up to 4 M tiles
-  float a1[N][4];
+  float v[N];           // raw activation per k-step (lane = position, half = channel parity)
+  float4 a0[N / 4][MT];  // A fragments: one 16-byte load covers 4 consecutive k-steps
+  float4 a1[N / 4][MT];
   float xs0[CP], xh0[CP], xs1[CP], xh1[CP];  // load-transform parameters (TCM only, XF != 0)
 };
 
+__device__ __forceinline__ float f4get(const float4& q, const int i) {
+  return i == 0 ? q.x : (i == 1 ? q.y : (i == 2 ? q.z : q.w));
+}
+
 // XF: 0 no load transform; 1 one PReLU->BN set for both accumulators; 2 one set per accumulator
-template <int EPI, int MT, int NT, int CP, bool SRC2, int XF>
+// PP: ping-pong two register sets (layers with few waves per SIMD need the ILP); otherwise one
+//     set per chunk and the other resident waves hide the load latency.
+template <int EPI, int MT, int NT, int CP, bool SRC2, int XF, bool PP>
 __global__ __launch_bounds__(256) void gconv2_kernel(const pdse_gconv_desc d) {
   constexpr bool DUAL = (EPI != PDSE_EPI_LINEAR);
   constexpr int N = NT * CP;
+  static_assert(N % 4 == 0, "a chunk must hold whole 4-k-step weight groups");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = lane & 31, h = lane >> 5;
   const int b = blockIdx.y;
@@ -56,34 +68,30 @@ __global__ __launch_bounds__(256) void gconv2_kernel(const pdse_gconv_desc d) {
 
   // ---- per-tap gather state, computed once
   int off0[NT], off1[SRC2 ? NT : 1];
-  unsigned inb_mask = 0, isp_mask = 0;
+  unsigned inb_mask = 0;
 #pragma unroll
   for (int tap = 0; tap < NT; ++tap) {
     const int dt = d.taps[2 * tap], df = d.taps[2 * tap + 1];
     const int tin = t + dt, fin = j * d.sf_in + df;
-    const bool fok = pvalid && fin >= 0 && fin < d.Fin;
-    const bool inb = fok && tin >= 0 && tin < d.Tin;
+    const bool inb = pvalid && fin >= 0 && fin < d.Fin && tin >= 0 && tin < d.Tin;
     if (inb) inb_mask |= 1u << tap;
-    if (fok && tin == -1 && d.padrow != nullptr) isp_mask |= 1u << tap;
     off0[tap] = inb ? (int)((int64_t)b * d.in0.sb + (int64_t)tin * d.in0.st + (int64_t)fin * d.in0.sf + (int64_t)h * d.in0.sc) : 0;
     if (SRC2)
       off1[tap] = inb ? (int)((int64_t)b * d.in1.sb + (int64_t)tin * d.in1.st + (int64_t)fin * d.in1.sf + (int64_t)h * d.in1.sc) : 0;
   }
-  const int ksteps = d.ksteps;
-  const float* wp0 = d.w0 + (size_t)mt0 * ksteps * 64 + lane;
-  const float* wp1 = DUAL ? d.w1 + (size_t)mt0 * ksteps * 64 + lane : nullptr;
+  const int kgroups = d.ksteps >> 2;   // host pads ksteps to a multiple of 4
+  const float4* wq0 = reinterpret_cast<const float4*>(d.w0) + (size_t)mt0 * kgroups * 64 + lane;
+  const float4* wq1 = DUAL ? reinterpret_cast<const float4*>(d.w1) + (size_t)mt0 * kgroups * 64 + lane : nullptr;
   const int cps0 = d.in0.C >> 1;
   const int cps1 = SRC2 ? (d.in1.C >> 1) : 0;
   const int nch0 = (cps0 + CP - 1) / CP, nch1 = (cps1 + CP - 1) / CP;
   const int nchunks = nch0 + nch1;
-  // frame -1 of the encoder reads the folded time bias; without a pad row the pointer still
-  // names readable memory (never selected: isp_mask is 0) so the load below needs no branch
-  const float* prow = d.padrow ? d.padrow + (int64_t)b * d.padrow_sb + h : d.w0;
+  // chunks are laid out back to back in the packed weights: chunk q starts at k-group q*N/4
+  // (the host packs source 0's pairs padded to a multiple of CP, then source 1's)
 
-  // chunk q -> (source s, first pair cp0); pairs are numbered globally: gp = (s ? cps0 : 0) + cp.
   // Straight-line code: every load is unconditional from a clamped (always readable) address
   // and masked afterwards, so the whole chunk is one scheduling region of independent loads.
-  auto issue = [&](Chunk<N, CP>& c, const int q) {
+  auto issue = [&](Chunk<N, CP, MT>& c, const int q) {
     const bool s1 = SRC2 && q >= nch0;
     const int cp0 = (s1 ? q - nch0 : q) * CP;
     const int cps = s1 ? cps1 : cps0;
@@ -91,31 +99,27 @@ __global__ __launch_bounds__(256) void gconv2_kernel(const pdse_gconv_desc d) {
     const float* sp = s1 ? d.in1.ptr : d.in0.ptr;
     const int sc2 = (int)(2 * (s1 ? d.in1.sc : d.in0.sc));
 #pragma unroll
+    for (int g4 = 0; g4 < N / 4; ++g4) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int mc = (mt0 + m < mtiles) ? m : 0;   // tiles past Cout re-read tile 0; never stored
+        c.a0[g4][m] = wq0[((size_t)mc * kgroups + (size_t)q * (N / 4) + g4) * 64];
+        if (DUAL) c.a1[g4][m] = wq1[((size_t)mc * kgroups + (size_t)q * (N / 4) + g4) * 64];
+      }
+    }
+#pragma unroll
     for (int cc = 0; cc < CP; ++cc) {
-      const bool live = cp0 + cc < cps;
-      const int cp = live ? cp0 + cc : cps - 1;
-      const int gp = gbase + cp;
+      // pairs past the end of a source are clamped to its last pair: the host packs ZERO weight
+      // rows there, so the (finite) value read is multiplied away — no uniform branch, which
+      // hipcc would turn into per-load control flow with a vmcnt(0) at every join
+      const int cp = min(cp0 + cc, cps - 1);
 #pragma unroll
       for (int tap = 0; tap < NT; ++tap) {
-        const int i = cc * NT + tap;
         const int o = (SRC2 && s1) ? off1[tap] : off0[tap];
-        float v = sp[o + cp * sc2];
-        v = ((inb_mask >> tap) & 1u) ? v : 0.f;
-        if constexpr (EPI == PDSE_EPI_BIGLU) {
-          const float pv = prow[2 * gp];
-          v = ((isp_mask >> tap) & 1u) ? pv : v;
-        }
-        c.v[i] = live ? v : 0.f;
-        const int ks = gp * NT + tap;
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          const int mc = (mt0 + m < mtiles) ? m : 0;   // tiles past Cout re-read tile 0; never stored
-          c.a0[i][m] = wp0[((size_t)mc * ksteps + ks) * 64];
-          if (DUAL) c.a1[i][m] = wp1[((size_t)mc * ksteps + ks) * 64];
-        }
+        c.v[cc * NT + tap] = sp[o + cp * sc2];   // raw: masking happens at use, or the wait would sit here
       }
       if constexpr (XF != 0) {
-        const int ci = 2 * gp + h;
+        const int ci = 2 * (gbase + cp) + h;
         c.xs0[cc] = d.xf_scale0[ci];
         c.xh0[cc] = d.xf_shift0[ci];
         if constexpr (XF == 2) {
@@ -124,10 +128,10 @@ __global__ __launch_bounds__(256) void gconv2_kernel(const pdse_gconv_desc d) {
         }
       }
     }
-    __builtin_amdgcn_sched_barrier(0);  // keep the chunk's loads together, ahead of the other chunk's MFMAs
+    __builtin_amdgcn_sched_barrier(0);  // keep the chunk's loads together, ahead of the MFMAs
   };
 
-  auto consume = [&](Chunk<N, CP>& c, const int q) {
+  auto consume = [&](Chunk<N, CP, MT>& c, const int q) {
     // ELU on load exists only for the GCRN decoder's skip source (gcrn.py:152-155)
     bool elu_src = false;
     if constexpr (SRC2 && EPI == PDSE_EPI_GLU) elu_src = (q >= nch0) ? d.in1.act == PDSE_ACT_ELU : d.in0.act == PDSE_ACT_ELU;
@@ -136,14 +140,14 @@ __global__ __launch_bounds__(256) void gconv2_kernel(const pdse_gconv_desc d) {
 #pragma unroll
       for (int tap = 0; tap < NT; ++tap) {
         const int i = cc * NT + tap;
-        float v = c.v[i];
+        const bool inb = (inb_mask >> tap) & 1u;
+        float v = inb ? c.v[i] : 0.f;
         if constexpr (SRC2 && EPI == PDSE_EPI_GLU) {
           const float e = expm1f(fminf(v, 0.f));   // elu(0) = 0 keeps masked lanes at zero
           v = (elu_src && v < 0.f) ? e : v;
         }
         float v0 = v, v1 = v;
         if constexpr (XF != 0) {
-          const bool inb = (inb_mask >> tap) & 1u;
           const float u = v > 0.f ? v : d.xf_slope0 * v;
           v0 = inb ? u * c.xs0[cc] + c.xh0[cc] : 0.f;   // zero padding is applied AFTER PReLU->BN (diff3.py:221-231)
           if constexpr (XF == 2) {
@@ -155,24 +159,32 @@ __global__ __launch_bounds__(256) void gconv2_kernel(const pdse_gconv_desc d) {
         }
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-          acc0[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(c.a0[i][m], v0, acc0[m], 0, 0, 0);
-          if (DUAL) acc1[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(c.a1[i][m], v1, acc1[m], 0, 0, 0);
+          acc0[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4get(c.a0[i >> 2][m], i & 3), v0, acc0[m], 0, 0, 0);
+          if (DUAL) acc1[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4get(c.a1[i >> 2][m], i & 3), v1, acc1[m], 0, 0, 0);
         }
       }
     }
   };
 
-  // ---- ping-pong over the chunks: loads of q+1 are in flight while q is multiplied
-  Chunk<N, CP> ca, cb;
-  issue(ca, 0);
-  int q = 0;
-  for (; q + 1 < nchunks; q += 2) {
-    issue(cb, q + 1);
-    consume(ca, q);
-    if (q + 2 < nchunks) issue(ca, q + 2);
-    consume(cb, q + 1);
+  if constexpr (PP) {
+    // ping-pong over the chunks: loads of q+1 are in flight while q is multiplied
+    Chunk<N, CP, MT> ca, cb;
+    issue(ca, 0);
+    int q = 0;
+    for (; q + 1 < nchunks; q += 2) {
+      issue(cb, q + 1);
+      consume(ca, q);
+      if (q + 2 < nchunks) issue(ca, q + 2);
+      consume(cb, q + 1);
+    }
+    if (q < nchunks) consume(ca, q);
+  } else {
+    Chunk<N, CP, MT> ca;
+    for (int q = 0; q < nchunks; ++q) {
+      issue(ca, q);
+      consume(ca, q);
+    }
   }
-  if (q < nchunks) consume(ca, q);
 
   gconv_epilogue<EPI, MT>(d, acc0, acc1, b, t, j, pvalid, lane, h, mt0, mtiles);
 }
@@ -193,18 +205,19 @@ static int pick_mt(const pdse_gconv_desc* d, int mtiles, int max_mt) {
   return mt;
 }
 
-template <int EPI, int NT, int CP, bool SRC2, int XF>
+// PP1/PP2/PP4: ping-pong at 1, 2, 4 channel tiles per wave (register budget decides)
+template <int EPI, int NT, int CP, bool SRC2, int XF, bool PP1, bool PP2, bool PP4>
 static void launch_mt(const pdse_gconv_desc* d, hipStream_t s, int mt, int gx, int mtiles) {
   const dim3 block(256);
   if constexpr (EPI == PDSE_EPI_BIGLU) {
-    hipLaunchKernelGGL((gconv2_kernel<EPI, 1, NT, CP, SRC2, XF>), dim3(gx, d->B, 1), block, 0, s, *d);
+    hipLaunchKernelGGL((gconv2_kernel<EPI, 1, NT, CP, SRC2, XF, PP1>), dim3(gx, d->B, 1), block, 0, s, *d);
   } else {
     if (mt >= 4)
-      hipLaunchKernelGGL((gconv2_kernel<EPI, 4, NT, (CP > 1 ? CP / 2 : 1), SRC2, XF>), dim3(gx, d->B, (mtiles + 3) / 4), block, 0, s, *d);
+      hipLaunchKernelGGL((gconv2_kernel<EPI, 4, NT, CP, SRC2, XF, PP4>), dim3(gx, d->B, (mtiles + 3) / 4), block, 0, s, *d);
     else if (mt == 2)
-      hipLaunchKernelGGL((gconv2_kernel<EPI, 2, NT, CP, SRC2, XF>), dim3(gx, d->B, (mtiles + 1) / 2), block, 0, s, *d);
+      hipLaunchKernelGGL((gconv2_kernel<EPI, 2, NT, CP, SRC2, XF, PP2>), dim3(gx, d->B, (mtiles + 1) / 2), block, 0, s, *d);
     else
-      hipLaunchKernelGGL((gconv2_kernel<EPI, 1, NT, CP, SRC2, XF>), dim3(gx, d->B, mtiles), block, 0, s, *d);
+      hipLaunchKernelGGL((gconv2_kernel<EPI, 1, NT, CP, SRC2, XF, PP1>), dim3(gx, d->B, mtiles), block, 0, s, *d);
   }
 }
 
@@ -224,26 +237,31 @@ int pdse_gconv2_launch(const pdse_gconv_desc* d, hipStream_t s) {
   // GLU keeps two accumulator sets: 4 tiles each would leave one wave per SIMD (268 VGPRs)
   const int mt = pick_mt(d, mtiles, d->epi == PDSE_EPI_GLU ? 2 : 4);
   const int xf = d->xf_mode;
-#define GO(EPI, NT, CP, SRC2, XF)                              \
-  do {                                                         \
-    launch_mt<EPI, NT, CP, SRC2, XF>(d, s, mt, gx, mtiles);    \
-    return pdse_check_launch("gconv2");                        \
+  if (d->padrow != nullptr || (d->ksteps & 3) != 0) {
+    pdse_set_error("gconv2: korder 1 needs ksteps % 4 == 0 and no pad row (materialise frame -1 in the input)");
+    return 1;
+  }
+  // (CP must match packing.V2_CP: the host pads each source's pairs to a multiple of CP)
+#define GO(EPI, NT, CP, SRC2, XF, PP1, PP2, PP4)                              \
+  do {                                                                        \
+    launch_mt<EPI, NT, CP, SRC2, XF, PP1, PP2, PP4>(d, s, mt, gx, mtiles);    \
+    return pdse_check_launch("gconv2");                                       \
   } while (0)
   if (d->epi == PDSE_EPI_LINEAR) {
-    if (nt == 1 && !two && xf == 0) GO(PDSE_EPI_LINEAR, 1, 8, false, 0);
-    if (nt == 1 && !two && xf == 1) GO(PDSE_EPI_LINEAR, 1, 8, false, 1);
-    if (nt == 1 && two && xf == 0) GO(PDSE_EPI_LINEAR, 1, 8, true, 0);
-    if (nt == 4 && !two && xf == 0) GO(PDSE_EPI_LINEAR, 4, 2, false, 0);
+    if (nt == 1 && !two && xf == 0) GO(PDSE_EPI_LINEAR, 1, 8, false, 0, true, true, true);
+    if (nt == 1 && !two && xf == 1) GO(PDSE_EPI_LINEAR, 1, 8, false, 1, true, true, true);
+    if (nt == 1 && two && xf == 0) GO(PDSE_EPI_LINEAR, 1, 8, true, 0, true, true, true);
+    if (nt == 4 && !two && xf == 0) GO(PDSE_EPI_LINEAR, 4, 2, false, 0, true, true, true);
   } else if (d->epi == PDSE_EPI_GLU) {
-    if (nt == 1 && two && xf == 0) GO(PDSE_EPI_GLU, 1, 4, true, 0);
-    if (nt == 2 && two && xf == 0) GO(PDSE_EPI_GLU, 2, 2, true, 0);
-    if (nt == 3 && !two && xf == 0) GO(PDSE_EPI_GLU, 3, 2, false, 0);
-    if (nt == 5 && !two && xf == 2) GO(PDSE_EPI_GLU, 5, 1, false, 2);
+    if (nt == 1 && two && xf == 0) GO(PDSE_EPI_GLU, 1, 4, true, 0, true, true, true);
+    if (nt == 2 && two && xf == 0) GO(PDSE_EPI_GLU, 2, 2, true, 0, true, true, true);
+    if (nt == 3 && !two && xf == 0) GO(PDSE_EPI_GLU, 3, 4, false, 0, true, false, false);
+    if (nt == 5 && !two && xf == 2) GO(PDSE_EPI_GLU, 5, 4, false, 2, true, false, false);
   } else if (d->epi == PDSE_EPI_BIGLU && !two && xf == 0) {
-    if (nt == 2) GO(PDSE_EPI_BIGLU, 2, 4, false, 0);
-    if (nt == 4) GO(PDSE_EPI_BIGLU, 4, 2, false, 0);
-    if (nt == 6) GO(PDSE_EPI_BIGLU, 6, 1, false, 0);
-    if (nt == 10) GO(PDSE_EPI_BIGLU, 10, 1, false, 0);
+    if (nt == 2) GO(PDSE_EPI_BIGLU, 2, 4, false, 0, true, true, true);
+    if (nt == 4) GO(PDSE_EPI_BIGLU, 4, 2, false, 0, true, true, true);
+    if (nt == 6) GO(PDSE_EPI_BIGLU, 6, 2, false, 0, true, true, true);
+    if (nt == 10) GO(PDSE_EPI_BIGLU, 10, 2, false, 0, false, false, false);
   }
 #undef GO
   pdse_set_error("gconv2: no pipelined instantiation for this (epilogue, taps, sources); pack with korder 0");

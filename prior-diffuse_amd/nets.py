@@ -90,15 +90,19 @@ class PlanBase:
                 d.xf_slope1 = float(xf["slope1"])
         d.cin1 = 1 if cin1 else 0
         wk0 = np.asarray(wk0)
-        if P.v2_supported(epi, len(taps), d.in1.C > 0, d.xf_mode, cin1) and not self.force_generic:
-            rows = P.korder1_rows(len(taps), d.in0.C + d.in1.C)      # pipelined kernel: taps innermost
-            wk0 = wk0[rows]
-            wk1 = None if wk1 is None else np.asarray(wk1)[rows]
+        key = (epi, len(taps), d.in1.C > 0, d.xf_mode)
+        if P.v2_supported(*key, cin1) and padrow is None and not self.force_generic:
+            rows = P.korder1_rows(len(taps), d.in0.C, d.in1.C, P.V2_CP[key])    # pipelined kernel order
+            w0 = P.pack_a4(wk0, rows)
+            d.w0, d.ksteps, d.Cout = ctx.up(w0).data_ptr(), len(rows) // 2, Cout
+            if wk1 is not None:
+                d.w1 = ctx.up(P.pack_a4(wk1, rows)).data_ptr()
             d.korder = 1
-        w0 = P.pack_a(wk0)
-        d.w0, d.ksteps, d.Cout = ctx.up(w0).data_ptr(), w0.shape[1], Cout
-        if wk1 is not None:
-            d.w1 = ctx.up(P.pack_a(wk1)).data_ptr()
+        else:
+            w0 = P.pack_a(wk0)
+            d.w0, d.ksteps, d.Cout = ctx.up(w0).data_ptr(), w0.shape[1], Cout
+            if wk1 is not None:
+                d.w1 = ctx.up(P.pack_a(wk1)).data_ptr()
 
         def dev(x):
             if x is None:
@@ -158,7 +162,7 @@ class EpsNetPlan(PlanBase):
         self.x = a(B, 2, T, F0)
         self.x_init = a(B, 2, T, F0) if time_cond else None
         self.out = a(B, 2, T, F0)
-        self.H = a(B, 32, T, F0)                     # conv1 output of the current block (largest: F=161)
+        self.H = a(B, 32, T + 1, F0)                 # conv1 output of the current block (+ explicit pad frame)
         self.en = [a(B, 64, T, f) for f in self.ENC_F[1:5]] + [a(B, 64, 4, T)]  # en5 stored [B,64,4,T]
         self.tcm_a, self.tcm_b = a(B, 256, T), a(B, 256, T)
         self.tcm_h, self.tcm_g = a(B, 64, T), a(B, 64, T)
@@ -244,20 +248,34 @@ class EpsNetPlan(PlanBase):
         else:
             b1 = self.ctx.up(self.w(p + ".conv1.bias"))
             bias0, pad, off_real, off_pad, sbb = b1, b1, 0, 0, 0
-        self.gconv(in0=src_x, in1=src_init, Tin=T, Fin=Fin, taps=[(0, 0)], sf_in=1, wk0=W1.T, Cout=32,
-                   bias0=bias0, bias0_off=off_real, bias0_sb=sbb, out=self.H, out_strides=nchw_out(32, T, Fin),
-                   B=B, Tout=T, Fout=Fin, tag=TAG_EPS_CONV1)
-        kk, taps = P.conv_taps(2, kw, 1)
+        # H = conv1 output with an explicit frame -1 in row 0: the reference pads the input with one
+        # zero frame on top and THEN adds the time bias (diff3.py:146-147), so that frame is
+        # conv1(0 + tp) = the folded bias.  Rows 1..T hold the real frames.
+        HT = T + 1
+        h_out = (32 * HT * Fin, HT * Fin, 0, Fin, 1)
+        if k == 1 and self.time_cond:
+            # real frames carry W1*b_preprocess in their bias (slot 15), the pad frame does not (slot 0)
+            self.gconv(in0=src_x, in1=src_init, Tin=T, Fin=Fin, taps=[(0, 0)], sf_in=1, wk0=W1.T, Cout=32,
+                       bias0=bias0, bias0_off=off_real, bias0_sb=sbb, out=self.H, out_strides=h_out, out_off=Fin,
+                       B=B, Tout=T, Fout=Fin, tag=TAG_EPS_CONV1)
+            self.gconv(in0=src_x, in1=src_init, Tin=T, Fin=Fin, taps=[(-(T + 1), 0)], sf_in=1, wk0=W1.T, Cout=32,
+                       bias0=pad, bias0_off=off_pad, bias0_sb=sbb, out=self.H, out_strides=h_out,
+                       B=B, Tout=1, Fout=Fin, tag=TAG_EPS_CONV1)
+        else:
+            # same bias for every frame: one launch over T+1 output frames reading input frame r-1
+            self.gconv(in0=src_x, in1=src_init, Tin=T, Fin=Fin, taps=[(-1, 0)], sf_in=1, wk0=W1.T, Cout=32,
+                       bias0=bias0, bias0_off=off_real, bias0_sb=sbb, out=self.H, out_strides=h_out,
+                       B=B, Tout=HT, Fout=Fin, tag=TAG_EPS_CONV1)
+        kk, taps = P.conv_taps(2, kw, 0)            # H row r = frame r-1: weight row kt reads H row t + kt
         post = P.bn_fold(self.sd, "en.en%d.0" % k)
         chain = dict(C2=64, wlc=self.w(p + ".l_conv.weight")[:, :, 0, 0], blc=self.w(p + ".l_conv.bias"),
                      wrc=self.w(p + ".r_conv.weight")[:, :, 0, 0], brc=self.w(p + ".r_conv.bias"),
                      wc2=self.w(p + ".conv2.weight")[:, :, 0, 0], bc2=self.w(p + ".conv2.bias"))
-        self.gconv(in0=self.src(self.H, 32, *nchw(32, T, Fin)), Tin=T, Fin=Fin, taps=taps, sf_in=2,
+        self.gconv(in0=self.src(self.H, 32, *nchw(32, HT, Fin)), Tin=HT, Fin=Fin, taps=taps, sf_in=2,
                    wk0=P.conv_kmat(self.sd[p + ".l.weight"], kk), wk1=P.conv_kmat(self.sd[p + ".r.weight"], kk),
                    Cout=32, bias0=self.w(p + ".l.bias"), bias1=self.w(p + ".r.bias"), epi=L.EPI_BIGLU,
                    act=L.ACT_PRELU, act_slope=float(self.w("en.en%d.1.weight" % k)[0]), post=post,
-                   padrow=pad, padrow_off=off_pad, padrow_sb=sbb, chain=chain, out=out_t,
-                   out_strides=out_strides, B=B, Tout=T, Fout=Fout, tag=TAG_EPS_BLOCK)
+                   chain=chain, out=out_t, out_strides=out_strides, B=B, Tout=T, Fout=Fout, tag=TAG_EPS_BLOCK)
         return Fout
 
     def _biconvtransglu(self, step, slot, p, k, in0, in1, Fin, out_t, out_strides_fn, bn_prefix, prelu_key):

@@ -36,25 +36,61 @@ def pack_a(wk):
     return out
 
 
-# (epilogue, taps, two sources, load transform) combinations that have a pipelined
-# (korder 1) instantiation in csrc/gconv2.hip::pdse_gconv2_launch — keep in sync.
-_V2 = {
-    (0, 1, False, 0), (0, 1, False, 1), (0, 1, True, 0), (0, 4, False, 0),
-    (1, 1, True, 0), (1, 2, True, 0), (1, 3, False, 0), (1, 5, False, 2),
-    (2, 2, False, 0), (2, 4, False, 0), (2, 6, False, 0), (2, 10, False, 0),
+# (epilogue, taps, two sources, load transform) -> channel pairs per chunk (CP) of the pipelined
+# (korder 1) instantiations in csrc/gconv2.hip::pdse_gconv2_launch — keep in sync.
+V2_CP = {
+    (0, 1, False, 0): 8, (0, 1, False, 1): 8, (0, 1, True, 0): 8, (0, 4, False, 0): 2,
+    (1, 1, True, 0): 4, (1, 2, True, 0): 2, (1, 3, False, 0): 4, (1, 5, False, 2): 4,
+    (2, 2, False, 0): 4, (2, 4, False, 0): 2, (2, 6, False, 0): 2, (2, 10, False, 0): 2,
 }
 
 
 def v2_supported(epi, ntaps, two_src, xf_mode, cin1):
-    return (not cin1) and (epi, ntaps, bool(two_src), xf_mode) in _V2
+    return (not cin1) and (epi, ntaps, bool(two_src), xf_mode) in V2_CP
 
 
-def korder1_rows(ntaps, cin):
-    """Row permutation tap-major (k = tap*Cin + ci) -> pair-major (kstep = (ci/2)*ntaps + tap)."""
-    gp = np.arange(cin // 2)[:, None, None]
-    tap = np.arange(ntaps)[None, :, None]
-    hh = np.arange(2)[None, None, :]
-    return (tap * cin + 2 * gp + hh).reshape(-1)
+def korder1_rows(ntaps, c0, c1, cp):
+    """Row order of the pipelined kernel: for each source, channel pairs in chunks of ``cp``
+    (the last chunk of a source zero-padded), taps innermost; each k-step holds the two
+    channels of a pair.  Returns tap-major row indices (k = tap*Cin + ci), -1 = zero row."""
+    cin = c0 + c1
+    rows = []
+    for cbase, c in ((0, c0), (c0, c1)):
+        cps = c // 2
+        for q in range((cps + cp - 1) // cp):
+            for cc in range(cp):
+                pair = q * cp + cc
+                for tap in range(ntaps):
+                    for hh in (0, 1):
+                        rows.append(tap * cin + cbase + 2 * pair + hh if pair < cps else -1)
+    rows = np.asarray(rows)
+    assert (len(rows) // 2) % 4 == 0
+    return rows
+
+
+def pack_a4(wk, rows):
+    """Pipelined-kernel weights: rows of wk [K, M] re-ordered by ``rows`` (korder1_rows) and
+    packed 4 k-steps deep: float32 [mtiles, ksteps/4, 64 lanes, 4]."""
+    wk = np.asarray(wk, np.float64)
+    M = wk.shape[1]
+    ordered = np.where((rows >= 0)[:, None], wk[np.maximum(rows, 0)], 0.0)   # [2*ksteps, M]
+    ksteps, mtiles = len(rows) // 2, (M + 31) // 32
+    pad = np.zeros((2 * ksteps, mtiles * 32))
+    pad[:, :M] = ordered
+    g = np.arange(ksteps // 4)[:, None, None]
+    lane_h = _H[None, :, None]
+    i = np.arange(4)[None, None, :]
+    k_idx = 2 * (4 * g + i) + lane_h                                  # [groups, 64, 4]
+    out = np.empty((mtiles, ksteps // 4, 64, 4), np.float32)
+    for mt in range(mtiles):
+        out[mt] = pad[k_idx, (32 * mt + _COL)[None, :, None]]
+    return out
+
+
+def unpack_a4(w, mtiles, ksteps):
+    """Inverse of pack_a4's fragment step: -> [2*ksteps, mtiles*32] in kernel row order."""
+    w = np.asarray(w, np.float32).reshape(mtiles, ksteps // 4, 2, 32, 4)     # [mt, g, h, col, i]
+    return w.transpose(1, 4, 2, 0, 3).reshape(2 * ksteps, mtiles * 32)        # k = 2(4g+i)+h
 
 
 def pack_chain(w):

@@ -77,15 +77,23 @@ def run_gconv(d, mem):
     Cin = d.in0.C + d.in1.C
     mtiles = (d.Cout + 31) // 32
     dual = d.epi != L.EPI_LINEAR
-    W0 = _unpack_a(mem.arr(d.w0, mtiles * d.ksteps * 64), mtiles, d.ksteps)
-    W1 = _unpack_a(mem.arr(d.w1, mtiles * d.ksteps * 64), mtiles, d.ksteps) if dual else None
     taps = mem.arr(d.taps, 2 * d.ntaps, np.int32).reshape(-1, 2)
-    if d.korder == 1:   # rows are (channel pair, tap, parity): bring them back to tap-major
-        rows = P.korder1_rows(d.ntaps, Cin)
-        inv = np.empty_like(rows)
-        inv[rows] = np.arange(len(rows))
-        W0 = W0[inv]
-        W1 = W1[inv] if dual else None
+    if d.korder == 1:   # pipelined layout: 4-k-step groups in (source, pair chunk, tap) order
+        key = (d.epi, d.ntaps, d.in1.C > 0, d.xf_mode)
+        rows = P.korder1_rows(d.ntaps, d.in0.C, d.in1.C, P.V2_CP[key])
+        assert len(rows) == 2 * d.ksteps
+
+        def unpack(ptr):
+            wk = P.unpack_a4(mem.arr(ptr, mtiles * d.ksteps * 64), mtiles, d.ksteps)
+            out = np.zeros((d.ntaps * Cin, mtiles * 32), np.float32)
+            out[rows[rows >= 0]] = wk[rows >= 0]
+            assert np.all(wk[rows < 0] == 0)
+            return out
+    else:
+        def unpack(ptr):
+            return _unpack_a(mem.arr(ptr, mtiles * d.ksteps * 64), mtiles, d.ksteps)
+    W0 = unpack(d.w0)
+    W1 = unpack(d.w1) if dual else None
     bI = np.arange(B)[:, None, None, None]
     tI = np.arange(To)[None, None, :, None]
     jI = np.arange(Fo)[None, None, None, :]
