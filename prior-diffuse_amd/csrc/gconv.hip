@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void gconv_kernel(const pdse_gconv_desc d) {
     }
   }
 
-  gconv_epilogue<EPI, MT>(d, acc0, acc1, b, t, j, pvalid, lane, h, mt0, mtiles);
+  gconv_epilogue<EPI, MT>(d, tail_from_desc(d), acc0, acc1, b, t, j, pvalid, lane, h, mt0, mtiles);
 }
 
 #define PDSE_REQUIRE(cond, msg)    \

@@ -25,6 +25,10 @@
 
 #include "gconv_common.h"
 
+#ifndef PDSE_ABLATE
+#define PDSE_ABLATE 0   // diagnostic builds: 1 no activation loads, 2 no weight loads, 4 plain epilogue
+#endif
+
 template <int N, int CP, int MT>
 struct Chunk {
   float v[N];           // raw activation per k-step (lane = position, half = channel parity)
@@ -55,6 +59,32 @@ __global__ __launch_bounds__(256) void gconv2_kernel(const pdse_gconv_desc d) {
   const int j = pvalid ? p - t * d.Fout : 0;
   const int mtiles = (d.Cout + 31) >> 5;
   const int mt0 = blockIdx.z * MT;
+
+  // BIGLU: copy the tail's operands (chain fragments, biases, folded BN) to LDS, once per
+  // workgroup; the copy is in flight during the tap set-up and is fenced just before the tail
+  __shared__ float tail_lds[EPI == PDSE_EPI_BIGLU ? PDSE_TAIL_FLOATS : 1];
+  if constexpr (EPI == PDSE_EPI_BIGLU) {
+    const int tid = threadIdx.x;
+    const int w2n = d.C2 == 1 ? 32 : ((d.C2 + 31) >> 5) * 1024;
+    for (int i = tid; i < 1024; i += 256) {
+      tail_lds[i] = d.wlc[i];
+      tail_lds[1024 + i] = d.wrc[i];
+    }
+    for (int i = tid; i < w2n; i += 256) tail_lds[2048 + i] = d.wc2[i];
+    if (tid < 32) {
+      tail_lds[4096 + tid] = d.bias0[tid];
+      tail_lds[4128 + tid] = d.bias1[tid];
+      tail_lds[4160 + tid] = d.blc[tid];
+      tail_lds[4192 + tid] = d.brc[tid];
+    }
+    if (tid < d.C2) {
+      tail_lds[4224 + tid] = d.bc2[tid];
+      if (d.post_scale) {
+        tail_lds[4288 + tid] = d.post_scale[tid];
+        tail_lds[4352 + tid] = d.post_shift[tid];
+      }
+    }
+  }
 
   f32x16 acc0[MT], acc1[DUAL ? MT : 1];
 #pragma unroll
@@ -103,8 +133,13 @@ __global__ __launch_bounds__(256) void gconv2_kernel(const pdse_gconv_desc d) {
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
         const int mc = (mt0 + m < mtiles) ? m : 0;   // tiles past Cout re-read tile 0; never stored
+#if PDSE_ABLATE & 2
+        c.a0[g4][m] = make_float4(q * 1e-9f, 0.1f, 0.2f, 0.3f);   // diagnostic: no weight loads
+        if (DUAL) c.a1[g4][m] = make_float4(q * 2e-9f, 0.1f, 0.2f, 0.3f);
+#else
         c.a0[g4][m] = wq0[((size_t)mc * kgroups + (size_t)q * (N / 4) + g4) * 64];
         if (DUAL) c.a1[g4][m] = wq1[((size_t)mc * kgroups + (size_t)q * (N / 4) + g4) * 64];
+#endif
       }
     }
 #pragma unroll
@@ -116,7 +151,11 @@ __global__ __launch_bounds__(256) void gconv2_kernel(const pdse_gconv_desc d) {
 #pragma unroll
       for (int tap = 0; tap < NT; ++tap) {
         const int o = (SRC2 && s1) ? off1[tap] : off0[tap];
+#if PDSE_ABLATE & 1
+        c.v[cc * NT + tap] = __builtin_amdgcn_readfirstlane(o) * 1e-9f + 0.5f;   // diagnostic: no activation loads
+#else
         c.v[cc * NT + tap] = sp[o + cp * sc2];   // raw: masking happens at use, or the wait would sit here
+#endif
       }
       if constexpr (XF != 0) {
         const int ci = 2 * (gbase + cp) + h;
@@ -186,7 +225,19 @@ __global__ __launch_bounds__(256) void gconv2_kernel(const pdse_gconv_desc d) {
     }
   }
 
-  gconv_epilogue<EPI, MT>(d, acc0, acc1, b, t, j, pvalid, lane, h, mt0, mtiles);
+#if PDSE_ABLATE & 4
+  if (pvalid) d.out[(int64_t)b * d.out_sb + (int64_t)t * d.out_st + (int64_t)j * d.out_sf + d.out_off] = acc0[0][0] + (DUAL ? acc1[0][3] : 0.f);
+#else
+  if constexpr (EPI == PDSE_EPI_BIGLU) {
+    __syncthreads();   // the tail operands staged at launch are in LDS by now
+    float* const sw = tail_lds;
+    const pdse_tail tl{sw, sw + 1024, sw + 2048, sw + 4096, sw + 4128, sw + 4160, sw + 4192, sw + 4224,
+                       d.post_scale ? sw + 4288 : nullptr, sw + 4352};
+    gconv_epilogue<EPI, MT>(d, tl, acc0, acc1, b, t, j, pvalid, lane, h, mt0, mtiles);
+  } else {
+    gconv_epilogue<EPI, MT>(d, tail_from_desc(d), acc0, acc1, b, t, j, pvalid, lane, h, mt0, mtiles);
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------
@@ -257,7 +308,7 @@ int pdse_gconv2_launch(const pdse_gconv_desc* d, hipStream_t s) {
     if (nt == 2 && two && xf == 0) GO(PDSE_EPI_GLU, 2, 2, true, 0, true, true, true);
     if (nt == 3 && !two && xf == 0) GO(PDSE_EPI_GLU, 3, 4, false, 0, true, false, false);
     if (nt == 5 && !two && xf == 2) GO(PDSE_EPI_GLU, 5, 4, false, 2, true, false, false);
-  } else if (d->epi == PDSE_EPI_BIGLU && !two && xf == 0) {
+  } else if (d->epi == PDSE_EPI_BIGLU && !two && xf == 0 && d->C2 <= 64) {   // tail image in LDS holds C2 <= 64
     if (nt == 2) GO(PDSE_EPI_BIGLU, 2, 4, false, 0, true, true, true);
     if (nt == 4) GO(PDSE_EPI_BIGLU, 4, 2, false, 0, true, true, true);
     if (nt == 6) GO(PDSE_EPI_BIGLU, 6, 2, false, 0, true, true, true);

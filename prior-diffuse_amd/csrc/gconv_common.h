@@ -12,81 +12,128 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // row of accumulator register r on lane-half h (32x32 C/D layout, cdna_hip_programming.md §3)
 __device__ __forceinline__ int rho(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+// Epilogue transcendentals use the hardware exp2/rcp (v_exp_f32 / v_rcp_f32, ~1 ulp each):
+// the ablation of profiles/r01_ablation.txt showed the epilogue, not the MFMA loop, bounding
+// the block kernels — accurate expf + IEEE division cost ~35 VALU instructions per sigmoid.
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + fast_exp(-x)); }
 
 __device__ __forceinline__ float act_f(float y, int act, float slope) {
   switch (act) {
     case PDSE_ACT_PRELU: return y > 0.f ? y : slope * y;
-    case PDSE_ACT_ELU: return y > 0.f ? y : expm1f(y);
+    case PDSE_ACT_ELU: return y > 0.f ? y : fast_exp(y) - 1.0f;
     case PDSE_ACT_SIGMOID: return sigmoid_f(y);
     default: return y;
   }
 }
 
+// register r of a 32x32 accumulator holds row KR(r) + 4*h
+#define PDSE_KR(r) (((r) & 3) + 8 * ((r) >> 2))
 
-// acc0/acc1: MT accumulator tiles of this wave; (b, t, j) its output position on this lane.
-template <int EPI, int MT>
-__device__ __forceinline__ void gconv_epilogue(const pdse_gconv_desc& d, f32x16* acc0, f32x16* acc1, const int b,
-                                               const int t, const int j, const bool pvalid, const int lane,
-                                               const int h, const int mt0, const int mtiles) {
-  const int64_t obase = (int64_t)b * d.out_sb + (int64_t)t * d.out_st + (int64_t)j * d.out_sf + d.out_off;
+// Channel-indexed vectors (bias, folded BN) and the output are addressed as
+//   base(lane half, tile) + KR(r) * stride
+// with KR(r) a compile-time constant and the stride wave-uniform, so the per-element address
+// work is one scalar multiply + one vector add instead of an integer divide/modulo pair.
+// CR1: out_cr == 1 (every layer but the STFT, whose channel index splits into (re/im, bin)).
+// Small per-layer operands of the BIGLU tail.  The pipelined kernel copies them into LDS once
+// per workgroup at launch (they are the same for every wave): fetched from global memory inside
+// the tail, each of the ~70 fragment loads exposed its full latency in front of a dependent MFMA.
+struct pdse_tail {
+  const float* wlc;
+  const float* wrc;
+  const float* wc2;
+  const float* bl;
+  const float* br;
+  const float* blc;
+  const float* brc;
+  const float* bc2;
+  const float* ps;  // nullptr: no folded BatchNorm
+  const float* pt;
+};
+// LDS image: [wlc 1024][wrc 1024][wc2 2048][bl 32][br 32][blc 32][brc 32][bc2 64][ps 64][pt 64]
+#define PDSE_TAIL_FLOATS (1024 + 1024 + 2048 + 4 * 32 + 3 * 64)
+
+__device__ __forceinline__ pdse_tail tail_from_desc(const pdse_gconv_desc& d) {
+  return pdse_tail{d.wlc, d.wrc, d.wc2, d.bias0, d.bias1, d.blc, d.brc, d.bc2, d.post_scale, d.post_shift};
+}
+
+template <int EPI, int MT, bool CR1>
+__device__ __forceinline__ void gconv_epilogue_impl(const pdse_gconv_desc& d, const pdse_tail& tl, f32x16* acc0,
+                                                    f32x16* acc1, const int b, const int t, const int j,
+                                                    const bool pvalid, const int lane, const int h, const int mt0,
+                                                    const int mtiles) {
+  float* const obase = d.out + ((int64_t)b * d.out_sb + (int64_t)t * d.out_st + (int64_t)j * d.out_sf + d.out_off);
+  const int64_t cstep = d.out_sc_hi;
+  auto chan_off = [&](const int co) -> int64_t {
+    if constexpr (CR1) return (int64_t)co * cstep;
+    else return (int64_t)(co / d.out_cr) * d.out_sc_hi + (int64_t)(co % d.out_cr) * d.out_sc_lo;
+  };
 
   if constexpr (EPI == PDSE_EPI_LINEAR || EPI == PDSE_EPI_GLU) {
+    const float* rbase = d.resid ? d.resid + (obase - d.out) : nullptr;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
       if (mt0 + m >= mtiles) continue;
+      const int c0 = 32 * (mt0 + m) + 4 * h;
+      const float* pb0 = d.bias0 ? d.bias0 + (int64_t)b * d.bias0_sb + c0 : nullptr;
+      const float* pb1 = (EPI == PDSE_EPI_GLU && d.bias1) ? d.bias1 + (int64_t)b * d.bias1_sb + c0 : nullptr;
+      const float* ps = d.post_scale ? d.post_scale + c0 : nullptr;
+      const float* pt = d.post_scale ? d.post_shift + c0 : nullptr;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int co = 32 * (mt0 + m) + rho(r, h);
+        const int co = c0 + PDSE_KR(r);
         if (pvalid && co < d.Cout) {
           float y = acc0[m][r];
-          if (d.bias0) y += d.bias0[(int64_t)b * d.bias0_sb + co];
+          if (pb0) y += pb0[PDSE_KR(r)];
           if constexpr (EPI == PDSE_EPI_GLU) {
             float g = acc1[m][r];
-            if (d.bias1) g += d.bias1[(int64_t)b * d.bias1_sb + co];
+            if (pb1) g += pb1[PDSE_KR(r)];
             y = y * sigmoid_f(g);
           }
-          if (d.post_scale) y = y * d.post_scale[co] + d.post_shift[co];
+          if (ps) y = y * ps[PDSE_KR(r)] + pt[PDSE_KR(r)];
           y = act_f(y, d.act, d.act_slope);
-          const int64_t idx = obase + (int64_t)(co / d.out_cr) * d.out_sc_hi + (int64_t)(co % d.out_cr) * d.out_sc_lo;
-          if (d.resid) y += d.resid[idx];
-          d.out[idx] = y;
+          const int64_t o = CR1 ? (int64_t)c0 * cstep + (int64_t)PDSE_KR(r) * cstep : chan_off(co);
+          if (rbase) y += rbase[o];
+          obase[o] = y;
         }
       }
     }
   } else {
     // BiConvGLU / BiConvTransGLU tail, register to register (model/diff3.py:316-326, :345-351)
     f32x16 L = acc0[0], R = acc1[0];
+    const float* pbl = tl.bl + 4 * h;
+    const float* pbr = tl.br + 4 * h;
+    const float* pblc = tl.blc + 4 * h;
+    const float* pbrc = tl.brc + 4 * h;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int c = rho(r, h);
-      L[r] += d.bias0[c];
-      R[r] += d.bias1[c];
+      L[r] += pbl[PDSE_KR(r)];
+      R[r] += pbr[PDSE_KR(r)];
     }
     f32x16 mL, mR;
 #pragma unroll
     for (int r = 0; r < 16; ++r) mL[r] = mR[r] = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      mL = __builtin_amdgcn_mfma_f32_32x32x2f32(d.wlc[r * 64 + lane], L[r], mL, 0, 0, 0);
-      mR = __builtin_amdgcn_mfma_f32_32x32x2f32(d.wrc[r * 64 + lane], R[r], mR, 0, 0, 0);
+      mL = __builtin_amdgcn_mfma_f32_32x32x2f32(tl.wlc[r * 64 + lane], L[r], mL, 0, 0, 0);
+      mR = __builtin_amdgcn_mfma_f32_32x32x2f32(tl.wrc[r * 64 + lane], R[r], mR, 0, 0, 0);
     }
     f32x16 G;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int c = rho(r, h);
-      const float ml = sigmoid_f(mL[r] + d.blc[c]);
-      const float mr = sigmoid_f(mR[r] + d.brc[c]);
+      const float ml = sigmoid_f(mL[r] + pblc[PDSE_KR(r)]);
+      const float mr = sigmoid_f(mR[r] + pbrc[PDSE_KR(r)]);
       G[r] = L[r] * mr + R[r] * ml;
     }
     if (d.C2 == 1) {
+      const float* pw = tl.wc2 + 4 * h;
       float part = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) part += d.wc2[rho(r, h)] * G[r];
-      float y = part + __shfl_xor(part, 32) + d.bc2[0];
-      if (d.post_scale) y = y * d.post_scale[0] + d.post_shift[0];
+      for (int r = 0; r < 16; ++r) part += pw[PDSE_KR(r)] * G[r];
+      float y = part + __shfl_xor(part, 32) + tl.bc2[0];
+      if (tl.ps) y = y * tl.ps[0] + tl.pt[0];
       y = act_f(y, d.act, d.act_slope);
-      if (pvalid && h == 0) d.out[obase] = y;
+      if (pvalid && h == 0) obase[0] = y;
     } else {
       const int tiles2 = (d.C2 + 31) >> 5;
       for (int m2 = 0; m2 < tiles2; ++m2) {
@@ -95,19 +142,36 @@ __device__ __forceinline__ void gconv_epilogue(const pdse_gconv_desc& d, f32x16*
         for (int r = 0; r < 16; ++r) O[r] = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          O = __builtin_amdgcn_mfma_f32_32x32x2f32(d.wc2[(m2 * 16 + r) * 64 + lane], G[r], O, 0, 0, 0);
+          O = __builtin_amdgcn_mfma_f32_32x32x2f32(tl.wc2[(m2 * 16 + r) * 64 + lane], G[r], O, 0, 0, 0);
+        const int c0 = 32 * m2 + 4 * h;
+        const float* pb = tl.bc2 + c0;
+        const float* ps = tl.ps ? tl.ps + c0 : nullptr;
+        const float* pt = tl.ps ? tl.pt + c0 : nullptr;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int co = 32 * m2 + rho(r, h);
+          const int co = c0 + PDSE_KR(r);
           if (pvalid && co < d.C2) {
-            float y = O[r] + d.bc2[co];
-            if (d.post_scale) y = y * d.post_scale[co] + d.post_shift[co];
+            float y = O[r] + pb[PDSE_KR(r)];
+            if (ps) y = y * ps[PDSE_KR(r)] + pt[PDSE_KR(r)];
             y = act_f(y, d.act, d.act_slope);
-            d.out[obase + (int64_t)(co / d.out_cr) * d.out_sc_hi + (int64_t)(co % d.out_cr) * d.out_sc_lo] = y;
+            const int64_t o = CR1 ? (int64_t)c0 * cstep + (int64_t)PDSE_KR(r) * cstep : chan_off(co);
+            obase[o] = y;
           }
         }
       }
     }
   }
+}
+
+// acc0/acc1: MT accumulator tiles of this wave; (b, t, j) its output position on this lane.
+template <int EPI, int MT>
+__device__ __forceinline__ void gconv_epilogue(const pdse_gconv_desc& d, const pdse_tail& tl, f32x16* acc0,
+                                               f32x16* acc1, const int b, const int t, const int j,
+                                               const bool pvalid, const int lane, const int h, const int mt0,
+                                               const int mtiles) {
+  if (d.out_cr == 1)
+    gconv_epilogue_impl<EPI, MT, true>(d, tl, acc0, acc1, b, t, j, pvalid, lane, h, mt0, mtiles);
+  else
+    gconv_epilogue_impl<EPI, MT, false>(d, tl, acc0, acc1, b, t, j, pvalid, lane, h, mt0, mtiles);
 }
 #endif

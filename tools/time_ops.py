@@ -1,0 +1,37 @@
+"""Diagnostic: per-operator hipEvent timings of one eps-net forward at the bench shape
+(B=32, T=401).  PDSE_LIB=<path to a diagnostic libpdse build> selects an ablation build
+(csrc/gconv2.hip, PDSE_ABLATE).  Not part of the product or the tests."""
+import importlib
+import os
+import statistics
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+nets = importlib.import_module("prior-diffuse_amd.nets")
+synth = importlib.import_module("prior-diffuse_amd.synth")
+L = importlib.import_module("prior-diffuse_amd._lib")
+
+B, T = int(os.environ.get("B", 32)), int(os.environ.get("T", 401))
+net = nets.EpsNetPlan(nets.Ctx("cuda:0"), synth.make_state_dict("DiffUNet1"), B, T, time_cond=True, nsteps=1)
+net.build_time()
+net.build_step(0)
+net.finish()
+g = torch.Generator().manual_seed(0)
+net.x.copy_(torch.randn(B, 2, T, 161, generator=g))
+net.x_init.copy_(torch.randn(B, 2, T, 161, generator=g) * 0.3)
+net.tsteps.fill_(10.45)
+n = len(net.descs)
+runs = [net.plan.time_ops(0, n) for _ in range(6)][1:]
+med = [statistics.median(r[i] for r in runs) * 1e3 for i in range(n)]
+names = {nets.TAG_EPS_BLOCK: "block", nets.TAG_EPS_CONV1: "conv1", nets.TAG_TCM: "tcm", nets.TAG_EW: "ew"}
+tot = {}
+for i, (d, tag) in enumerate(net.descs):
+    tot[names.get(tag, "?")] = tot.get(names.get(tag, "?"), 0) + med[i]
+sel = [i for i, (d, tag) in enumerate(net.descs) if tag == nets.TAG_EPS_BLOCK][:5] + \
+      [i for i, (d, tag) in enumerate(net.descs) if tag == nets.TAG_EPS_BLOCK][-2:] + \
+      [i for i, (d, tag) in enumerate(net.descs) if tag == nets.TAG_TCM][:3] + \
+      [i for i, (d, tag) in enumerate(net.descs) if tag == nets.TAG_EPS_CONV1][:3]
+print(os.environ.get("PDSE_LIB", "default"), " total %.0f us" % sum(med), {k: round(v) for k, v in tot.items()})
+print("   ", " ".join("%s%d:nt%d=%.0f" % (names.get(net.descs[i][1], "?")[0], i, net.descs[i][0].ntaps, med[i]) for i in sel))
