@@ -296,3 +296,17 @@ def test_pipelined_kernel_agrees_with_generic_kernel(L, weights, monkeypatch):
     _sync()
     assert rel_l2(fast.cpu(), slow.cpu()) < 1e-5
     assert rel_l2(g_fast.cpu(), g_slow.cpu()) < 1e-5
+
+
+def test_concurrent_sub_batches_bit_identical(L, weights):
+    """nsplit concurrent sub-batch pipelines (separate streams, graph replay) == one pipeline."""
+    P = pkg("pipeline")
+    B, L_ = 5, 3200                                  # ragged split: 3 + 2
+    wav, x_T = pkg("synth").synthetic_waveforms(B, L_, seed=11)
+    one = P.SamplerPipeline(DEV, "GCRN", weights("GCRN"), weights("DiffUNet1"), B, L_=L_)
+    w1, s1 = one.enhance(wav.to(DEV), x_T.to(DEV))
+    two = P.ConcurrentSampler(DEV, "GCRN", weights("GCRN"), weights("DiffUNet1"), B, L_=L_, nsplit=2)
+    for graph in (False, True, True):
+        w2, s2 = two.enhance(wav.to(DEV), x_T.to(DEV), graph=graph)
+        _sync()
+        assert torch.equal(w1, w2) and torch.equal(s1, s2)
