@@ -50,6 +50,9 @@ def load_reference():
         os.environ.pop("CUDA_VISIBLE_DEVICES", None)
     else:
         os.environ["CUDA_VISIBLE_DEVICES"] = saved_env
+    # model/dbaiat.py imports ptflops at the top for its __main__ block only (dbaiat.py:5,643)
+    sys.modules.setdefault("ptflops", types.SimpleNamespace(get_model_complexity_info=None))
+    ref.dbaiat = _load("ref_dbaiat", REF + "/model/dbaiat.py")
     return ref
 
 
@@ -177,6 +180,26 @@ def main():
         # ---- A3' DiffUNet prior small
         outd = dprior(xg)
         np.savez(os.path.join(OUT, "diffunet_prior_small.npz"), seed_x=31, out=outd.numpy())
+
+        # ---- A3'' DB-AIAT prior (conf/dbaiat.yml: aia_complex_trans_ri), with intermediates
+        aia = ref.dbaiat.aia_complex_trans_ri()
+        aia.load_state_dict(synth.make_state_dict("aia_complex_trans_ri", 1234), strict=True)
+        aia.eval()
+        xa = seeded((2, 2, 12, 161), 51)
+        caps = {}
+        hk = [aia.en_ri.register_forward_hook(lambda m, i, o: caps.__setitem__("en_ri", o)),
+              aia.dual_trans.register_forward_hook(lambda m, i, o: caps.__setitem__("trans", o)),
+              aia.aham.register_forward_hook(lambda m, i, o: caps.__setitem__("aham", o)),
+              aia.dual_trans.row_norm[0].register_forward_hook(lambda m, i, o: caps.__setitem__("row0", o)),
+              aia.dual_trans.col_norm[0].register_forward_hook(lambda m, i, o: caps.__setitem__("col0", o))]
+        outa = aia(xa)
+        for h in hk:
+            h.remove()
+        print("aia out rms %.3f en_ri %.3f trans_last %.3f aham %.3f" % (outa.pow(2).mean().sqrt(),
+              caps["en_ri"].pow(2).mean().sqrt(), caps["trans"][0].pow(2).mean().sqrt(), caps["aham"].pow(2).mean().sqrt()))
+        np.savez(os.path.join(OUT, "aia_small.npz"), seed_x=51, en_ri_c8=caps["en_ri"][:, ::8].numpy(),
+                 row0=caps["row0"].numpy(), col0=caps["col0"].numpy(), trans_last_c8=caps["trans"][0][:, ::8].numpy(),
+                 aham_c8=caps["aham"][:, ::8].numpy(), out=outa.numpy())
 
         # ---- A4/A5 reverse-loop traces with injected x_T: the reference's own loop
         # body (trainer/complex_ddpm_trainer.py:964-998) driven on the real modules

@@ -401,3 +401,143 @@ def enhance(prior_name, prior_sd, ddpm_sd, wav, x_T, noise_schedule, inference_n
                      inference_noise_schedule, fast_sampling, use_sigma)
     out = istft_ri(decompress_square(spec), wav.shape[-1])
     return out * c[:, None], spec
+
+
+# --------------------------------------------------------------------------
+# A3''  prior aia_complex_trans_ri  (reference: model/dbaiat.py)
+# --------------------------------------------------------------------------
+def _ln_last(sd, p, x):
+    return F.layer_norm(x, (x.shape[-1],), sd[p + ".weight"], sd[p + ".bias"], 1e-5)
+
+
+def dense_block(sd, p, x):
+    """reference: model/dbaiat.py:605-631 — 4 dilated (2,3) convs, LayerNorm over F, per-channel
+    PReLU, dense concatenation [newest, ..., input]; causal zero padding of dil frames on top,
+    one bin left/right."""
+    skip = x
+    out = x
+    for i in range(4):
+        dil = 2 ** i
+        out = F.pad(skip, (1, 1, dil, 0))
+        out = F.conv2d(out, sd["%s.conv%d.weight" % (p, i + 1)], sd["%s.conv%d.bias" % (p, i + 1)], dilation=(dil, 1))
+        out = _ln_last(sd, "%s.norm%d" % (p, i + 1), out)
+        out = F.prelu(out, sd["%s.prelu%d.weight" % (p, i + 1)])
+        skip = torch.cat([out, skip], dim=1)
+    return out
+
+
+def dense_encoder(sd, x):
+    """reference: model/dbaiat.py:481-501."""
+    out = F.conv2d(x, sd["en_ri.inp_conv.weight"], sd["en_ri.inp_conv.bias"])
+    out = F.prelu(_ln_last(sd, "en_ri.inp_norm", out), sd["en_ri.inp_prelu.weight"])
+    out = dense_block(sd, "en_ri.enc_dense1", out)
+    out = F.conv2d(out, sd["en_ri.enc_conv1.weight"], sd["en_ri.enc_conv1.bias"], stride=(1, 2))
+    return F.prelu(_ln_last(sd, "en_ri.enc_norm1", out), sd["en_ri.enc_prelu1.weight"])
+
+
+def gru_layer(x, w_ih, w_hh, b_ih, b_hh, reverse=False):
+    """Single-direction nn.GRU layer, seq-first [S,N,I], zero initial state, gate order r,z,n:
+    n = tanh(W_in x + b_in + r * (W_hn h + b_hn)); h' = (1-z) n + z h."""
+    S, N, _ = x.shape
+    H = w_hh.shape[1]
+    h = x.new_zeros(N, H)
+    gx = F.linear(x, w_ih, b_ih)
+    outs = [None] * S
+    order = range(S - 1, -1, -1) if reverse else range(S)
+    for s in order:
+        gh = F.linear(h, w_hh, b_hh)
+        xr, xz, xn = gx[s].chunk(3, dim=1)
+        hr, hz, hn = gh.chunk(3, dim=1)
+        r = torch.sigmoid(xr + hr)
+        z = torch.sigmoid(xz + hz)
+        n = torch.tanh(xn + r * hn)
+        h = (1 - z) * n + z * h
+        outs[s] = h
+    return torch.stack(outs, dim=0)
+
+
+def mha(sd, p, x, heads=4):
+    """nn.MultiheadAttention self-attention, seq-first [S,N,E], no mask, no dropout."""
+    S, N, E = x.shape
+    qkv = F.linear(x, sd[p + ".in_proj_weight"], sd[p + ".in_proj_bias"])
+    q, k, v = qkv.chunk(3, dim=-1)
+    hd = E // heads
+
+    def split(t):
+        return t.reshape(S, N * heads, hd).transpose(0, 1)          # [N*heads, S, hd]
+
+    q, k, v = split(q) * (hd ** -0.5), split(k), split(v)
+    att = torch.softmax(torch.bmm(q, k.transpose(1, 2)), dim=-1)
+    out = torch.bmm(att, v).transpose(0, 1).reshape(S, N, E)
+    return F.linear(out, sd[p + ".out_proj.weight"], sd[p + ".out_proj.bias"])
+
+
+def aia_encoder_layer(sd, p, src):
+    """reference: model/dbaiat.py:66-88 (TransformerEncoderLayer.forward)."""
+    src_norm = _ln_last(sd, p + ".norm3", src)
+    src = src + mha(sd, p + ".self_attn", src_norm)
+    src = _ln_last(sd, p + ".norm1", src)
+    g = p + ".gru."
+    fw = gru_layer(src, sd[g + "weight_ih_l0"], sd[g + "weight_hh_l0"], sd[g + "bias_ih_l0"], sd[g + "bias_hh_l0"])
+    bw = gru_layer(src, sd[g + "weight_ih_l0_reverse"], sd[g + "weight_hh_l0_reverse"],
+                   sd[g + "bias_ih_l0_reverse"], sd[g + "bias_hh_l0_reverse"], reverse=True)
+    out = torch.cat([fw, bw], dim=-1)
+    src2 = F.linear(F.relu(out), sd[p + ".linear2.weight"], sd[p + ".linear2.bias"])
+    return _ln_last(sd, p + ".norm2", src + src2)
+
+
+def aia_transformer(sd, x, taps=None):
+    """reference: model/dbaiat.py:133-154 — 4 x (row over F, col over T), shared output head."""
+    p = "dual_trans"
+    b, c, dim2, dim1 = x.shape
+    output = F.prelu(F.conv2d(x, sd[p + ".input.0.weight"], sd[p + ".input.0.bias"]), sd[p + ".input.1.weight"])
+    outs = []
+    for i in range(4):
+        row_in = output.permute(3, 0, 2, 1).contiguous().view(dim1, b * dim2, -1)
+        row = aia_encoder_layer(sd, "%s.row_trans.%d" % (p, i), row_in)
+        row = row.view(dim1, b, dim2, -1).permute(1, 3, 2, 0).contiguous()
+        row = F.group_norm(row, 1, sd["%s.row_norm.%d.weight" % (p, i)], sd["%s.row_norm.%d.bias" % (p, i)], 1e-8)
+        col_in = output.permute(2, 0, 3, 1).contiguous().view(dim2, b * dim1, -1)
+        col = aia_encoder_layer(sd, "%s.col_trans.%d" % (p, i), col_in)
+        col = col.view(dim2, b, dim1, -1).permute(1, 3, 0, 2).contiguous()
+        col = F.group_norm(col, 1, sd["%s.col_norm.%d.weight" % (p, i)], sd["%s.col_norm.%d.bias" % (p, i)], 1e-8)
+        if taps is not None and i == 0:
+            taps["row0"], taps["col0"] = row, col
+        output = output + sd[p + ".k1"] * row + sd[p + ".k2"] * col
+        outs.append(F.conv2d(F.prelu(output, sd[p + ".output.0.weight"]), sd[p + ".output.1.weight"],
+                             sd[p + ".output.1.bias"]))
+    return outs
+
+
+def aham(sd, outs):
+    """reference: model/dbaiat.py:266-288 — softmax over the 4 layer outputs of conv1(avgpool(x_i))."""
+    ys = [F.conv2d(o.mean(dim=(2, 3), keepdim=True), sd["aham.conv1.weight"], sd["aham.conv1.bias"]) for o in outs]
+    w = torch.softmax(torch.cat(ys, dim=1), dim=1)                  # [B,4,1,1]
+    merged = sum(w[:, i:i + 1] * outs[i] for i in range(4))
+    return outs[-1] + merged
+
+
+def dense_decoder(sd, p, x):
+    """reference: model/dbaiat.py:527-548 + SPConvTranspose2d :587-602 (sub-pixel, r = 2)."""
+    out = dense_block(sd, p + ".dec_dense1", x)
+    out = F.conv2d(F.pad(out, (1, 1, 0, 0)), sd[p + ".dec_conv1.conv.weight"], sd[p + ".dec_conv1.conv.bias"])
+    bsz, nch, H, W = out.shape
+    out = out.view(bsz, 2, nch // 2, H, W).permute(0, 2, 3, 4, 1).contiguous().view(bsz, nch // 2, H, -1)
+    out = F.pad(out, (1, 0, 0, 0))
+    out = F.prelu(_ln_last(sd, p + ".dec_norm1", out), sd[p + ".dec_prelu1.weight"])
+    return F.conv2d(out, sd[p + ".out_conv.weight"], sd[p + ".out_conv.bias"])
+
+
+def aia_complex_trans_ri_forward(sd, x, taps=None):
+    """reference: model/dbaiat.py:461-478."""
+    x_ri = dense_encoder(sd, x)
+    outs = aia_transformer(sd, x_ri, taps)
+    merged = aham(sd, outs)
+    if taps is not None:
+        taps["en_ri"], taps["trans_last"], taps["aham"] = x_ri, outs[-1], merged
+    real = dense_decoder(sd, "de1", merged)
+    imag = dense_decoder(sd, "de2", merged)
+    return torch.cat((real, imag), dim=1)
+
+
+PRIORS["aia_complex_trans_ri"] = aia_complex_trans_ri_forward

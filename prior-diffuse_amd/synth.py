@@ -176,7 +176,72 @@ def gcrn_spec():
     return spec
 
 
+def _dense_block(prefix, width_f):
+    # reference: model/dbaiat.py:605-631 (depth 4, dilations 1,2,4,8 along time)
+    out = []
+    for i in range(1, 5):
+        out += _conv("%s.conv%d" % (prefix, i), (64, 64 * i, 2, 3), 64 * i * 6, 1.5)
+        out += [("%s.norm%d.weight" % (prefix, i), (width_f,), "bn_w"), ("%s.norm%d.bias" % (prefix, i), (width_f,), "bn_b")]
+        out += [("%s.prelu%d.weight" % (prefix, i), (64,), "prelu")]
+    return out
+
+
+def _aia_layer(prefix):
+    # reference: model/dbaiat.py:41-88 (TransformerEncoderLayer, d_model 32, 4 heads, biGRU 32->64)
+    out = [
+        (prefix + ".self_attn.in_proj_weight", (96, 32), "w", 32, 1.5),
+        (prefix + ".self_attn.in_proj_bias", (96,), "bias"),
+    ]
+    out += _conv(prefix + ".self_attn.out_proj", (32, 32), 32, 1.0)
+    for suf in ("", "_reverse"):
+        out += [
+            (prefix + ".gru.weight_ih_l0" + suf, (192, 32), "w", 32, 1.5),
+            (prefix + ".gru.weight_hh_l0" + suf, (192, 64), "w", 64, 1.5),
+            (prefix + ".gru.bias_ih_l0" + suf, (192,), "bias"),
+            (prefix + ".gru.bias_hh_l0" + suf, (192,), "bias"),
+        ]
+    out += _conv(prefix + ".linear2", (32, 128), 128, 1.5)
+    for n in (1, 2, 3):
+        out += [(prefix + ".norm%d.weight" % n, (32,), "bn_w"), (prefix + ".norm%d.bias" % n, (32,), "bn_b")]
+    return out
+
+
+def aia_complex_trans_ri_spec():
+    """Ordered spec of the DB-AIAT prior selected by conf/dbaiat.yml:13
+    (reference: model/dbaiat.py:450-478 and the blocks it names)."""
+    spec = []
+    spec += _conv("en_ri.inp_conv", (64, 2, 1, 1), 2, 1.0)
+    spec += [("en_ri.inp_norm.weight", (161,), "bn_w"), ("en_ri.inp_norm.bias", (161,), "bn_b"),
+             ("en_ri.inp_prelu.weight", (64,), "prelu")]
+    spec += _dense_block("en_ri.enc_dense1", 161)
+    spec += _conv("en_ri.enc_conv1", (64, 64, 1, 3), 64 * 3, 1.5)
+    spec += [("en_ri.enc_norm1.weight", (80,), "bn_w"), ("en_ri.enc_norm1.bias", (80,), "bn_b"),
+             ("en_ri.enc_prelu1.weight", (64,), "prelu")]
+    spec += [("dual_trans.k1", (1,), "gain1"), ("dual_trans.k2", (1,), "gain1")]
+    spec += _conv("dual_trans.input.0", (32, 64, 1, 1), 64, 1.4)
+    spec += [("dual_trans.input.1.weight", (1,), "prelu")]
+    for kind in ("row_trans", "col_trans"):
+        for i in range(4):
+            spec += _aia_layer("dual_trans.%s.%d" % (kind, i))
+    for kind in ("row_norm", "col_norm"):
+        for i in range(4):
+            spec += [("dual_trans.%s.%d.weight" % (kind, i), (32,), "bn_w"),
+                     ("dual_trans.%s.%d.bias" % (kind, i), (32,), "bn_b")]
+    spec += [("dual_trans.output.0.weight", (1,), "prelu")]
+    spec += _conv("dual_trans.output.1", (64, 32, 1, 1), 32, 1.4)
+    spec += [("aham.k3", (1,), "gain1")]
+    spec += _conv("aham.conv1", (1, 64, 1, 1), 64, 4.0)
+    for de in ("de1", "de2"):
+        spec += _dense_block(de + ".dec_dense1", 80)
+        spec += _conv(de + ".dec_conv1.conv", (128, 64, 1, 3), 64 * 3, 1.5)
+        spec += [(de + ".dec_norm1.weight", (161,), "bn_w"), (de + ".dec_norm1.bias", (161,), "bn_b"),
+                 (de + ".dec_prelu1.weight", (64,), "prelu")]
+        spec += _conv(de + ".out_conv", (1, 64, 1, 1), 64, 1.0)
+    return spec
+
+
 ARCH_SPECS = {
+    "aia_complex_trans_ri": aia_complex_trans_ri_spec,
     "DiffUNet1": diffunet1_spec,
     "DiffUNet": diffunet_spec,
     "GCRN": gcrn_spec,
@@ -211,6 +276,8 @@ def make_state_dict(arch, seed=1234, as_torch=True):
             v = rng.uniform(0.5, 1.5, shape)
         elif kind == "prelu":
             v = rng.uniform(0.1, 0.4, shape)
+        elif kind == "gain1":
+            v = rng.uniform(0.6, 1.0, shape)
         elif kind == "bn_nbt":
             sd[key] = np.array(100, dtype=np.int64)
             continue

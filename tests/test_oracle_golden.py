@@ -173,3 +173,19 @@ def test_stft_convention_against_float64_dft():
     feat = R.compress_sqrt(torch.from_numpy(ri))
     back = R.istft_ri(R.decompress_square(feat), 1600)
     assert rel_l2(back, wav) < 1e-5
+
+
+def test_aia_prior_with_intermediates(weights):
+    """DB-AIAT prior (model/dbaiat.py aia_complex_trans_ri): dense blocks, LayerNorm over bins,
+    multi-head attention + biGRU over bins and over frames, GroupNorm, AHAM merge, sub-pixel decoder."""
+    g = golden("aia_small")
+    sd = weights("aia_complex_trans_ri")
+    taps = {}
+    with torch.no_grad():
+        out = R.aia_complex_trans_ri_forward(sd, seeded((2, 2, 12, 161), g["seed_x"]), taps=taps)
+    assert rel_l2(taps["en_ri"][:, ::8], g["en_ri_c8"]) < TOL
+    assert rel_l2(taps["row0"], g["row0"]) < 5e-6
+    assert rel_l2(taps["col0"], g["col0"]) < 5e-6
+    assert rel_l2(taps["trans_last"][:, ::8], g["trans_last_c8"]) < 1e-5
+    assert rel_l2(taps["aham"][:, ::8], g["aham_c8"]) < 1e-5
+    assert rel_l2(out, g["out"]) < 1e-5
