@@ -212,6 +212,86 @@ typedef struct pdse_lstm_desc {
   int32_t B, Bp, T, H, G, pad_;
 } pdse_lstm_desc;
 
+/* ---- DB-AIAT prior (model/dbaiat.py), channel-major [B,C,T,F] tensors ------------------- */
+
+/* LayerNorm over the bins of every (b,c,t) row + per-channel PReLU
+ * (dbaiat.py:498, :627-628, :545): out = prelu_c(ln_F(in)).  out rows may sit inside a larger
+ * channel-concatenated buffer (out_sb); in is dense [B,C,T,F]. */
+typedef struct pdse_rowln_desc {
+  const float* in;
+  const float* gamma; /* [F] */
+  const float* beta;
+  const float* slope; /* [C] */
+  float* out;
+  int64_t out_sb; /* batch stride of out (channel stride is T*F on both sides) */
+  int32_t B, C, T, F;
+  float eps;
+  int32_t pad_;
+} pdse_rowln_desc;
+
+/* LayerNorm over the C channels at every (b,t,f) (nn.LayerNorm(d_model) on [S,N,32], dbaiat.py:76,81,87) */
+typedef struct pdse_chln_desc {
+  const float* in;
+  const float* gamma; /* [C] */
+  const float* beta;
+  float* out;
+  int64_t plane; /* T*F */
+  int32_t B, C;
+  float eps;
+  int32_t pad_;
+} pdse_chln_desc;
+
+/* Multi-head self-attention core (nn.MultiheadAttention, dbaiat.py:77-79) on projected
+ * qkv [B,3*E,T,F] (q already scaled by head_dim^-0.5): softmax(q k^T) v per (b, line, head).
+ * axis 0: sequence runs over the bins F (one line per frame); axis 1: over the frames T. */
+typedef struct pdse_attn_desc {
+  const float* qkv;
+  float* out; /* [B,E,T,F] */
+  int32_t B, T, F, E, heads, axis, pad0_, pad1_;
+} pdse_attn_desc;
+
+/* Bidirectional single-layer GRU (dbaiat.py:45,83) along one axis, hidden 64, persistent per
+ * line: gx [B,2*3*H,T,F] = W_ih x + b_ih of both directions ([fw r,z,n | bw r,z,n]);
+ * whh [2][3H/32][H/2][64] MFMA A fragments, bhh [2][3H]; y [B,2H,T,F] = [fw | bw]. */
+typedef struct pdse_gru_desc {
+  const float* gx;
+  const float* whh;
+  const float* bhh;
+  float* y;
+  int32_t B, T, F, H, axis, pad_;
+} pdse_gru_desc;
+
+/* GroupNorm(1,C) statistics + the AIA layer update (dbaiat.py:142,147-148):
+ *   out = base + k1 * gn(row) + k2 * gn(col);  stats scratch [B][4] (sum,sumsq of row | col). */
+typedef struct pdse_gncomb_desc {
+  const float* base;
+  const float* row;
+  const float* col;
+  const float* g_row; /* [C] */
+  const float* b_row;
+  const float* g_col;
+  const float* b_col;
+  float* stats; /* [B][4] scratch */
+  float* out;
+  int64_t plane; /* T*F */
+  int32_t B, C;
+  float k1, k2, eps;
+  int32_t pad_;
+} pdse_gncomb_desc;
+
+/* AHAM merge of the 4 layer outputs (dbaiat.py:266-288): w = softmax_i(conv1(avgpool(x_i)));
+ * out = x_3 + sum_i w_i x_i.  means scratch [4][B][C]. */
+typedef struct pdse_aham_desc {
+  const float* x[4];
+  const float* w; /* conv1 weight [C] */
+  float* means;
+  float* out;
+  int64_t plane;
+  int32_t B, C;
+  float bias;
+  int32_t pad_;
+} pdse_aham_desc;
+
 enum pdse_op_kind {
   PDSE_OP_GCONV = 0,
   PDSE_OP_TIME = 1,
@@ -221,7 +301,13 @@ enum pdse_op_kind {
   PDSE_OP_OLA = 5,
   PDSE_OP_SIGMA = 6,
   PDSE_OP_LN = 7,
-  PDSE_OP_LSTM = 8
+  PDSE_OP_LSTM = 8,
+  PDSE_OP_ROWLN = 9,
+  PDSE_OP_CHLN = 10,
+  PDSE_OP_ATTN = 11,
+  PDSE_OP_GRU = 12,
+  PDSE_OP_GNCOMB = 13,
+  PDSE_OP_AHAM = 14
 };
 
 int pdse_abi_version(void);
@@ -239,6 +325,12 @@ int pdse_ola_f32(const pdse_ola_desc* d, pdse_stream_t s);
 int pdse_sigma_mask_f32(const pdse_sigma_desc* d, pdse_stream_t s);
 int pdse_layernorm_f32(const pdse_ln_desc* d, pdse_stream_t s);
 int pdse_lstm_f32(const pdse_lstm_desc* d, pdse_stream_t s);
+int pdse_rowln_prelu_f32(const pdse_rowln_desc* d, pdse_stream_t s);
+int pdse_chln_f32(const pdse_chln_desc* d, pdse_stream_t s);
+int pdse_attention_f32(const pdse_attn_desc* d, pdse_stream_t s);
+int pdse_bigru_f32(const pdse_gru_desc* d, pdse_stream_t s);
+int pdse_gn_combine_f32(const pdse_gncomb_desc* d, pdse_stream_t s);
+int pdse_aham_f32(const pdse_aham_desc* d, pdse_stream_t s);
 
 /* plans: a recorded operator sequence replayed by one call (and capturable in a hipGraph) */
 typedef struct pdse_plan pdse_plan;

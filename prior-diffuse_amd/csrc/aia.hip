@@ -1,0 +1,386 @@
+// aia.hip — the non-convolutional operators of the DB-AIAT prior (model/dbaiat.py):
+// LayerNorm over bins + per-channel PReLU, LayerNorm over channels, the attention core,
+// a persistent per-line bidirectional GRU, GroupNorm + layer update, AHAM merge.
+// All tensors are channel-major [B,C,T,F] fp32; the convolutions and Linear layers of the
+// model run on the gather-GEMM kernels (gconv.hip / gconv2.hip).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pdse.h"
+#include "pdse_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define REQ(cond, msg)     \
+  do {                     \
+    if (!(cond)) {         \
+      pdse_set_error(msg); \
+      return 1;            \
+    }                      \
+  } while (0)
+
+__device__ __forceinline__ float aia_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+__device__ __forceinline__ float aia_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + aia_exp(-x)); }
+
+// ---------------------------------------------------------------------------------------
+// LayerNorm over the F bins of a (b,c,t) row, then PReLU with the channel's slope
+// (dbaiat.py:498 inp_norm/inp_prelu, :627-628 DenseBlock, :500 enc_norm1, :545 dec_norm1).
+// One wavefront per row (F <= 192: three values per lane), HBM-bound.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rowln_kernel(const pdse_rowln_desc d) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t rows = (int64_t)d.B * d.C * d.T;
+  if (row >= rows) return;
+  const int64_t b = row / ((int64_t)d.C * d.T), ct = row - b * (int64_t)d.C * d.T;
+  const int c = (int)(ct / d.T);
+  const float* x = d.in + row * d.F;
+  float* o = d.out + b * d.out_sb + ct * d.F;
+  float v[3];
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int i = k * 64 + lane;
+    v[k] = i < d.F ? x[i] : 0.f;
+    sum += v[k];
+  }
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+  const float mean = sum / (float)d.F;
+  float sq = 0.f;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float e = (k * 64 + lane) < d.F ? v[k] - mean : 0.f;
+    sq += e * e;
+  }
+  for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off);
+  const float rstd = 1.0f / sqrtf(sq / (float)d.F + d.eps);
+  const float slope = d.slope[c];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int i = k * 64 + lane;
+    if (i < d.F) {
+      const float y = (v[k] - mean) * rstd * d.gamma[i] + d.beta[i];
+      o[i] = y > 0.f ? y : slope * y;
+    }
+  }
+}
+
+int pdse_rowln_launch(const pdse_rowln_desc* d, hipStream_t s) {
+  REQ(d && d->in && d->gamma && d->beta && d->slope && d->out, "rowln: null pointer");
+  REQ(d->B > 0 && d->C > 0 && d->T > 0 && d->F > 0 && d->F <= 192, "rowln: bad sizes (F <= 192)");
+  const int64_t rows = (int64_t)d->B * d->C * d->T;
+  REQ((rows + 3) / 4 < (1ll << 31), "rowln: too many rows");
+  hipLaunchKernelGGL(rowln_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, *d);
+  return pdse_check_launch("rowln");
+}
+
+// ---------------------------------------------------------------------------------------
+// LayerNorm over the C (<= 64) channels of every position (the d_model axis of the
+// transformer layers, dbaiat.py:76,81,87).  One thread per position, coalesced across threads.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void chln_kernel(const pdse_chln_desc d) {
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (q >= d.plane) return;
+  const float* x = d.in + (int64_t)b * d.C * d.plane + q;
+  float* o = d.out + (int64_t)b * d.C * d.plane + q;
+  float v[64];
+  float sum = 0.f;
+#pragma unroll
+  for (int c = 0; c < 64; ++c) {
+    v[c] = c < d.C ? x[(int64_t)c * d.plane] : 0.f;
+    sum += v[c];
+  }
+  const float mean = sum / (float)d.C;
+  float sq = 0.f;
+#pragma unroll
+  for (int c = 0; c < 64; ++c) {
+    const float e = c < d.C ? v[c] - mean : 0.f;
+    sq += e * e;
+  }
+  const float rstd = 1.0f / sqrtf(sq / (float)d.C + d.eps);
+#pragma unroll
+  for (int c = 0; c < 64; ++c)
+    if (c < d.C) o[(int64_t)c * d.plane] = (v[c] - mean) * rstd * d.gamma[c] + d.beta[c];
+}
+
+int pdse_chln_launch(const pdse_chln_desc* d, hipStream_t s) {
+  REQ(d && d->in && d->gamma && d->beta && d->out, "chln: null pointer");
+  REQ(d->B > 0 && d->B <= 65535 && d->C > 0 && d->C <= 64 && d->plane > 0, "chln: bad sizes (C <= 64)");
+  hipLaunchKernelGGL(chln_kernel, dim3((unsigned)((d->plane + 255) / 256), d->B), dim3(256), 0, s, *d);
+  return pdse_check_launch("chln");
+}
+
+// ---------------------------------------------------------------------------------------
+// Attention core: one workgroup per (line, b); K and V of the line live in LDS, each thread
+// owns (query position, head) pairs and runs an online softmax over the keys.
+// E = 32, 4 heads of 8 (dbaiat.py:123-126); sequence 80 (bins) or T (frames).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_kernel(const pdse_attn_desc d) {
+  extern __shared__ float kv[];  // [S][E] keys, then [S][E] values
+  const int E = d.E, HD = 8;
+  const int b = blockIdx.y, line = blockIdx.x;
+  const int S = d.axis == 0 ? d.F : d.T;
+  const int64_t plane = (int64_t)d.T * d.F;
+  const int64_t base = (int64_t)b * 3 * E * plane + (d.axis == 0 ? (int64_t)line * d.F : (int64_t)line);
+  const int64_t ss = d.axis == 0 ? 1 : d.F;
+  float* ks = kv;
+  float* vs = kv + (size_t)S * E;
+  for (int i = threadIdx.x; i < S * E; i += 256) {
+    const int e = i / S, sp = i - e * S;  // consecutive threads -> consecutive sequence positions
+    ks[sp * E + e] = d.qkv[base + (int64_t)(E + e) * plane + (int64_t)sp * ss];
+    vs[sp * E + e] = d.qkv[base + (int64_t)(2 * E + e) * plane + (int64_t)sp * ss];
+  }
+  __syncthreads();
+  const int64_t obase = (int64_t)b * E * plane + (d.axis == 0 ? (int64_t)line * d.F : (int64_t)line);
+  for (int idx = threadIdx.x; idx < S * d.heads; idx += 256) {
+    const int hd = idx / S, sq = idx - hd * S;
+    float q[HD], acc[HD];
+#pragma unroll
+    for (int e = 0; e < HD; ++e) {
+      q[e] = d.qkv[base + (int64_t)(hd * HD + e) * plane + (int64_t)sq * ss];
+      acc[e] = 0.f;
+    }
+    float m = -1e30f, l = 0.f;
+    for (int sp = 0; sp < S; ++sp) {
+      const float* kr = ks + sp * E + hd * HD;
+      float sc = 0.f;
+#pragma unroll
+      for (int e = 0; e < HD; ++e) sc += q[e] * kr[e];
+      const float mn = fmaxf(m, sc);
+      const float corr = aia_exp(m - mn), pw = aia_exp(sc - mn);
+      const float* vr = vs + sp * E + hd * HD;
+      l = l * corr + pw;
+#pragma unroll
+      for (int e = 0; e < HD; ++e) acc[e] = acc[e] * corr + pw * vr[e];
+      m = mn;
+    }
+    const float inv = 1.0f / l;
+#pragma unroll
+    for (int e = 0; e < HD; ++e) d.out[obase + (int64_t)(hd * HD + e) * plane + (int64_t)sq * ss] = acc[e] * inv;
+  }
+}
+
+int pdse_attn_launch(const pdse_attn_desc* d, hipStream_t s) {
+  REQ(d && d->qkv && d->out, "attention: null pointer");
+  REQ(d->B > 0 && d->B <= 65535 && d->T > 0 && d->F > 0 && d->E == 32 && d->heads == 4, "attention: E = 32, 4 heads");
+  REQ(d->axis == 0 || d->axis == 1, "attention: axis 0 (bins) or 1 (frames)");
+  const int S = d->axis == 0 ? d->F : d->T, lines = d->axis == 0 ? d->T : d->F;
+  const size_t lds = (size_t)2 * S * d->E * sizeof(float);
+  REQ(lds <= 160 * 1024, "attention: sequence too long for one LDS image (S <= 640)");
+  if (lds > 64 * 1024)
+    if (pdse_check_hip(hipFuncSetAttribute((const void*)attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                       "attention lds attribute"))
+      return 1;
+  hipLaunchKernelGGL(attn_kernel, dim3(lines, d->B), dim3(256), lds, s, *d);
+  return pdse_check_launch("attention");
+}
+
+// ---------------------------------------------------------------------------------------
+// Bidirectional GRU, hidden 64 (dbaiat.py:45,83), persistent over the sequence: a workgroup
+// owns 32 lines of one direction for all S steps, so the recurrence needs no inter-workgroup
+// synchronisation.  Waves 0..5 hold one 32-row tile of W_hh each in registers (A operand) and
+// multiply it with the state h [64 x 32 lines] kept in LDS (B operand, conflict-free rows);
+// all 8 waves then apply the gates (r,z,n order, n = tanh(x_n + r * (W_hn h + b_hn))).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void gru_kernel(const pdse_gru_desc d) {
+  constexpr int H = 64, G3 = 192;
+  __shared__ float hs[H][32];
+  __shared__ float gh[G3][33];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 31, hh = lane >> 5;
+  const int dir = blockIdx.y;
+  const int S = d.axis == 0 ? d.F : d.T;
+  const int per_b = d.axis == 0 ? d.T : d.F;
+  const int nlines = d.B * per_b;
+  const int64_t plane = (int64_t)d.T * d.F;
+  const int64_t ss = d.axis == 0 ? 1 : d.F;
+
+  float a[32];
+  if (wave < 6) {
+    const float* A = d.whh + ((size_t)(dir * 6 + wave) * 32) * 64 + lane;
+#pragma unroll
+    for (int ks = 0; ks < 32; ++ks) a[ks] = A[(size_t)ks * 64];
+  }
+  for (int i = threadIdx.x; i < H * 32; i += 512) (&hs[0][0])[i] = 0.f;
+
+  // gate work of this thread: 4 (unit, line) items, lines fastest
+  int64_t gbase[4], ybase[4];
+  int unit[4], ln[4];
+  bool live[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int it = threadIdx.x + 512 * k;
+    unit[k] = it >> 5;
+    ln[k] = it & 31;
+    const int L = blockIdx.x * 32 + ln[k];
+    live[k] = L < nlines;
+    const int b = live[k] ? L / per_b : 0, w = live[k] ? L - b * per_b : 0;
+    const int64_t pos = d.axis == 0 ? (int64_t)w * d.F : (int64_t)w;
+    gbase[k] = (int64_t)b * 6 * H * plane + pos + (int64_t)(dir * G3 + unit[k]) * plane;
+    ybase[k] = (int64_t)b * 2 * H * plane + pos + (int64_t)(dir * H + unit[k]) * plane;
+  }
+  const float* bh = d.bhh + dir * G3;
+  __syncthreads();
+
+  for (int step = 0; step < S; ++step) {
+    const int sq = dir ? S - 1 - step : step;
+    float xr[4], xz[4], xn[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int64_t o = gbase[k] + (int64_t)sq * ss;
+      xr[k] = live[k] ? d.gx[o] : 0.f;
+      xz[k] = live[k] ? d.gx[o + (int64_t)H * plane] : 0.f;
+      xn[k] = live[k] ? d.gx[o + (int64_t)2 * H * plane] : 0.f;
+    }
+    if (wave < 6) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 32; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks], hs[2 * ks + hh][col], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        gh[row][col] = acc[r] + bh[row];
+      }
+    }
+    __syncthreads();
+    float hn[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int u = unit[k], l = ln[k];
+      const float r = aia_sigmoid(xr[k] + gh[u][l]);
+      const float z = aia_sigmoid(xz[k] + gh[H + u][l]);
+      const float n = tanhf(xn[k] + r * gh[2 * H + u][l]);
+      hn[k] = (1.f - z) * n + z * hs[u][l];
+    }
+    __syncthreads();   // every MFMA wave has consumed hs, every gate thread has read gh
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      hs[unit[k]][ln[k]] = hn[k];
+      if (live[k]) d.y[ybase[k] + (int64_t)sq * ss] = hn[k];
+    }
+    __syncthreads();
+  }
+}
+
+int pdse_gru_launch(const pdse_gru_desc* d, hipStream_t s) {
+  REQ(d && d->gx && d->whh && d->bhh && d->y, "bigru: null pointer");
+  REQ(d->B > 0 && d->T > 0 && d->F > 0 && d->H == 64, "bigru: hidden size 64 (dbaiat.py:45)");
+  REQ(d->axis == 0 || d->axis == 1, "bigru: axis 0 (bins) or 1 (frames)");
+  const int nlines = d->B * (d->axis == 0 ? d->T : d->F);
+  hipLaunchKernelGGL(gru_kernel, dim3((nlines + 31) / 32, 2), dim3(512), 0, s, *d);
+  return pdse_check_launch("bigru");
+}
+
+// ---------------------------------------------------------------------------------------
+// GroupNorm(1, C, eps 1e-8) of the row and column branches + the AIA layer update
+// (dbaiat.py:142,147-148).  Two launches: fixed-order partial sums (deterministic, no float
+// atomics), then every workgroup of the apply pass folds the 64 partials in double.
+// ---------------------------------------------------------------------------------------
+#define GN_PARTS 64
+__global__ __launch_bounds__(256) void gn_stats_kernel(const pdse_gncomb_desc d) {
+  __shared__ float red[4][4];
+  const int b = blockIdx.y, part = blockIdx.x;
+  const int64_t n = (int64_t)d.C * d.plane;
+  const float* r = d.row + (int64_t)b * n;
+  const float* c = d.col + (int64_t)b * n;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t i = (int64_t)part * 256 + threadIdx.x; i < n; i += (int64_t)GN_PARTS * 256) {
+    const float a = r[i], e = c[i];
+    s[0] += a;
+    s[1] += a * a;
+    s[2] += e;
+    s[3] += e * e;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    for (int off = 32; off > 0; off >>= 1) s[k] += __shfl_xor(s[k], off);
+  if ((threadIdx.x & 63) == 0)
+    for (int k = 0; k < 4; ++k) red[threadIdx.x >> 6][k] = s[k];
+  __syncthreads();
+  if (threadIdx.x < 4)
+    d.stats[((size_t)b * GN_PARTS + part) * 4 + threadIdx.x] =
+        red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const pdse_gncomb_desc d) {
+  __shared__ float st[4];
+  const int b = blockIdx.y;
+  const int64_t n = (int64_t)d.C * d.plane;
+  if (threadIdx.x < 4) {
+    double acc = 0.0;
+    for (int p = 0; p < GN_PARTS; ++p) acc += (double)d.stats[((size_t)b * GN_PARTS + p) * 4 + threadIdx.x];
+    st[threadIdx.x] = (float)(acc / (double)n);
+  }
+  __syncthreads();
+  const float mr = st[0], mc = st[2];
+  const float rr = 1.0f / sqrtf(fmaxf(st[1] - mr * mr, 0.f) + d.eps);
+  const float rc = 1.0f / sqrtf(fmaxf(st[3] - mc * mc, 0.f) + d.eps);
+  const int64_t off = (int64_t)b * n;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i / d.plane);
+    const float gr = (d.row[off + i] - mr) * rr * d.g_row[c] + d.b_row[c];
+    const float gc = (d.col[off + i] - mc) * rc * d.g_col[c] + d.b_col[c];
+    d.out[off + i] = d.base[off + i] + d.k1 * gr + d.k2 * gc;
+  }
+}
+
+int pdse_gncomb_launch(const pdse_gncomb_desc* d, hipStream_t s) {
+  REQ(d && d->base && d->row && d->col && d->g_row && d->b_row && d->g_col && d->b_col && d->stats && d->out,
+      "gn_combine: null pointer");
+  REQ(d->B > 0 && d->B <= 65535 && d->C > 0 && d->plane > 0, "gn_combine: bad sizes");
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(GN_PARTS, d->B), dim3(256), 0, s, *d);
+  const int64_t n = (int64_t)d->C * d->plane;
+  int bx = (int)((n + 255) / 256);
+  if (bx > 256) bx = 256;
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(bx, d->B), dim3(256), 0, s, *d);
+  return pdse_check_launch("gn_combine");
+}
+
+// ---------------------------------------------------------------------------------------
+// AHAM (dbaiat.py:266-288): channel means of the 4 layer outputs, softmax over the layers of
+// conv1(mean) (conv1 is linear, so it commutes with the average pool), weighted merge.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void aham_mean_kernel(const pdse_aham_desc d) {
+  __shared__ float red[4];
+  const int c = blockIdx.x, b = blockIdx.y, i = blockIdx.z;
+  const float* x = d.x[i] + ((int64_t)b * d.C + c) * d.plane;
+  float s = 0.f;
+  for (int64_t q = threadIdx.x; q < d.plane; q += 256) s += x[q];
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) d.means[((size_t)i * d.B + b) * d.C + c] = (red[0] + red[1] + red[2] + red[3]) / (float)d.plane;
+}
+
+__global__ __launch_bounds__(256) void aham_merge_kernel(const pdse_aham_desc d) {
+  __shared__ float w[4];
+  const int b = blockIdx.y;
+  if (threadIdx.x < 4) {
+    float y = d.bias;
+    for (int c = 0; c < d.C; ++c) y += d.w[c] * d.means[((size_t)threadIdx.x * d.B + b) * d.C + c];
+    w[threadIdx.x] = y;
+  }
+  __syncthreads();
+  const float mx = fmaxf(fmaxf(w[0], w[1]), fmaxf(w[2], w[3]));
+  const float e0 = expf(w[0] - mx), e1 = expf(w[1] - mx), e2 = expf(w[2] - mx), e3 = expf(w[3] - mx);
+  const float inv = 1.0f / (e0 + e1 + e2 + e3);
+  const int64_t n = (int64_t)d.C * d.plane, off = (int64_t)b * n;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float x3 = d.x[3][off + i];
+    d.out[off + i] = x3 + inv * (e0 * d.x[0][off + i] + e1 * d.x[1][off + i] + e2 * d.x[2][off + i] + e3 * x3);
+  }
+}
+
+int pdse_aham_launch(const pdse_aham_desc* d, hipStream_t s) {
+  REQ(d && d->x[0] && d->x[1] && d->x[2] && d->x[3] && d->w && d->means && d->out, "aham: null pointer");
+  REQ(d->B > 0 && d->B <= 65535 && d->C > 0 && d->C <= 65535 && d->plane > 0, "aham: bad sizes");
+  hipLaunchKernelGGL(aham_mean_kernel, dim3(d->C, d->B, 4), dim3(256), 0, s, *d);
+  const int64_t n = (int64_t)d->C * d->plane;
+  int bx = (int)((n + 255) / 256);
+  if (bx > 256) bx = 256;
+  hipLaunchKernelGGL(aham_merge_kernel, dim3(bx, d->B), dim3(256), 0, s, *d);
+  return pdse_check_launch("aham");
+}

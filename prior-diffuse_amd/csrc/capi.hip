@@ -33,6 +33,12 @@ union pdse_any_desc {
   pdse_sigma_desc sigma;
   pdse_ln_desc ln;
   pdse_lstm_desc lstm;
+  pdse_rowln_desc rowln;
+  pdse_chln_desc chln;
+  pdse_attn_desc attn;
+  pdse_gru_desc gru;
+  pdse_gncomb_desc gncomb;
+  pdse_aham_desc aham;
 };
 
 struct pdse_op {
@@ -58,6 +64,12 @@ static int op_size(int kind) {
     case PDSE_OP_SIGMA: return (int)sizeof(pdse_sigma_desc);
     case PDSE_OP_LN: return (int)sizeof(pdse_ln_desc);
     case PDSE_OP_LSTM: return (int)sizeof(pdse_lstm_desc);
+    case PDSE_OP_ROWLN: return (int)sizeof(pdse_rowln_desc);
+    case PDSE_OP_CHLN: return (int)sizeof(pdse_chln_desc);
+    case PDSE_OP_ATTN: return (int)sizeof(pdse_attn_desc);
+    case PDSE_OP_GRU: return (int)sizeof(pdse_gru_desc);
+    case PDSE_OP_GNCOMB: return (int)sizeof(pdse_gncomb_desc);
+    case PDSE_OP_AHAM: return (int)sizeof(pdse_aham_desc);
     default: return -1;
   }
 }
@@ -73,6 +85,12 @@ static int launch_op(const pdse_op& op, hipStream_t s) {
     case PDSE_OP_SIGMA: return pdse_sigma_launch(&op.d.sigma, s);
     case PDSE_OP_LN: return pdse_ln_launch(&op.d.ln, s);
     case PDSE_OP_LSTM: return pdse_lstm_launch(&op.d.lstm, s);
+    case PDSE_OP_ROWLN: return pdse_rowln_launch(&op.d.rowln, s);
+    case PDSE_OP_CHLN: return pdse_chln_launch(&op.d.chln, s);
+    case PDSE_OP_ATTN: return pdse_attn_launch(&op.d.attn, s);
+    case PDSE_OP_GRU: return pdse_gru_launch(&op.d.gru, s);
+    case PDSE_OP_GNCOMB: return pdse_gncomb_launch(&op.d.gncomb, s);
+    case PDSE_OP_AHAM: return pdse_aham_launch(&op.d.aham, s);
     default: pdse_set_error("plan: unknown op kind"); return 1;
   }
 }
@@ -92,6 +110,12 @@ int pdse_ola_f32(const pdse_ola_desc* d, pdse_stream_t s) { return pdse_ola_laun
 int pdse_sigma_mask_f32(const pdse_sigma_desc* d, pdse_stream_t s) { return pdse_sigma_launch(d, (hipStream_t)s); }
 int pdse_layernorm_f32(const pdse_ln_desc* d, pdse_stream_t s) { return pdse_ln_launch(d, (hipStream_t)s); }
 int pdse_lstm_f32(const pdse_lstm_desc* d, pdse_stream_t s) { return pdse_lstm_launch(d, (hipStream_t)s); }
+int pdse_rowln_prelu_f32(const pdse_rowln_desc* d, pdse_stream_t s) { return pdse_rowln_launch(d, (hipStream_t)s); }
+int pdse_chln_f32(const pdse_chln_desc* d, pdse_stream_t s) { return pdse_chln_launch(d, (hipStream_t)s); }
+int pdse_attention_f32(const pdse_attn_desc* d, pdse_stream_t s) { return pdse_attn_launch(d, (hipStream_t)s); }
+int pdse_bigru_f32(const pdse_gru_desc* d, pdse_stream_t s) { return pdse_gru_launch(d, (hipStream_t)s); }
+int pdse_gn_combine_f32(const pdse_gncomb_desc* d, pdse_stream_t s) { return pdse_gncomb_launch(d, (hipStream_t)s); }
+int pdse_aham_f32(const pdse_aham_desc* d, pdse_stream_t s) { return pdse_aham_launch(d, (hipStream_t)s); }
 
 int pdse_plan_create(pdse_plan** out) {
   if (!out) {

@@ -303,6 +303,8 @@ int pdse_gconv2_launch(const pdse_gconv_desc* d, hipStream_t s) {
     if (nt == 1 && !two && xf == 1) GO(PDSE_EPI_LINEAR, 1, 8, false, 1, true, true, true);
     if (nt == 1 && two && xf == 0) GO(PDSE_EPI_LINEAR, 1, 8, true, 0, true, true, true);
     if (nt == 4 && !two && xf == 0) GO(PDSE_EPI_LINEAR, 4, 2, false, 0, true, true, true);
+    if (nt == 3 && !two && xf == 0) GO(PDSE_EPI_LINEAR, 3, 4, false, 0, true, true, true);   // dbaiat (1,3) convs
+    if (nt == 6 && !two && xf == 0) GO(PDSE_EPI_LINEAR, 6, 2, false, 0, true, true, true);   // dbaiat dense blocks
   } else if (d->epi == PDSE_EPI_GLU) {
     if (nt == 1 && two && xf == 0) GO(PDSE_EPI_GLU, 1, 4, true, 0, true, true, true);
     if (nt == 2 && two && xf == 0) GO(PDSE_EPI_GLU, 2, 2, true, 0, true, true, true);

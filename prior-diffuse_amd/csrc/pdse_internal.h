@@ -20,4 +20,10 @@ int pdse_ola_launch(const pdse_ola_desc* d, hipStream_t s);
 int pdse_sigma_launch(const pdse_sigma_desc* d, hipStream_t s);
 int pdse_ln_launch(const pdse_ln_desc* d, hipStream_t s);
 int pdse_lstm_launch(const pdse_lstm_desc* d, hipStream_t s);
+int pdse_rowln_launch(const pdse_rowln_desc* d, hipStream_t s);
+int pdse_chln_launch(const pdse_chln_desc* d, hipStream_t s);
+int pdse_attn_launch(const pdse_attn_desc* d, hipStream_t s);
+int pdse_gru_launch(const pdse_gru_desc* d, hipStream_t s);
+int pdse_gncomb_launch(const pdse_gncomb_desc* d, hipStream_t s);
+int pdse_aham_launch(const pdse_aham_desc* d, hipStream_t s);
 #endif

@@ -600,3 +600,182 @@ class IstftPlan(PlanBase):
         o.B, o.T, o.L, o.n_fft, o.hop = B, T, self.L, 320, 160
         self.add(o, TAG_SIGNAL)
         return self.wav
+
+
+# ==========================================================================
+# DB-AIAT prior  aia_complex_trans_ri  (model/dbaiat.py:450-478)
+# ==========================================================================
+class AiaPlan(PlanBase):
+    """dense_encoder -> AIA_Transformer (4 x {row over bins, col over frames}) -> AHAM ->
+    two dense_decoders.  Convolutions / Linear layers run on the gather-GEMM kernels, the rest
+    on the operators of csrc/aia.hip."""
+
+    FH = 80  # bins after the stride-2 encoder conv
+
+    def __init__(self, ctx, sd, B, T, plan=None):
+        super().__init__(ctx, plan)
+        self.sd, self.B, self.T = sd, B, T
+        a = ctx.alloc
+        FH = self.FH
+        self.x = a(B, 2, T, F0)
+        self.out = a(B, 2, T, F0)
+        self.tmp161 = a(B, 64, T, F0)
+        self.tmp80 = a(B, 64, T, FH)
+        self.D161 = a(B, 320, T, F0)            # dense buffer [out4,out3,out2,out1,x]
+        self.D80 = a(B, 320, T, FH)
+        self.x_ri = a(B, 64, T, FH)
+        self.cur = a(B, 32, T, FH)               # AIA state ("output" in dbaiat.py:138)
+        self.nxt = a(B, 32, T, FH)
+        self.n_a, self.n_b = a(B, 32, T, FH), a(B, 32, T, FH)
+        self.qkv = a(B, 96, T, FH)
+        self.att = a(B, 32, T, FH)
+        self.gx = a(B, 384, T, FH)
+        self.gy = a(B, 128, T, FH)
+        self.s1, self.s2 = a(B, 32, T, FH), a(B, 32, T, FH)
+        self.br = [a(B, 32, T, FH), a(B, 32, T, FH)]      # row / col branch outputs
+        self.outs = [a(B, 64, T, FH) for _ in range(4)]
+        self.merged = a(B, 64, T, FH)
+        self.gn_stats = a(B, 64, 4)
+        self.means = a(4, B, 64)
+        self.dec_up = a(B, 64, T, F0, zero=True)  # sub-pixel output; bin 0 is the left zero pad, never written
+
+    def w(self, k):
+        return P._np(self.sd[k])
+
+    # ---- small operators ---------------------------------------------------
+    def _rowln(self, src, dst, dst_sb, C_, F_, norm, prelu, dst_off=0):
+        d = L.RowlnDesc()
+        d.in_, d.out = src.data_ptr(), Ctx.ptr(dst, dst_off)
+        d.gamma, d.beta = self.ctx.up(self.w(norm + ".weight")).data_ptr(), self.ctx.up(self.w(norm + ".bias")).data_ptr()
+        d.slope = self.ctx.up(self.w(prelu + ".weight")).data_ptr()
+        d.out_sb, d.B, d.C, d.T, d.F, d.eps = dst_sb, self.B, C_, self.T, F_, 1e-5
+        self.add(d, TAG_PRIOR)
+
+    def _chln(self, src, dst, norm):
+        d = L.ChlnDesc()
+        d.in_, d.out = src.data_ptr(), dst.data_ptr()
+        d.gamma, d.beta = self.ctx.up(self.w(norm + ".weight")).data_ptr(), self.ctx.up(self.w(norm + ".bias")).data_ptr()
+        d.plane, d.B, d.C, d.eps = self.T * self.FH, self.B, 32, 1e-5
+        self.add(d, TAG_PRIOR)
+
+    def _pw(self, src_t, Cin, wk, bias, out_t, Cout, F_, resid=None, act=L.ACT_NONE, act_slope=0.0, xf=None,
+            in_act=L.ACT_NONE):
+        """1x1 convolution / Linear over the channel axis of [B,Cin,T,F_]."""
+        T = self.T
+        self.gconv(in0=self.src(src_t, Cin, *nchw(Cin, T, F_), act=in_act), Tin=T, Fin=F_, taps=[(0, 0)], sf_in=1,
+                   wk0=wk, Cout=Cout, bias0=bias, act=act, act_slope=act_slope, xf=xf, resid=resid, out=out_t,
+                   out_strides=nchw_out(Cout, T, F_), B=self.B, Tout=T, Fout=F_, tag=TAG_PRIOR)
+
+    def _dense_block(self, p, D, F_, tmp):
+        """dbaiat.py:605-631.  D [B,320,T,F_] holds [out4,out3,out2,out1,x]; x is already in block 4."""
+        B, T = self.B, self.T
+        for i in range(1, 5):
+            dil = 2 ** (i - 1)
+            cin = 64 * i
+            cstart = (5 - i) * 64                                    # skip = channels cstart..319
+            kk = [(kt, kf) for kt in range(2) for kf in range(3)]
+            taps = [((kt - 1) * dil, kf - 1) for kt, kf in kk]       # pad (1,1,dil,0): causal in time, same in bins
+            self.gconv(in0=self.src(D, cin, *nchw(320, T, F_), off=cstart * T * F_), Tin=T, Fin=F_, taps=taps, sf_in=1,
+                       wk0=P.conv_kmat(self.sd["%s.conv%d.weight" % (p, i)], kk), Cout=64,
+                       bias0=self.w("%s.conv%d.bias" % (p, i)), out=tmp, out_strides=nchw_out(64, T, F_), B=B, Tout=T,
+                       Fout=F_, tag=TAG_PRIOR)
+            self._rowln(tmp, D, 320 * T * F_, 64, F_, "%s.norm%d" % (p, i), "%s.prelu%d" % (p, i),
+                        dst_off=(4 - i) * 64 * T * F_)
+        return 0  # out4 sits in channel block 0
+
+    def _encoder_layer(self, p, axis, src_t, dst_t):
+        """TransformerEncoderLayer (dbaiat.py:66-88) along bins (axis 0) or frames (axis 1)."""
+        B, T, FH = self.B, self.T, self.FH
+        self._chln(src_t, self.n_a, p + ".norm3")
+        Wi, bi = self.w(p + ".self_attn.in_proj_weight").copy(), self.w(p + ".self_attn.in_proj_bias").copy()
+        Wi[:32] *= 8 ** -0.5                                          # q scaled by head_dim^-0.5 inside the projection
+        bi[:32] *= 8 ** -0.5
+        self._pw(self.n_a, 32, Wi.T, bi, self.qkv, 96, FH)
+        d = L.AttnDesc()
+        d.qkv, d.out, d.B, d.T, d.F, d.E, d.heads, d.axis = self.qkv.data_ptr(), self.att.data_ptr(), B, T, FH, 32, 4, axis
+        self.add(d, TAG_PRIOR)
+        self._pw(self.att, 32, self.w(p + ".self_attn.out_proj.weight").T, self.w(p + ".self_attn.out_proj.bias"),
+                 self.s1, 32, FH, resid=src_t)                        # src + attention
+        self._chln(self.s1, self.n_b, p + ".norm1")
+        g = p + ".gru."
+        Wih = np.concatenate([self.w(g + "weight_ih_l0"), self.w(g + "weight_ih_l0_reverse")], 0)   # [384, 32]
+        bih = np.concatenate([self.w(g + "bias_ih_l0"), self.w(g + "bias_ih_l0_reverse")], 0)
+        self._pw(self.n_b, 32, Wih.T, bih, self.gx, 384, FH)
+        whh = np.stack([P.pack_a(self.w(g + "weight_hh_l0" + suf).T) for suf in ("", "_reverse")], 0)   # [2,6,32,64]
+        bhh = np.stack([self.w(g + "bias_hh_l0"), self.w(g + "bias_hh_l0_reverse")], 0)
+        gd = L.GruDesc()
+        gd.gx, gd.y = self.gx.data_ptr(), self.gy.data_ptr()
+        gd.whh, gd.bhh = self.ctx.up(whh).data_ptr(), self.ctx.up(bhh).data_ptr()
+        gd.B, gd.T, gd.F, gd.H, gd.axis = B, T, FH, 64, axis
+        self.add(gd, TAG_LSTM)
+        # relu -> linear2 -> + residual (the normed tensor); ReLU = the load transform with slope 0, identity affine
+        relu = dict(mode=1, scale0=np.ones(128), shift0=np.zeros(128), slope0=0.0)
+        self._pw(self.gy, 128, self.w(p + ".linear2.weight").T, self.w(p + ".linear2.bias"), self.s2, 32, FH,
+                 resid=self.n_b, xf=relu)
+        self._chln(self.s2, dst_t, p + ".norm2")
+
+    def build(self, x=None, out=None):
+        B, T, FH = self.B, self.T, self.FH
+        x = self.x if x is None else x
+        out = self.out if out is None else out
+        sd = self.sd
+        # ---- dense_encoder (dbaiat.py:481-501)
+        self._pw(x, 2, self.w("en_ri.inp_conv.weight")[:, :, 0, 0].T, self.w("en_ri.inp_conv.bias"), self.tmp161, 64, F0)
+        self._rowln(self.tmp161, self.D161, 320 * T * F0, 64, F0, "en_ri.inp_norm", "en_ri.inp_prelu",
+                    dst_off=256 * T * F0)
+        self._dense_block("en_ri.enc_dense1", self.D161, F0, self.tmp161)
+        kk, taps = P.conv_taps(1, 3, 0)
+        self.gconv(in0=self.src(self.D161, 64, *nchw(320, T, F0)), Tin=T, Fin=F0, taps=taps, sf_in=2,
+                   wk0=P.conv_kmat(sd["en_ri.enc_conv1.weight"], kk), Cout=64, bias0=self.w("en_ri.enc_conv1.bias"),
+                   out=self.tmp80, out_strides=nchw_out(64, T, FH), B=B, Tout=T, Fout=FH, tag=TAG_PRIOR)
+        self._rowln(self.tmp80, self.x_ri, 64 * T * FH, 64, FH, "en_ri.enc_norm1", "en_ri.enc_prelu1")
+        # ---- AIA_Transformer (dbaiat.py:133-154)
+        p = "dual_trans"
+        self._pw(self.x_ri, 64, self.w(p + ".input.0.weight")[:, :, 0, 0].T, self.w(p + ".input.0.bias"), self.cur, 32, FH,
+                 act=L.ACT_PRELU, act_slope=float(self.w(p + ".input.1.weight")[0]))
+        k1, k2 = float(self.w(p + ".k1")[0]), float(self.w(p + ".k2")[0])
+        slope_o = float(self.w(p + ".output.0.weight")[0])
+        ident = dict(mode=1, scale0=np.ones(32), shift0=np.zeros(32), slope0=slope_o)   # PReLU on load
+        cur, nxt = self.cur, self.nxt
+        for i in range(4):
+            self._encoder_layer("%s.row_trans.%d" % (p, i), 0, cur, self.br[0])
+            self._encoder_layer("%s.col_trans.%d" % (p, i), 1, cur, self.br[1])
+            g = L.GncombDesc()
+            g.base, g.row, g.col, g.out = cur.data_ptr(), self.br[0].data_ptr(), self.br[1].data_ptr(), nxt.data_ptr()
+            up = self.ctx.up
+            g.g_row, g.b_row = up(self.w("%s.row_norm.%d.weight" % (p, i))).data_ptr(), up(self.w("%s.row_norm.%d.bias" % (p, i))).data_ptr()
+            g.g_col, g.b_col = up(self.w("%s.col_norm.%d.weight" % (p, i))).data_ptr(), up(self.w("%s.col_norm.%d.bias" % (p, i))).data_ptr()
+            g.stats, g.plane, g.B, g.C, g.k1, g.k2, g.eps = self.gn_stats.data_ptr(), T * FH, B, 32, k1, k2, 1e-8
+            self.add(g, TAG_PRIOR)
+            cur, nxt = nxt, cur
+            self._pw(cur, 32, self.w(p + ".output.1.weight")[:, :, 0, 0].T, self.w(p + ".output.1.bias"), self.outs[i], 64,
+                     FH, xf=ident)
+        # ---- AHAM (dbaiat.py:266-288)
+        ah = L.AhamDesc()
+        for i in range(4):
+            ah.x[i] = self.outs[i].data_ptr()
+        ah.w, ah.bias = self.ctx.up(self.w("aham.conv1.weight").reshape(64)).data_ptr(), float(self.w("aham.conv1.bias")[0])
+        ah.means, ah.out, ah.plane, ah.B, ah.C = self.means.data_ptr(), self.merged.data_ptr(), T * FH, B, 64
+        self.add(ah, TAG_PRIOR)
+        # ---- two dense_decoders (dbaiat.py:527-548) with the sub-pixel up-convolution (:587-602)
+        for ch, de in enumerate(("de1", "de2")):
+            # merged -> channel block 4 of every batch item (strided over batch: one copy per item)
+            for b in range(B):
+                c = L.EwDesc()
+                c.a, c.out = Ctx.ptr(self.merged, b * 64 * T * FH), Ctx.ptr(self.D80, (b * 320 + 256) * T * FH)
+                c.n, c.op = 64 * T * FH, L.EW_COPY
+                self.add(c, TAG_EW)
+            self._dense_block(de + ".dec_dense1", self.D80, FH, self.tmp80)
+            taps = [(0, kf - 1) for kf in range(3)]                   # pad (1,1) in bins
+            kk = [(0, kf) for kf in range(3)]
+            # co = r*64 + c  ->  channel c, bin 1 + 2w + r   (sub-pixel r = 2, then one zero bin on the left)
+            self.gconv(in0=self.src(self.D80, 64, *nchw(320, T, FH)), Tin=T, Fin=FH, taps=taps, sf_in=1,
+                       wk0=P.conv_kmat(sd[de + ".dec_conv1.conv.weight"], kk), Cout=128,
+                       bias0=self.w(de + ".dec_conv1.conv.bias"), out=self.dec_up,
+                       out_strides=(64 * T * F0, 1, T * F0, F0, 2), out_cr=64, out_off=1, B=B, Tout=T, Fout=FH,
+                       tag=TAG_PRIOR)
+            self._rowln(self.dec_up, self.tmp161, 64 * T * F0, 64, F0, de + ".dec_norm1", de + ".dec_prelu1")
+            self.gconv(in0=self.src(self.tmp161, 64, *nchw(64, T, F0)), Tin=T, Fin=F0, taps=[(0, 0)], sf_in=1,
+                       wk0=self.w(de + ".out_conv.weight")[:, :, 0, 0].T, Cout=1, bias0=self.w(de + ".out_conv.bias"),
+                       out=out, out_strides=nchw_out(2, T, F0), out_off=ch * T * F0, B=B, Tout=T, Fout=F0, tag=TAG_PRIOR)
+        return out

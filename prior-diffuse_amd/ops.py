@@ -99,4 +99,22 @@ class GCRNOp(_PlannedOp):
         return net.out.clone()
 
 
-PRIOR_OPS = {"GCRN": GCRNOp, "DiffUNet": DiffUNetOp}
+class AiaOp(_PlannedOp):
+    """Prior ``aia_complex_trans_ri.forward(x)`` (model/dbaiat.py:461-478, conf/dbaiat.yml:13)."""
+
+    def __call__(self, x):
+        self._check(x)
+        B, _, T, _ = x.shape
+        key = (B, T)
+        if key not in self._plans:
+            net = nets.AiaPlan(nets.Ctx(self.device), self.sd, B, T)
+            net.build()
+            net.finish()
+            self._plans[key] = net
+        net = self._plans[key]
+        net.x.copy_(x)
+        net.plan.run(self._stream())
+        return net.out.clone()
+
+
+PRIOR_OPS = {"GCRN": GCRNOp, "DiffUNet": DiffUNetOp, "aia_complex_trans_ri": AiaOp}

@@ -52,8 +52,10 @@ class SamplerPipeline:
             self.prior = adopt(nets.GcrnPlan(ctx, prior_sd, B, T, plan=self.plan))
         elif prior_name == "DiffUNet":
             self.prior = adopt(nets.EpsNetPlan(ctx, prior_sd, B, T, time_cond=False, plan=self.plan))
+        elif prior_name == "aia_complex_trans_ri":
+            self.prior = adopt(nets.AiaPlan(ctx, prior_sd, B, T, plan=self.plan))
         else:
-            raise ValueError("prior %r not built yet (GCRN, DiffUNet)" % prior_name)
+            raise ValueError("prior %r not built (GCRN, DiffUNet, aia_complex_trans_ri)" % prior_name)
         self.eps = adopt(nets.EpsNetPlan(ctx, ddpm_sd, B, T, time_cond=True, nsteps=S, plan=self.plan))
         self.istft = adopt(nets.IstftPlan(ctx, B, T, L_, plan=self.plan)) if with_signal else None
 
@@ -71,7 +73,7 @@ class SamplerPipeline:
 
         if with_signal:
             mark("stft", lambda: self.stft.build(feat=self.feat))
-        if prior_name == "GCRN":
+        if prior_name in ("GCRN", "aia_complex_trans_ri"):
             mark("prior", lambda: self.prior.build(x=self.feat, out=self.prior.out))
         else:
             mark("prior", lambda: self.prior.build_step(0, x=self.feat, out=self.prior.out))

@@ -53,8 +53,7 @@ class ComplexDDPMTrainer(object):
         L.load()
         self.prior_name = self.config.model.name
         if self.prior_name not in ops.PRIOR_OPS:
-            raise NotImplementedError("prior %r: GCRN and DiffUNet are built; dbaiat is a later row of SURVEY §8"
-                                      % self.prior_name)
+            raise NotImplementedError("prior %r: built priors are %s" % (self.prior_name, sorted(ops.PRIOR_OPS)))
         self.prior_sd, self.ddpm_sd = prior_state_dict, ddpm_state_dict
         if getattr(self.args, "retrain", False):                      # :91-97
             self._load_checkpoint()

@@ -310,3 +310,35 @@ def test_concurrent_sub_batches_bit_identical(L, weights):
         w2, s2 = two.enhance(wav.to(DEV), x_T.to(DEV), graph=graph)
         _sync()
         assert torch.equal(w1, w2) and torch.equal(s1, s2)
+
+
+def test_aia_prior_golden_and_oracle(L, weights, R):
+    """DB-AIAT prior (aia_complex_trans_ri): golden vectors of the reference module at T=12 with
+    intermediates, then the oracle at T=401 (attention and GRU over 401 frames)."""
+    g = golden("aia_small")
+    op = pkg("ops").AiaOp(weights("aia_complex_trans_ri"), DEV)
+    out = op(seeded((2, 2, 12, 161), g["seed_x"]).to(DEV))
+    net = op._plans[(2, 12)]
+    _sync()
+    assert rel_l2(net.x_ri.cpu()[:, ::8], g["en_ri_c8"]) < 2e-5
+    assert rel_l2(net.outs[3].cpu()[:, ::8], g["trans_last_c8"]) < 5e-5
+    assert rel_l2(net.merged.cpu()[:, ::8], g["aham_c8"]) < 5e-5
+    assert rel_l2(out.cpu(), g["out"]) < 5e-5
+    x = seeded((1, 2, 401, 161), 61)
+    big = op(x.to(DEV)).cpu()
+    with torch.no_grad():
+        ref = R.aia_complex_trans_ri_forward(weights("aia_complex_trans_ri"), x)
+    assert rel_l2(big, ref) < 1e-4
+
+
+def test_sample_with_aia_prior(L, weights, R):
+    params = pkg("params").params
+    feat, x_T = pkg("synth").synthetic_spectrogram(2, 24, seed=3)
+    pipe = pkg("pipeline").SamplerPipeline(DEV, "aia_complex_trans_ri", weights("aia_complex_trans_ri"),
+                                           weights("DiffUNet1"), 2, T=24)
+    spec, init = pipe.sample(feat.to(DEV), x_T.to(DEV))
+    with torch.no_grad():
+        ref, ref_init = R.sample("aia_complex_trans_ri", weights("aia_complex_trans_ri"), weights("DiffUNet1"), feat, x_T,
+                                 params.noise_schedule, params.inference_noise_schedule, True, False)
+    assert rel_l2(init.cpu(), ref_init) < 5e-5
+    assert rel_l2(spec.cpu(), ref) < 1e-4
