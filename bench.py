@@ -39,6 +39,8 @@ def main():
     ap.add_argument("--seconds", type=float, default=4.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--prior", default="GCRN", choices=["GCRN", "DiffUNet", "aia_complex_trans_ri"],
+                    help="discriminative prior (BASELINE configs 1-3: GCRN; config 4: aia_complex_trans_ri)")
     ap.add_argument("--streams", type=int, default=1, help="concurrent sub-batch pipelines per GPU")
     args = ap.parse_args()
 
@@ -69,7 +71,7 @@ def main():
 
     B, L_ = args.batch, int(args.seconds * 16000)
     T = 1 + L_ // 160
-    gs, ds = synth.make_state_dict("GCRN"), synth.make_state_dict("DiffUNet1")
+    gs, ds = synth.make_state_dict(args.prior), synth.make_state_dict("DiffUNet1")
     # the global batch is generated once from the seed and sliced, so results do not depend on N
     lo, hi = shard.shard_range(B * world, world, rank)
     wav, x_T = synth.synthetic_waveforms(B * world, L_, seed=1234)
@@ -77,10 +79,10 @@ def main():
 
     use_graph = not args.no_graph
     if args.streams > 1:
-        runner = pipeline.ConcurrentSampler(dev, "GCRN", gs, ds, B, L_=L_, nsplit=args.streams, fast_sampling=True)
+        runner = pipeline.ConcurrentSampler(dev, args.prior, gs, ds, B, L_=L_, nsplit=args.streams, fast_sampling=True)
         pipe = runner.pipes[0]
     else:
-        runner = pipe = pipeline.SamplerPipeline(dev, "GCRN", gs, ds, B, L_=L_, fast_sampling=True)
+        runner = pipe = pipeline.SamplerPipeline(dev, args.prior, gs, ds, B, L_=L_, fast_sampling=True)
 
     def step():
         runner.enhance(wav, x_T, graph=use_graph)
@@ -124,7 +126,7 @@ def main():
     if args.streams > 1:
         del runner
         torch.cuda.empty_cache()
-        pipe = pipeline.SamplerPipeline(dev, "GCRN", gs, ds, B, L_=L_, fast_sampling=True)
+        pipe = pipeline.SamplerPipeline(dev, args.prior, gs, ds, B, L_=L_, fast_sampling=True)
     pipe.stft.wav.copy_(wav)
     pipe.xT_in.copy_(x_T)
     torch.cuda.synchronize()
@@ -166,9 +168,9 @@ def main():
         w_cpu, x_cpu = synth.synthetic_waveforms(B * world, L_, seed=1234)
         w_cpu, x_cpu = w_cpu[:cb], x_cpu[:cb]
         with torch.no_grad():
-            R.enhance("GCRN", gs, ds, w_cpu[:1], x_cpu[:1], params.noise_schedule, params.inference_noise_schedule, True)
+            R.enhance(args.prior, gs, ds, w_cpu[:1], x_cpu[:1], params.noise_schedule, params.inference_noise_schedule, True)
             tc = time.perf_counter()
-            R.enhance("GCRN", gs, ds, w_cpu, x_cpu, params.noise_schedule, params.inference_noise_schedule, True)
+            R.enhance(args.prior, gs, ds, w_cpu, x_cpu, params.noise_schedule, params.inference_noise_schedule, True)
             tc = time.perf_counter() - tc
         cpu = {"value": round(cb * args.seconds / tc, 3), "unit": "audio_s/s", "cores": nthreads, "kind": "port",
                "sample": "oracle (torch-CPU fp32 restatement), %d of the %d utterances, full path incl. STFT/ISTFT, "
@@ -180,8 +182,8 @@ def main():
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "frames_per_s_per_gpu": round(args.steps * B * T / elapsed, 1),
-        "config": {"workload": "B=%d x %.0f s 16 kHz utterances per GPU, [B,2,%d,161] spectrograms, GCRN prior + "
-                               "DiffUNet1 6-step fast sampling, STFT..ISTFT, seeded random weights" % (B, args.seconds, T),
+        "config": {"workload": "B=%d x %.0f s 16 kHz utterances per GPU, [B,2,%d,161] spectrograms, %s prior + "
+                               "DiffUNet1 6-step fast sampling, STFT..ISTFT, seeded random weights" % (B, args.seconds, T, args.prior),
                    "global_batch": B * world, "frames": T, "parallelism": "batch-shard x%d" % world,
                    "graph": use_graph, "streams_per_gpu": args.streams},
         "roofline": roofline, "cpu_baseline": cpu,
