@@ -41,8 +41,16 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--prior", default="GCRN", choices=["GCRN", "DiffUNet", "aia_complex_trans_ri"],
                     help="discriminative prior (BASELINE configs 1-3: GCRN; config 4: aia_complex_trans_ri)")
+    ap.add_argument("--inflight", type=int, default=3,
+                    help="batches in flight, each on its own HIP stream (1: strictly sequential, hipGraph replay). "
+                         "The latency-bound LSTM/TCM chains of one batch run beside the MFMA-bound blocks of the others; "
+                         "every batch's result is bit-identical to the sequential run")
+    ap.add_argument("--stage-streams", action="store_true",
+                    help="with --inflight 2: prior stream | loop stream instead of one stream per batch")
     ap.add_argument("--streams", type=int, default=1, help="concurrent sub-batch pipelines per GPU")
     args = ap.parse_args()
+    args.overlap = args.inflight > 1
+    args.depth, args.by_batch = max(2, args.inflight), not args.stage_streams
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -78,14 +86,21 @@ def main():
     wav, x_T = wav[lo:hi].to(dev), x_T[lo:hi].to(dev)
 
     use_graph = not args.no_graph
-    if args.streams > 1:
+    if args.overlap:
+        runner = pipeline.PipelinedSampler(dev, args.prior, gs, ds, B, L_, depth=args.depth, by_batch=args.by_batch,
+                                           fast_sampling=True)
+        pipe = runner.pipes[0]
+    elif args.streams > 1:
         runner = pipeline.ConcurrentSampler(dev, args.prior, gs, ds, B, L_=L_, nsplit=args.streams, fast_sampling=True)
         pipe = runner.pipes[0]
     else:
         runner = pipe = pipeline.SamplerPipeline(dev, args.prior, gs, ds, B, L_=L_, fast_sampling=True)
 
     def step():
-        runner.enhance(wav, x_T, graph=use_graph)
+        if args.overlap:
+            runner.submit(wav, x_T)          # every submitted batch completes inside the timed region (drain below)
+        else:
+            runner.enhance(wav, x_T, graph=use_graph)
 
     note("plan built: %d operators; warm-up (graph=%s)" % (len(pipe.descs), use_graph))
     for _ in range(args.warmup):
@@ -94,6 +109,8 @@ def main():
     note("warm-up done; timing %d steps" % args.steps)
 
     def barrier():
+        if args.overlap:
+            runner.drain()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -123,7 +140,7 @@ def main():
     # kernel durations are measured on the launch stream of ONE full-batch pipeline, launches back to back
     # (in the timed region above the sub-batch pipelines overlap each other, so wall time < sum of durations)
     stream = torch.cuda.current_stream().cuda_stream
-    if args.streams > 1:
+    if args.streams > 1 or args.overlap:
         del runner
         torch.cuda.empty_cache()
         pipe = pipeline.SamplerPipeline(dev, args.prior, gs, ds, B, L_=L_, fast_sampling=True)
@@ -185,7 +202,8 @@ def main():
         "config": {"workload": "B=%d x %.0f s 16 kHz utterances per GPU, [B,2,%d,161] spectrograms, %s prior + "
                                "DiffUNet1 6-step fast sampling, STFT..ISTFT, seeded random weights" % (B, args.seconds, T, args.prior),
                    "global_batch": B * world, "frames": T, "parallelism": "batch-shard x%d" % world,
-                   "graph": use_graph, "streams_per_gpu": args.streams},
+                   "graph": use_graph and not args.overlap, "streams_per_gpu": args.streams,
+                   "batches_in_flight": args.inflight},
         "roofline": roofline, "cpu_baseline": cpu,
     }
     print(json.dumps(out))

@@ -218,3 +218,79 @@ class ConcurrentSampler:
         else:
             self._run_all(False, "prior", "step0")
         return (torch.cat([p.spec for p in self.pipes], 0), torch.cat([p.prior.out for p in self.pipes], 0))
+
+
+class PipelinedSampler:
+    """Throughput mode for a stream of batches: two ``SamplerPipeline`` instances (ping-pong
+    buffers) and two HIP streams.  Stage 1 of batch n+1 (STFT + prior — dominated by the
+    latency-bound LSTM frame chain, which leaves most CUs idle) runs on the *prior* stream
+    while stage 2 of batch n (reverse loop + ISTFT — MFMA-bound) runs on the *loop* stream.
+    Per-batch results are bit-identical to ``SamplerPipeline.enhance``; only the schedule
+    differs.  ``submit`` returns immediately; ``result`` waits for that batch."""
+
+    def __init__(self, device, prior_name, prior_sd, ddpm_sd, B, L_, depth=2, by_batch=False, **kw):
+        """depth: batches in flight (= buffer sets).  by_batch False: two stage streams (prior | loop);
+        True: every batch runs start to end on its own stream, ``depth`` streams round-robin."""
+        self.device = torch.device(device)
+        self.depth, self.by_batch = depth, by_batch
+        self.pipes = [SamplerPipeline(device, prior_name, prior_sd, ddpm_sd, B, L_=L_, **kw) for _ in range(depth)]
+        self.s_prior = torch.cuda.Stream(self.device, priority=-1)   # tiny dependent launches: schedule them first
+        self.s_loop = torch.cuda.Stream(self.device)
+        self.s_batch = [torch.cuda.Stream(self.device) for _ in range(depth)] if by_batch else []
+        self.n = 0
+        self.done = [None] * depth      # event: batch in slot finished
+        self.nsteps = self.pipes[0].nsteps
+
+    def submit(self, wav, x_T):
+        slot = self.n % self.depth
+        p = self.pipes[slot]
+        if self.by_batch:
+            cur = torch.cuda.current_stream(self.device)
+            ready = torch.cuda.Event()
+            ready.record(cur)
+            st = self.s_batch[slot]
+            with torch.cuda.stream(st):
+                st.wait_event(ready)                              # same stream as the slot's previous batch: ordered
+                for src in (wav, x_T):                            # inputs were allocated on the caller's stream: tell
+                    if src.is_cuda:                               # the caching allocator this stream still reads them
+                        src.record_stream(st)
+                p.stft.wav.copy_(wav, non_blocking=True)
+                p.xT_in.copy_(x_T, non_blocking=True)
+                p.plan.run_range(0, len(p.descs), st.cuda_stream)
+                self.done[slot] = torch.cuda.Event()
+                self.done[slot].record(st)
+            self.n += 1
+            return slot
+        cur = torch.cuda.current_stream(self.device)
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        with torch.cuda.stream(self.s_prior):
+            self.s_prior.wait_event(ready)
+            if self.done[slot] is not None:
+                self.s_prior.wait_event(self.done[slot])      # the slot's buffers are free again
+            for src in (wav, x_T):
+                if src.is_cuda:
+                    src.record_stream(self.s_prior)
+            p.stft.wav.copy_(wav, non_blocking=True)
+            p.xT_in.copy_(x_T, non_blocking=True)
+            p.plan.run_range(p.ranges["stft"][0], p.ranges["prior"][1], self.s_prior.cuda_stream)
+            staged = torch.cuda.Event()
+            staged.record(self.s_prior)
+        with torch.cuda.stream(self.s_loop):
+            self.s_loop.wait_event(staged)
+            p.plan.run_range(p.ranges["prologue"][0], len(p.descs), self.s_loop.cuda_stream)
+            self.done[slot] = torch.cuda.Event()
+            self.done[slot].record(self.s_loop)
+        self.n += 1
+        return slot
+
+    def result(self, slot):
+        torch.cuda.current_stream(self.device).wait_event(self.done[slot])
+        p = self.pipes[slot]
+        return p.istft.wav, p.spec
+
+    def drain(self):
+        cur = torch.cuda.current_stream(self.device)
+        for e in self.done:
+            if e is not None:
+                cur.wait_event(e)

@@ -342,3 +342,27 @@ def test_sample_with_aia_prior(L, weights, R):
                                  params.noise_schedule, params.inference_noise_schedule, True, False)
     assert rel_l2(init.cpu(), ref_init) < 5e-5
     assert rel_l2(spec.cpu(), ref) < 1e-4
+
+
+def test_pipelined_batches_bit_identical(L, weights):
+    """Throughput mode: prior of batch n+1 beside the reverse loop of batch n on two streams;
+    each batch's result equals the plain sequential run bit for bit."""
+    P = pkg("pipeline")
+    B, L_ = 2, 3200
+    one = P.SamplerPipeline(DEV, "GCRN", weights("GCRN"), weights("DiffUNet1"), B, L_=L_)
+    batches = [pkg("synth").synthetic_waveforms(B, L_, seed=20 + i) for i in range(7)]
+    refs = [tuple(t.clone() for t in one.enhance(w.to(DEV), x.to(DEV))) for w, x in batches]
+    for kw in (dict(depth=2, by_batch=False), dict(depth=3, by_batch=True)):
+        pp = P.PipelinedSampler(DEV, "GCRN", weights("GCRN"), weights("DiffUNet1"), B, L_, **kw)
+        got, pending = [], []
+        for w, x in batches:
+            pending.append(pp.submit(w.to(DEV), x.to(DEV)))
+            if len(pending) == kw["depth"]:                # collect the oldest batch while the others are in flight
+                wv, sp = pp.result(pending.pop(0))
+                got.append((wv.clone(), sp.clone()))
+        while pending:
+            wv, sp = pp.result(pending.pop(0))
+            got.append((wv.clone(), sp.clone()))
+        _sync()
+        for (rw, rs), (gw, gs) in zip(refs, got):
+            assert torch.equal(rw, gw) and torch.equal(rs, gs)
