@@ -88,7 +88,7 @@ def main():
     use_graph = not args.no_graph
     if args.overlap:
         runner = pipeline.PipelinedSampler(dev, args.prior, gs, ds, B, L_, depth=args.depth, by_batch=args.by_batch,
-                                           fast_sampling=True)
+                                           graph=use_graph, fast_sampling=True)
         pipe = runner.pipes[0]
     elif args.streams > 1:
         runner = pipeline.ConcurrentSampler(dev, args.prior, gs, ds, B, L_=L_, nsplit=args.streams, fast_sampling=True)
@@ -202,7 +202,7 @@ def main():
         "config": {"workload": "B=%d x %.0f s 16 kHz utterances per GPU, [B,2,%d,161] spectrograms, %s prior + "
                                "DiffUNet1 6-step fast sampling, STFT..ISTFT, seeded random weights" % (B, args.seconds, T, args.prior),
                    "global_batch": B * world, "frames": T, "parallelism": "batch-shard x%d" % world,
-                   "graph": use_graph and not args.overlap, "streams_per_gpu": args.streams,
+                   "graph": use_graph and (not args.overlap or args.by_batch), "streams_per_gpu": args.streams,
                    "batches_in_flight": args.inflight},
         "roofline": roofline, "cpu_baseline": cpu,
     }

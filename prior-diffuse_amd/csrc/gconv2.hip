@@ -25,6 +25,9 @@
 
 #include "gconv_common.h"
 
+#ifndef PDSE_WAVES_PER_EU
+#define PDSE_WAVES_PER_EU 1   // experiment knob: minimum resident waves per SIMD the register allocator must allow
+#endif
 #ifndef PDSE_ABLATE
 #define PDSE_ABLATE 0   // diagnostic builds: 1 no activation loads, 2 no weight loads, 4 plain epilogue
 #endif
@@ -45,7 +48,7 @@ __device__ __forceinline__ float f4get(const float4& q, const int i) {
 // PP: ping-pong two register sets (layers with few waves per SIMD need the ILP); otherwise one
 //     set per chunk and the other resident waves hide the load latency.
 template <int EPI, int MT, int NT, int CP, bool SRC2, int XF, bool PP>
-__global__ __launch_bounds__(256) void gconv2_kernel(const pdse_gconv_desc d) {
+__global__ __launch_bounds__(256, PDSE_WAVES_PER_EU) void gconv2_kernel(const pdse_gconv_desc d) {
   constexpr bool DUAL = (EPI != PDSE_EPI_LINEAR);
   constexpr int N = NT * CP;
   static_assert(N % 4 == 0, "a chunk must hold whole 4-k-step weight groups");

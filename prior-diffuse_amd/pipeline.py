@@ -228,11 +228,11 @@ class PipelinedSampler:
     Per-batch results are bit-identical to ``SamplerPipeline.enhance``; only the schedule
     differs.  ``submit`` returns immediately; ``result`` waits for that batch."""
 
-    def __init__(self, device, prior_name, prior_sd, ddpm_sd, B, L_, depth=2, by_batch=False, **kw):
+    def __init__(self, device, prior_name, prior_sd, ddpm_sd, B, L_, depth=2, by_batch=False, graph=True, **kw):
         """depth: batches in flight (= buffer sets).  by_batch False: two stage streams (prior | loop);
         True: every batch runs start to end on its own stream, ``depth`` streams round-robin."""
         self.device = torch.device(device)
-        self.depth, self.by_batch = depth, by_batch
+        self.depth, self.by_batch, self.graph = depth, by_batch, graph
         self.pipes = [SamplerPipeline(device, prior_name, prior_sd, ddpm_sd, B, L_=L_, **kw) for _ in range(depth)]
         self.s_prior = torch.cuda.Stream(self.device, priority=-1)   # tiny dependent launches: schedule them first
         self.s_loop = torch.cuda.Stream(self.device)
@@ -256,7 +256,12 @@ class PipelinedSampler:
                         src.record_stream(st)
                 p.stft.wav.copy_(wav, non_blocking=True)
                 p.xT_in.copy_(x_T, non_blocking=True)
-                p.plan.run_range(0, len(p.descs), st.cuda_stream)
+                if self.graph:        # one hipGraph per in-flight buffer set: ~8000 launches become one host call
+                    if not p.plan.has_graph:
+                        p.plan.build_graph(st.cuda_stream)
+                    p.plan.launch_graph(st.cuda_stream)
+                else:
+                    p.plan.run_range(0, len(p.descs), st.cuda_stream)
                 self.done[slot] = torch.cuda.Event()
                 self.done[slot].record(st)
             self.n += 1
