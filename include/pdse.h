@@ -108,7 +108,15 @@ typedef struct pdse_gconv_desc {
   /* K order of the packed weights: 0: k = tap*Cin + ci (generic kernel); 1: k-step =
      (ci/2)*ntaps + tap, k = 2*kstep + (ci&1) (pipelined kernel: taps innermost, unrolled) */
   int32_t korder;
-  int32_t pad_;
+  /* Dual-phase stride-(1,2) ConvTranspose2d (BIGLU only, korder 1): one launch computes the even
+     output bins f_o = 2j (weights w0/w1 over all ntaps taps) AND the odd bins 2j+1 (weights w2/w3
+     over the taps selected by p1mask, ksteps1 k-steps), stores them side by side (out_sf = 2 bin
+     strides).  w2 == NULL: single phase.  Fout1 = number of valid odd bins (j < Fout1). */
+  int32_t ksteps1;
+  const float* w2;
+  const float* w3;
+  int32_t p1mask;
+  int32_t Fout1;
 } pdse_gconv_desc;
 
 /* Diffusion-step embedding + every per-stage time bias folded through the following 1x1

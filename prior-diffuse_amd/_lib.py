@@ -43,7 +43,7 @@ class GconvDesc(C.Structure):
         ("out_sb", _i64), ("out_sc_hi", _i64), ("out_sc_lo", _i64), ("out_st", _i64),
         ("out_sf", _i64), ("out_off", _i64),
         ("out_cr", _i32), ("B", _i32), ("Tout", _i32), ("Fout", _i32),
-        ("korder", _i32), ("pad_", _i32),
+        ("korder", _i32), ("ksteps1", _i32), ("w2", _fp), ("w3", _fp), ("p1mask", _i32), ("Fout1", _i32),
     ]
 
 

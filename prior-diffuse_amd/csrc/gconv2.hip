@@ -32,11 +32,16 @@
 #define PDSE_ABLATE 0   // diagnostic builds: 1 no activation loads, 2 no weight loads, 4 plain epilogue
 #endif
 
-template <int N, int CP, int MT>
+constexpr int popc(int m) { return m ? (m & 1) + popc(m >> 1) : 0; }
+constexpr int rank_of(int m, int tap) { return popc(m & ((1 << tap) - 1)); }   // index of `tap` among the set bits
+
+template <int N, int CP, int MT, int N1>
 struct Chunk {
   float v[N];           // raw activation per k-step (lane = position, half = channel parity)
   float4 a0[N / 4][MT];  // A fragments: one 16-byte load covers 4 consecutive k-steps
   float4 a1[N / 4][MT];
+  float4 a2[N1 > 0 ? N1 / 4 : 1];   // odd-bin phase of a dual-phase transposed conv (MT == 1)
+  float4 a3[N1 > 0 ? N1 / 4 : 1];
   float xs0[CP], xh0[CP], xs1[CP], xh1[CP];  // load-transform parameters (TCM only, XF != 0)
 };
 
@@ -47,11 +52,14 @@ __device__ __forceinline__ float f4get(const float4& q, const int i) {
 // XF: 0 no load transform; 1 one PReLU->BN set for both accumulators; 2 one set per accumulator
 // PP: ping-pong two register sets (layers with few waves per SIMD need the ILP); otherwise one
 //     set per chunk and the other resident waves hide the load latency.
-template <int EPI, int MT, int NT, int CP, bool SRC2, int XF, bool PP>
+// P1MASK != 0: dual-phase transposed conv — taps in the mask also feed the odd output bins.
+template <int EPI, int MT, int NT, int CP, bool SRC2, int XF, bool PP, int P1MASK = 0>
 __global__ __launch_bounds__(256, PDSE_WAVES_PER_EU) void gconv2_kernel(const pdse_gconv_desc d) {
   constexpr bool DUAL = (EPI != PDSE_EPI_LINEAR);
   constexpr int N = NT * CP;
-  static_assert(N % 4 == 0, "a chunk must hold whole 4-k-step weight groups");
+  constexpr int NT1 = popc(P1MASK), N1 = NT1 * CP;
+  static_assert(N % 4 == 0 && N1 % 4 == 0, "a chunk must hold whole 4-k-step weight groups");
+  static_assert(P1MASK == 0 || (EPI == PDSE_EPI_BIGLU && MT == 1), "dual phase is a BIGLU feature");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = lane & 31, h = lane >> 5;
   const int b = blockIdx.y;
@@ -90,6 +98,7 @@ __global__ __launch_bounds__(256, PDSE_WAVES_PER_EU) void gconv2_kernel(const pd
   }
 
   f32x16 acc0[MT], acc1[DUAL ? MT : 1];
+  f32x16 acc2[1], acc3[1];   // odd-bin phase
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
 #pragma unroll
@@ -98,6 +107,8 @@ __global__ __launch_bounds__(256, PDSE_WAVES_PER_EU) void gconv2_kernel(const pd
       if (DUAL) acc1[m][r] = 0.f;
     }
   }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc2[0][r] = acc3[0][r] = 0.f;
 
   // ---- per-tap gather state, computed once
   int off0[NT], off1[SRC2 ? NT : 1];
@@ -115,6 +126,8 @@ __global__ __launch_bounds__(256, PDSE_WAVES_PER_EU) void gconv2_kernel(const pd
   const int kgroups = d.ksteps >> 2;   // host pads ksteps to a multiple of 4
   const float4* wq0 = reinterpret_cast<const float4*>(d.w0) + (size_t)mt0 * kgroups * 64 + lane;
   const float4* wq1 = DUAL ? reinterpret_cast<const float4*>(d.w1) + (size_t)mt0 * kgroups * 64 + lane : nullptr;
+  const float4* wq2 = P1MASK ? reinterpret_cast<const float4*>(d.w2) + lane : nullptr;
+  const float4* wq3 = P1MASK ? reinterpret_cast<const float4*>(d.w3) + lane : nullptr;
   const int cps0 = d.in0.C >> 1;
   const int cps1 = SRC2 ? (d.in1.C >> 1) : 0;
   const int nch0 = (cps0 + CP - 1) / CP, nch1 = (cps1 + CP - 1) / CP;
@@ -124,7 +137,7 @@ __global__ __launch_bounds__(256, PDSE_WAVES_PER_EU) void gconv2_kernel(const pd
 
   // Straight-line code: every load is unconditional from a clamped (always readable) address
   // and masked afterwards, so the whole chunk is one scheduling region of independent loads.
-  auto issue = [&](Chunk<N, CP, MT>& c, const int q) {
+  auto issue = [&](Chunk<N, CP, MT, N1>& c, const int q) {
     const bool s1 = SRC2 && q >= nch0;
     const int cp0 = (s1 ? q - nch0 : q) * CP;
     const int cps = s1 ? cps1 : cps0;
@@ -143,6 +156,13 @@ __global__ __launch_bounds__(256, PDSE_WAVES_PER_EU) void gconv2_kernel(const pd
         c.a0[g4][m] = wq0[((size_t)mc * kgroups + (size_t)q * (N / 4) + g4) * 64];
         if (DUAL) c.a1[g4][m] = wq1[((size_t)mc * kgroups + (size_t)q * (N / 4) + g4) * 64];
 #endif
+      }
+    }
+    if constexpr (P1MASK != 0) {
+#pragma unroll
+      for (int g4 = 0; g4 < N1 / 4; ++g4) {
+        c.a2[g4] = wq2[((size_t)q * (N1 / 4) + g4) * 64];
+        c.a3[g4] = wq3[((size_t)q * (N1 / 4) + g4) * 64];
       }
     }
 #pragma unroll
@@ -173,7 +193,7 @@ __global__ __launch_bounds__(256, PDSE_WAVES_PER_EU) void gconv2_kernel(const pd
     __builtin_amdgcn_sched_barrier(0);  // keep the chunk's loads together, ahead of the MFMAs
   };
 
-  auto consume = [&](Chunk<N, CP, MT>& c, const int q) {
+  auto consume = [&](Chunk<N, CP, MT, N1>& c, const int q) {
     // ELU on load exists only for the GCRN decoder's skip source (gcrn.py:152-155)
     bool elu_src = false;
     if constexpr (SRC2 && EPI == PDSE_EPI_GLU) elu_src = (q >= nch0) ? d.in1.act == PDSE_ACT_ELU : d.in0.act == PDSE_ACT_ELU;
@@ -204,13 +224,20 @@ __global__ __launch_bounds__(256, PDSE_WAVES_PER_EU) void gconv2_kernel(const pd
           acc0[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4get(c.a0[i >> 2][m], i & 3), v0, acc0[m], 0, 0, 0);
           if (DUAL) acc1[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4get(c.a1[i >> 2][m], i & 3), v1, acc1[m], 0, 0, 0);
         }
+        if constexpr (P1MASK != 0) {
+          if ((P1MASK >> tap) & 1) {   // folds after unrolling
+            const int i1 = cc * NT1 + rank_of(P1MASK, tap);
+            acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4get(c.a2[i1 >> 2], i1 & 3), v0, acc2[0], 0, 0, 0);
+            acc3[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4get(c.a3[i1 >> 2], i1 & 3), v0, acc3[0], 0, 0, 0);
+          }
+        }
       }
     }
   };
 
   if constexpr (PP) {
     // ping-pong over the chunks: loads of q+1 are in flight while q is multiplied
-    Chunk<N, CP, MT> ca, cb;
+    Chunk<N, CP, MT, N1> ca, cb;
     issue(ca, 0);
     int q = 0;
     for (; q + 1 < nchunks; q += 2) {
@@ -221,7 +248,7 @@ __global__ __launch_bounds__(256, PDSE_WAVES_PER_EU) void gconv2_kernel(const pd
     }
     if (q < nchunks) consume(ca, q);
   } else {
-    Chunk<N, CP, MT> ca;
+    Chunk<N, CP, MT, N1> ca;
     for (int q = 0; q < nchunks; ++q) {
       issue(ca, q);
       consume(ca, q);
@@ -237,6 +264,8 @@ __global__ __launch_bounds__(256, PDSE_WAVES_PER_EU) void gconv2_kernel(const pd
     const pdse_tail tl{sw, sw + 1024, sw + 2048, sw + 4096, sw + 4128, sw + 4160, sw + 4192, sw + 4224,
                        d.post_scale ? sw + 4288 : nullptr, sw + 4352};
     gconv_epilogue<EPI, MT>(d, tl, acc0, acc1, b, t, j, pvalid, lane, h, mt0, mtiles);
+    if constexpr (P1MASK != 0)   // odd bins: one bin stride further (out_sf spans two bins)
+      gconv_epilogue<EPI, MT>(d, tl, acc2, acc3, b, t, j, pvalid && j < d.Fout1, lane, h, mt0, mtiles, d.out_sf >> 1);
   } else {
     gconv_epilogue<EPI, MT>(d, tail_from_desc(d), acc0, acc1, b, t, j, pvalid, lane, h, mt0, mtiles);
   }
@@ -313,6 +342,22 @@ int pdse_gconv2_launch(const pdse_gconv_desc* d, hipStream_t s) {
     if (nt == 2 && two && xf == 0) GO(PDSE_EPI_GLU, 2, 2, true, 0, true, true, true);
     if (nt == 3 && !two && xf == 0) GO(PDSE_EPI_GLU, 3, 4, false, 0, true, false, false);
     if (nt == 5 && !two && xf == 2) GO(PDSE_EPI_GLU, 5, 4, false, 2, true, false, false);
+  } else if (d->epi == PDSE_EPI_BIGLU && !two && xf == 0 && d->C2 <= 64 && d->w2 != nullptr) {
+    // dual-phase transposed conv: kernel (2,3) -> 4 union taps, odd bins use taps {0,2};
+    //                             kernel (2,5) -> 6 union taps, odd bins use taps {0,1,3,4}
+    const dim3 block(256), grid(gx, d->B, 1);
+    if (d->w3 == nullptr || (d->out_sf & 1) || (d->ksteps1 & 3)) {
+      pdse_set_error("gconv2: dual phase needs w2 and w3, an even out_sf and ksteps1 % 4 == 0");
+      return 1;
+    }
+    if (nt == 4 && d->p1mask == 5) {
+      hipLaunchKernelGGL((gconv2_kernel<PDSE_EPI_BIGLU, 1, 4, 2, false, 0, true, 5>), grid, block, 0, s, *d);
+      return pdse_check_launch("gconv2");
+    }
+    if (nt == 6 && d->p1mask == 27) {
+      hipLaunchKernelGGL((gconv2_kernel<PDSE_EPI_BIGLU, 1, 6, 2, false, 0, false, 27>), grid, block, 0, s, *d);
+      return pdse_check_launch("gconv2");
+    }
   } else if (d->epi == PDSE_EPI_BIGLU && !two && xf == 0 && d->C2 <= 64) {   // tail image in LDS holds C2 <= 64
     if (nt == 2) GO(PDSE_EPI_BIGLU, 2, 4, false, 0, true, true, true);
     if (nt == 4) GO(PDSE_EPI_BIGLU, 4, 2, false, 0, true, true, true);

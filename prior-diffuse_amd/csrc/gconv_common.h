@@ -61,8 +61,9 @@ template <int EPI, int MT, bool CR1>
 __device__ __forceinline__ void gconv_epilogue_impl(const pdse_gconv_desc& d, const pdse_tail& tl, f32x16* acc0,
                                                     f32x16* acc1, const int b, const int t, const int j,
                                                     const bool pvalid, const int lane, const int h, const int mt0,
-                                                    const int mtiles) {
-  float* const obase = d.out + ((int64_t)b * d.out_sb + (int64_t)t * d.out_st + (int64_t)j * d.out_sf + d.out_off);
+                                                    const int mtiles, const int64_t extra_off) {
+  float* const obase =
+      d.out + ((int64_t)b * d.out_sb + (int64_t)t * d.out_st + (int64_t)j * d.out_sf + d.out_off + extra_off);
   const int64_t cstep = d.out_sc_hi;
   auto chan_off = [&](const int co) -> int64_t {
     if constexpr (CR1) return (int64_t)co * cstep;
@@ -172,10 +173,10 @@ template <int EPI, int MT>
 __device__ __forceinline__ void gconv_epilogue(const pdse_gconv_desc& d, const pdse_tail& tl, f32x16* acc0,
                                                f32x16* acc1, const int b, const int t, const int j,
                                                const bool pvalid, const int lane, const int h, const int mt0,
-                                               const int mtiles) {
+                                               const int mtiles, const int64_t extra_off = 0) {
   if (d.out_cr == 1)
-    gconv_epilogue_impl<EPI, MT, true>(d, tl, acc0, acc1, b, t, j, pvalid, lane, h, mt0, mtiles);
+    gconv_epilogue_impl<EPI, MT, true>(d, tl, acc0, acc1, b, t, j, pvalid, lane, h, mt0, mtiles, extra_off);
   else
-    gconv_epilogue_impl<EPI, MT, false>(d, tl, acc0, acc1, b, t, j, pvalid, lane, h, mt0, mtiles);
+    gconv_epilogue_impl<EPI, MT, false>(d, tl, acc0, acc1, b, t, j, pvalid, lane, h, mt0, mtiles, extra_off);
 }
 #endif

@@ -71,8 +71,9 @@ class PlanBase:
     def gconv(self, *, in0, in1=None, Tin, Fin, taps, sf_in, wk0, wk1=None, Cout, bias0=None, bias0_sb=0,
               bias1=None, bias1_sb=0, epi=L.EPI_LINEAR, act=L.ACT_NONE, act_slope=0.0, post=None,
               padrow=None, padrow_sb=0, padrow_off=0, xf=None, cin1=False, chain=None, resid=None, out,
-              out_strides, out_off=0, out_cr=1, B, Tout, Fout, tag=TAG_NONE, bias0_off=0):
-        """wk0/wk1: [K, Cout] float64 k-major matrices (packed here); biases/post: numpy or device tensors."""
+              out_strides, out_off=0, out_cr=1, B, Tout, Fout, tag=TAG_NONE, bias0_off=0, phase1=None):
+        """wk0/wk1: [K, Cout] float64 k-major matrices (packed here); biases/post: numpy or device tensors.
+        phase1 (dual-phase transposed conv, BIGLU): dict(wk2, wk3, mask, ntaps1, Fout1)."""
         ctx = self.ctx
         d = L.GconvDesc()
         d.in0 = in0
@@ -98,6 +99,11 @@ class PlanBase:
             if wk1 is not None:
                 d.w1 = ctx.up(P.pack_a4(wk1, rows)).data_ptr()
             d.korder = 1
+            if phase1 is not None:
+                rows1 = P.korder1_rows(phase1["ntaps1"], d.in0.C, 0, P.V2_CP[key])
+                d.w2 = ctx.up(P.pack_a4(phase1["wk2"], rows1)).data_ptr()
+                d.w3 = ctx.up(P.pack_a4(phase1["wk3"], rows1)).data_ptr()
+                d.ksteps1, d.p1mask, d.Fout1 = len(rows1) // 2, phase1["mask"], phase1["Fout1"]
         else:
             w0 = P.pack_a(wk0)
             d.w0, d.ksteps, d.Cout = ctx.up(w0).data_ptr(), w0.shape[1], Cout
@@ -298,17 +304,28 @@ class EpsNetPlan(PlanBase):
         chain = dict(C2=C2, wlc=self.w(p + ".l_conv.weight")[:, :, 0, 0].T, blc=self.w(p + ".l_conv.bias"),
                      wrc=self.w(p + ".r_conv.weight")[:, :, 0, 0].T, brc=self.w(p + ".r_conv.bias"),
                      wc2=wc2, bc2=self.w(p + ".conv2.bias"))
-        for phase in (0, 1):
-            kk, taps = P.convT_phase_taps(2, kw, phase)
-            Fo = (Fout - phase + 1) // 2
-            osb, osc, _, ost, osf = out_strides_fn(Fout)
-            self.gconv(in0=self.src(self.H, 32, *nchw(32, T, Fin)), Tin=T, Fin=Fin, taps=taps, sf_in=1,
-                       wk0=P.convT_kmat(self.sd[p + ".l.weight"], kk), wk1=P.convT_kmat(self.sd[p + ".r.weight"], kk),
-                       Cout=32, bias0=self.w(p + ".l.bias"), bias1=self.w(p + ".r.bias"), epi=L.EPI_BIGLU,
-                       act=L.ACT_PRELU if prelu_key else L.ACT_NONE,
-                       act_slope=float(self.w(prelu_key)[0]) if prelu_key else 0.0, post=post, chain=chain,
-                       out=out_t, out_strides=(osb, osc, 0, ost, 2 * osf), out_off=phase * osf + self._out_off,
-                       B=B, Tout=T, Fout=Fo, tag=TAG_EPS_BLOCK)
+        osb, osc, _, ost, osf = out_strides_fn(Fout)
+        common = dict(Cout=32, bias0=self.w(p + ".l.bias"), bias1=self.w(p + ".r.bias"), epi=L.EPI_BIGLU,
+                      act=L.ACT_PRELU if prelu_key else L.ACT_NONE,
+                      act_slope=float(self.w(prelu_key)[0]) if prelu_key else 0.0, post=post, chain=chain, out=out_t,
+                      out_strides=(osb, osc, 0, ost, 2 * osf), B=B, Tout=T, tag=TAG_EPS_BLOCK)
+        src_h = self.src(self.H, 32, *nchw(32, T, Fin))
+        kk0, taps0 = P.convT_phase_taps(2, kw, 0)
+        kk1, taps1 = P.convT_phase_taps(2, kw, 1)
+        if not self.force_generic:
+            # both output phases in one launch: the odd bins read a subset of the even bins' taps, so the
+            # activation loads are shared and every wave stores neighbouring (2j, 2j+1) bins together
+            mask = sum(1 << taps0.index(tp) for tp in taps1)
+            ph1 = dict(wk2=P.convT_kmat(self.sd[p + ".l.weight"], kk1), wk3=P.convT_kmat(self.sd[p + ".r.weight"], kk1),
+                       mask=mask, ntaps1=len(taps1), Fout1=Fout // 2)
+            self.gconv(in0=src_h, Tin=T, Fin=Fin, taps=taps0, sf_in=1, wk0=P.convT_kmat(self.sd[p + ".l.weight"], kk0),
+                       wk1=P.convT_kmat(self.sd[p + ".r.weight"], kk0), out_off=self._out_off, Fout=(Fout + 1) // 2,
+                       phase1=ph1, **common)
+        else:
+            for phase, (kk, taps) in enumerate(((kk0, taps0), (kk1, taps1))):
+                self.gconv(in0=src_h, Tin=T, Fin=Fin, taps=taps, sf_in=1, wk0=P.convT_kmat(self.sd[p + ".l.weight"], kk),
+                           wk1=P.convT_kmat(self.sd[p + ".r.weight"], kk), out_off=phase * osf + self._out_off,
+                           Fout=(Fout - phase + 1) // 2, **common)
         return Fout
 
     def _residual(self, p, dil, xin, xout):

@@ -94,6 +94,18 @@ def run_gconv(d, mem):
             return _unpack_a(mem.arr(ptr, mtiles * d.ksteps * 64), mtiles, d.ksteps)
     W0 = unpack(d.w0)
     W1 = unpack(d.w1) if dual else None
+    ph1 = None
+    if d.w2:    # dual-phase transposed conv: odd output bins from the taps in p1mask
+        sel = [i for i in range(d.ntaps) if (d.p1mask >> i) & 1]
+        rows1 = P.korder1_rows(len(sel), d.in0.C, 0, P.V2_CP[(d.epi, d.ntaps, False, d.xf_mode)])
+        assert len(rows1) == 2 * d.ksteps1
+
+        def unpack1(ptr):
+            wk = P.unpack_a4(mem.arr(ptr, d.ksteps1 * 64), 1, d.ksteps1)
+            out = np.zeros((len(sel) * Cin, 32), np.float32)
+            out[rows1[rows1 >= 0]] = wk[rows1 >= 0]
+            return out
+        ph1 = (sel, unpack1(d.w2), unpack1(d.w3), np.zeros((B, 32, To, Fo), np.float32), np.zeros((B, 32, To, Fo), np.float32))
     bI = np.arange(B)[:, None, None, None]
     tI = np.arange(To)[None, None, :, None]
     jI = np.arange(Fo)[None, None, None, :]
@@ -135,6 +147,10 @@ def run_gconv(d, mem):
                 k0 = ti
             else:
                 k0 = ti * Cin + cbase
+            if ph1 is not None and ti in ph1[0]:
+                k1 = ph1[0].index(ti) * Cin + cbase
+                ph1[3][...] += np.einsum("km,bktf->bmtf", ph1[1][k1:k1 + S.C], v0.astype(np.float32), optimize=True)
+                ph1[4][...] += np.einsum("km,bktf->bmtf", ph1[2][k1:k1 + S.C], v0.astype(np.float32), optimize=True)
             acc0 += np.einsum("km,bktf->bmtf", W0[k0:k0 + S.C], v0.astype(np.float32), optimize=True)
             if dual:
                 acc1 += np.einsum("km,bktf->bmtf", W1[k0:k0 + S.C], v1.astype(np.float32), optimize=True)
@@ -168,20 +184,30 @@ def run_gconv(d, mem):
             y = y * _sig(acc1[:, :d.Cout] + bias(d.bias1, d.bias1_sb, d.Cout))
         store(post(y, d.Cout), d.Cout)
     else:
-        Lh = acc0[:, :32] + mem.arr(d.bias0, 32)[None, :, None, None]
-        Rh = acc1[:, :32] + mem.arr(d.bias1, 32)[None, :, None, None]
-        Wlc = _unpack_chain(mem.arr(d.wlc, 16 * 64), 1)
-        Wrc = _unpack_chain(mem.arr(d.wrc, 16 * 64), 1)
-        mL = _sig(np.einsum("oc,bctf->botf", Wlc, Lh) + mem.arr(d.blc, 32)[None, :, None, None])
-        mR = _sig(np.einsum("oc,bctf->botf", Wrc, Rh) + mem.arr(d.brc, 32)[None, :, None, None])
-        G = Lh * mR + Rh * mL
-        if d.C2 == 1:
-            y = np.einsum("c,bctf->btf", mem.arr(d.wc2, 32), G)[:, None] + mem.arr(d.bc2, 1)[0]
-        else:
-            t2 = (d.C2 + 31) // 32
-            Wc2 = _unpack_chain(mem.arr(d.wc2, t2 * 16 * 64), t2)[:d.C2]
-            y = np.einsum("oc,bctf->botf", Wc2, G) + mem.arr(d.bc2, d.C2)[None, :, None, None]
-        store(post(y.astype(np.float32), d.C2), d.C2)
+        def tail(aL, aR, extra, jmax):
+            Lh = aL[:, :32] + mem.arr(d.bias0, 32)[None, :, None, None]
+            Rh = aR[:, :32] + mem.arr(d.bias1, 32)[None, :, None, None]
+            Wlc = _unpack_chain(mem.arr(d.wlc, 16 * 64), 1)
+            Wrc = _unpack_chain(mem.arr(d.wrc, 16 * 64), 1)
+            mL = _sig(np.einsum("oc,bctf->botf", Wlc, Lh) + mem.arr(d.blc, 32)[None, :, None, None])
+            mR = _sig(np.einsum("oc,bctf->botf", Wrc, Rh) + mem.arr(d.brc, 32)[None, :, None, None])
+            G = Lh * mR + Rh * mL
+            if d.C2 == 1:
+                y = np.einsum("c,bctf->btf", mem.arr(d.wc2, 32), G)[:, None] + mem.arr(d.bc2, 1)[0]
+            else:
+                t2 = (d.C2 + 31) // 32
+                Wc2 = _unpack_chain(mem.arr(d.wc2, t2 * 16 * 64), t2)[:d.C2]
+                y = np.einsum("oc,bctf->botf", Wc2, G) + mem.arr(d.bc2, d.C2)[None, :, None, None]
+            y = post(y.astype(np.float32), d.C2)
+            co = np.arange(d.C2)[None, :, None, None]
+            idx = (out_off + bI * d.out_sb + (co // d.out_cr) * d.out_sc_hi + (co % d.out_cr) * d.out_sc_lo
+                   + tI * d.out_st + jI * d.out_sf + d.out_off + extra)
+            idx = np.broadcast_to(idx, y.shape)
+            out_flat[idx[..., :jmax]] = y[..., :jmax]
+
+        tail(acc0, acc1, 0, Fo)
+        if ph1 is not None:
+            tail(ph1[3], ph1[4], d.out_sf // 2, d.Fout1)
 
 
 def run_time(d, mem):
