@@ -9,6 +9,7 @@ Tolerances (fp32 both sides; only summation order differs: MFMA fmaf chains vs o
   reverse-step arithmetic       bit-exact
 """
 import importlib
+import os
 
 import numpy as np
 import pytest
@@ -366,3 +367,37 @@ def test_pipelined_batches_bit_identical(L, weights):
         _sync()
         for (rw, rs), (gw, gs) in zip(refs, got):
             assert torch.equal(rw, gw) and torch.equal(rs, gs)
+
+
+def test_checkpoint_rules_and_cli_surface(L, weights, tmp_path, monkeypatch):
+    """A8: best_checkpoint.pth is the reference's 4-element list (complex_ddpm_trainer.py:616-622);
+    element 0 -> prior, element 2 -> DiffUNet1 only with --joint/--draw (:91-97).  The CLI mirror
+    takes the reference's flags (main.py:23-36) and derives the same directories (:38-40)."""
+    import argparse
+
+    ck = tmp_path / "assets" / "checkpoint" / "gcrn"
+    ck.mkdir(parents=True)
+    torch.save([weights("GCRN"), {"optim": 1}, weights("DiffUNet1"), {"optim": 2}], str(ck / "best_checkpoint.pth"))
+    (tmp_path / "conf").mkdir()
+    (tmp_path / "conf" / "gcrn.yml").write_text(
+        "train:\n  batch_size: 8\n  win_size: 320\n  fft_num: 320\n  win_shift: 160\n  feat_type: \"sqrt\"\n"
+        "model:\n  name: 'GCRN'\n")
+    monkeypatch.chdir(tmp_path)
+    main = pkg("main")
+    args, config = main.parse_args_and_config(["--retrain", "--joint", "--generate", "--assets", "assets", "--doc", "gcrn",
+                                               "--config", "gcrn.yml", "--sigma"])
+    assert args.checkpoint == os.path.join("assets", "checkpoint", "gcrn")
+    assert args.generated_wav == os.path.join("assets", "wav", "gcrn") and os.path.isdir(args.generated_wav)
+    assert config.model.name == "GCRN" and args.sigma and args.seed == 1234
+    tr = pkg("trainer")
+    t = tr.ComplexDDPMTrainer(args, config, device=DEV)
+    assert set(t.prior_sd) == set(weights("GCRN")) and set(t.ddpm_sd) == set(weights("DiffUNet1"))
+    wav = 0.1 * seeded((2, 2400), 4)
+    out = t.enhance(wav)                       # --sigma path, x_T drawn on the device
+    assert out.shape == wav.shape and torch.isfinite(out).all()
+    # without --joint/--draw the DiffUNet1 weights are NOT taken from the file (reference rule)
+    args2 = argparse.Namespace(**{**vars(args), "joint": False, "draw": False})
+    with pytest.raises(ValueError, match="no weights"):
+        tr.ComplexDDPMTrainer(args2, config, device=DEV)
+    with pytest.raises(ValueError, match="level"):
+        main.parse_args_and_config(["--verbose", "loud", "--config", "gcrn.yml"])
