@@ -112,11 +112,14 @@ int pdse_chln_launch(const pdse_chln_desc* d, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------
-// Attention core: one workgroup per (line, b); K and V of the line live in LDS, each thread
-// owns (query position, head) pairs and runs an online softmax over the keys.
+// Attention core: one workgroup per (line, b); K and V of the line live in LDS (16-byte aligned
+// rows), each thread owns (query position, head) pairs and runs an online softmax over the keys.
 // E = 32, 4 heads of 8 (dbaiat.py:123-126); sequence 80 (bins) or T (frames).
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_kernel(const pdse_attn_desc d) {
+// 1024 threads (4 waves per SIMD hide the LDS latency of the serial key loop); keys are taken
+// four at a time so the running maximum is rescaled once per block instead of once per key.
+#define ATTN_THREADS 1024
+__global__ __launch_bounds__(ATTN_THREADS) void attn_kernel(const pdse_attn_desc d) {
   extern __shared__ float kv[];  // [S][E] keys, then [S][E] values
   const int E = d.E, HD = 8;
   const int b = blockIdx.y, line = blockIdx.x;
@@ -126,14 +129,14 @@ __global__ __launch_bounds__(256) void attn_kernel(const pdse_attn_desc d) {
   const int64_t ss = d.axis == 0 ? 1 : d.F;
   float* ks = kv;
   float* vs = kv + (size_t)S * E;
-  for (int i = threadIdx.x; i < S * E; i += 256) {
+  for (int i = threadIdx.x; i < S * E; i += ATTN_THREADS) {
     const int e = i / S, sp = i - e * S;  // consecutive threads -> consecutive sequence positions
     ks[sp * E + e] = d.qkv[base + (int64_t)(E + e) * plane + (int64_t)sp * ss];
     vs[sp * E + e] = d.qkv[base + (int64_t)(2 * E + e) * plane + (int64_t)sp * ss];
   }
   __syncthreads();
   const int64_t obase = (int64_t)b * E * plane + (d.axis == 0 ? (int64_t)line * d.F : (int64_t)line);
-  for (int idx = threadIdx.x; idx < S * d.heads; idx += 256) {
+  for (int idx = threadIdx.x; idx < S * d.heads; idx += ATTN_THREADS) {
     const int hd = idx / S, sq = idx - hd * S;
     float q[HD], acc[HD];
 #pragma unroll
@@ -142,14 +145,41 @@ __global__ __launch_bounds__(256) void attn_kernel(const pdse_attn_desc d) {
       acc[e] = 0.f;
     }
     float m = -1e30f, l = 0.f;
-    for (int sp = 0; sp < S; ++sp) {
-      const float* kr = ks + sp * E + hd * HD;
-      float sc = 0.f;
+    const float* kh = ks + hd * HD;
+    const float* vh = vs + hd * HD;
+    int sp = 0;
+    for (; sp + 4 <= S; sp += 4) {
+      float sc[4];
 #pragma unroll
-      for (int e = 0; e < HD; ++e) sc += q[e] * kr[e];
-      const float mn = fmaxf(m, sc);
-      const float corr = aia_exp(m - mn), pw = aia_exp(sc - mn);
-      const float* vr = vs + sp * E + hd * HD;
+      for (int u = 0; u < 4; ++u) {
+        const float4 k0 = *reinterpret_cast<const float4*>(kh + (sp + u) * E);
+        const float4 k1 = *reinterpret_cast<const float4*>(kh + (sp + u) * E + 4);
+        sc[u] = q[0] * k0.x + q[1] * k0.y + q[2] * k0.z + q[3] * k0.w + q[4] * k1.x + q[5] * k1.y + q[6] * k1.z + q[7] * k1.w;
+      }
+      const float mn = fmaxf(fmaxf(m, fmaxf(sc[0], sc[1])), fmaxf(sc[2], sc[3]));
+      const float corr = aia_exp(m - mn);
+      l *= corr;
+#pragma unroll
+      for (int e = 0; e < HD; ++e) acc[e] *= corr;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float pw = aia_exp(sc[u] - mn);
+        const float4 v0 = *reinterpret_cast<const float4*>(vh + (sp + u) * E);
+        const float4 v1 = *reinterpret_cast<const float4*>(vh + (sp + u) * E + 4);
+        l += pw;
+        acc[0] += pw * v0.x; acc[1] += pw * v0.y; acc[2] += pw * v0.z; acc[3] += pw * v0.w;
+        acc[4] += pw * v1.x; acc[5] += pw * v1.y; acc[6] += pw * v1.z; acc[7] += pw * v1.w;
+      }
+      m = mn;
+    }
+    for (; sp < S; ++sp) {
+      const float* kr = kh + sp * E;
+      float s1 = 0.f;
+#pragma unroll
+      for (int e = 0; e < HD; ++e) s1 += q[e] * kr[e];
+      const float mn = fmaxf(m, s1);
+      const float corr = aia_exp(m - mn), pw = aia_exp(s1 - mn);
+      const float* vr = vh + sp * E;
       l = l * corr + pw;
 #pragma unroll
       for (int e = 0; e < HD; ++e) acc[e] = acc[e] * corr + pw * vr[e];
@@ -172,7 +202,7 @@ int pdse_attn_launch(const pdse_attn_desc* d, hipStream_t s) {
     if (pdse_check_hip(hipFuncSetAttribute((const void*)attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                        "attention lds attribute"))
       return 1;
-  hipLaunchKernelGGL(attn_kernel, dim3(lines, d->B), dim3(256), lds, s, *d);
+  hipLaunchKernelGGL(attn_kernel, dim3(lines, d->B), dim3(ATTN_THREADS), lds, s, *d);
   return pdse_check_launch("attention");
 }
 

@@ -676,12 +676,28 @@ class AiaPlan(PlanBase):
         self.add(d, TAG_PRIOR)
 
     def _pw(self, src_t, Cin, wk, bias, out_t, Cout, F_, resid=None, act=L.ACT_NONE, act_slope=0.0, xf=None,
-            in_act=L.ACT_NONE):
-        """1x1 convolution / Linear over the channel axis of [B,Cin,T,F_]."""
-        T = self.T
-        self.gconv(in0=self.src(src_t, Cin, *nchw(Cin, T, F_), act=in_act), Tin=T, Fin=F_, taps=[(0, 0)], sf_in=1,
+            in_layout="tf", out_layout="tf"):
+        """1x1 convolution / Linear over the channel axis of [B,Cin,T,F_].
+
+        Layouts: "tf" = [B,C,T,F] (bins innermost, the model's own), "ft" = [B,C,F,T] (frames
+        innermost).  The row GRU and the column attention walk the axis that is strided in "tf";
+        their operands are produced in "ft" so that the 32 lines of a workgroup sit next to each
+        other in memory at every step.  A launch whose two sides differ iterates its lanes along t
+        (coalesced on the "ft" side — the wide tensors — and scattered on the 32-channel "tf" side)."""
+        T, B = self.T, self.B
+        plane = T * F_
+        if in_layout == "tf" and out_layout == "tf":
+            self.gconv(in0=self.src(src_t, Cin, *nchw(Cin, T, F_)), Tin=T, Fin=F_, taps=[(0, 0)], sf_in=1,
+                       wk0=wk, Cout=Cout, bias0=bias, act=act, act_slope=act_slope, xf=xf, resid=resid, out=out_t,
+                       out_strides=nchw_out(Cout, T, F_), B=B, Tout=T, Fout=F_, tag=TAG_PRIOR)
+            return
+        # lanes along t: the kernel's "frame" index is the bin f, its "bin" index is the frame t
+        i_st, i_sf = (1, F_) if in_layout == "tf" else (T, 1)
+        o_st, o_sf = (1, F_) if out_layout == "tf" else (T, 1)
+        assert resid is None or out_layout == "tf"
+        self.gconv(in0=self.src(src_t, Cin, Cin * plane, plane, i_st, i_sf), Tin=F_, Fin=T, taps=[(0, 0)], sf_in=1,
                    wk0=wk, Cout=Cout, bias0=bias, act=act, act_slope=act_slope, xf=xf, resid=resid, out=out_t,
-                   out_strides=nchw_out(Cout, T, F_), B=self.B, Tout=T, Fout=F_, tag=TAG_PRIOR)
+                   out_strides=(Cout * plane, plane, 0, o_st, o_sf), B=B, Tout=F_, Fout=T, tag=TAG_PRIOR)
 
     def _dense_block(self, p, D, F_, tmp):
         """dbaiat.py:605-631.  D [B,320,T,F_] holds [out4,out3,out2,out1,x]; x is already in block 4."""
@@ -701,34 +717,43 @@ class AiaPlan(PlanBase):
         return 0  # out4 sits in channel block 0
 
     def _encoder_layer(self, p, axis, src_t, dst_t):
-        """TransformerEncoderLayer (dbaiat.py:66-88) along bins (axis 0) or frames (axis 1)."""
+        """TransformerEncoderLayer (dbaiat.py:66-88) along bins (axis 0) or frames (axis 1).
+
+        Attention over frames and the GRU over bins run on "ft" operands with the kernels'
+        coalesced code path (attention axis 0 / GRU axis 1 on the swapped tensor)."""
         B, T, FH = self.B, self.T, self.FH
         self._chln(src_t, self.n_a, p + ".norm3")
         Wi, bi = self.w(p + ".self_attn.in_proj_weight").copy(), self.w(p + ".self_attn.in_proj_bias").copy()
         Wi[:32] *= 8 ** -0.5                                          # q scaled by head_dim^-0.5 inside the projection
         bi[:32] *= 8 ** -0.5
-        self._pw(self.n_a, 32, Wi.T, bi, self.qkv, 96, FH)
+        att_ft = axis == 1                                            # sequence over frames: operands in "ft"
+        lay = "ft" if att_ft else "tf"
+        self._pw(self.n_a, 32, Wi.T, bi, self.qkv, 96, FH, out_layout=lay)
         d = L.AttnDesc()
-        d.qkv, d.out, d.B, d.T, d.F, d.E, d.heads, d.axis = self.qkv.data_ptr(), self.att.data_ptr(), B, T, FH, 32, 4, axis
+        d.qkv, d.out, d.B, d.E, d.heads, d.axis = self.qkv.data_ptr(), self.att.data_ptr(), B, 32, 4, 0
+        d.T, d.F = (FH, T) if att_ft else (T, FH)                     # "ft": the innermost axis is the sequence either way
         self.add(d, TAG_PRIOR)
         self._pw(self.att, 32, self.w(p + ".self_attn.out_proj.weight").T, self.w(p + ".self_attn.out_proj.bias"),
-                 self.s1, 32, FH, resid=src_t)                        # src + attention
+                 self.s1, 32, FH, resid=src_t, in_layout=lay)         # src + attention
         self._chln(self.s1, self.n_b, p + ".norm1")
         g = p + ".gru."
         Wih = np.concatenate([self.w(g + "weight_ih_l0"), self.w(g + "weight_ih_l0_reverse")], 0)   # [384, 32]
         bih = np.concatenate([self.w(g + "bias_ih_l0"), self.w(g + "bias_ih_l0_reverse")], 0)
-        self._pw(self.n_b, 32, Wih.T, bih, self.gx, 384, FH)
+        gru_ft = axis == 0                                            # sequence over bins: lines = frames -> "ft"
+        lay = "ft" if gru_ft else "tf"
+        self._pw(self.n_b, 32, Wih.T, bih, self.gx, 384, FH, out_layout=lay)
         whh = np.stack([P.pack_a(self.w(g + "weight_hh_l0" + suf).T) for suf in ("", "_reverse")], 0)   # [2,6,32,64]
         bhh = np.stack([self.w(g + "bias_hh_l0"), self.w(g + "bias_hh_l0_reverse")], 0)
         gd = L.GruDesc()
         gd.gx, gd.y = self.gx.data_ptr(), self.gy.data_ptr()
         gd.whh, gd.bhh = self.ctx.up(whh).data_ptr(), self.ctx.up(bhh).data_ptr()
-        gd.B, gd.T, gd.F, gd.H, gd.axis = B, T, FH, 64, axis
+        gd.B, gd.H, gd.axis = B, 64, 1                                # lines on the innermost axis, sequence on the outer
+        gd.T, gd.F = (FH, T) if gru_ft else (T, FH)
         self.add(gd, TAG_LSTM)
         # relu -> linear2 -> + residual (the normed tensor); ReLU = the load transform with slope 0, identity affine
         relu = dict(mode=1, scale0=np.ones(128), shift0=np.zeros(128), slope0=0.0)
         self._pw(self.gy, 128, self.w(p + ".linear2.weight").T, self.w(p + ".linear2.bias"), self.s2, 32, FH,
-                 resid=self.n_b, xf=relu)
+                 resid=self.n_b, xf=relu, in_layout=lay)
         self._chln(self.s2, dst_t, p + ".norm2")
 
     def build(self, x=None, out=None):
