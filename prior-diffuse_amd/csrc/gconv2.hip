@@ -26,7 +26,7 @@
 #include "gconv_common.h"
 
 #ifndef PDSE_WAVES_PER_EU
-#define PDSE_WAVES_PER_EU 1   // experiment knob: minimum resident waves per SIMD the register allocator must allow
+#define PDSE_WAVES_PER_EU 2   // at least two resident waves per SIMD: caps the allocation at 256 VGPRs (the dual-phase tail reached 272)
 #endif
 #ifndef PDSE_ABLATE
 #define PDSE_ABLATE 0   // diagnostic builds: 1 no activation loads, 2 no weight loads, 4 plain epilogue
@@ -263,9 +263,10 @@ __global__ __launch_bounds__(256, PDSE_WAVES_PER_EU) void gconv2_kernel(const pd
     float* const sw = tail_lds;
     const pdse_tail tl{sw, sw + 1024, sw + 2048, sw + 4096, sw + 4128, sw + 4160, sw + 4192, sw + 4224,
                        d.post_scale ? sw + 4288 : nullptr, sw + 4352};
-    gconv_epilogue<EPI, MT>(d, tl, acc0, acc1, b, t, j, pvalid, lane, h, mt0, mtiles);
-    if constexpr (P1MASK != 0)   // odd bins: one bin stride further (out_sf spans two bins)
-      gconv_epilogue<EPI, MT>(d, tl, acc2, acc3, b, t, j, pvalid && j < d.Fout1, lane, h, mt0, mtiles, d.out_sf >> 1);
+    if constexpr (P1MASK != 0)   // even + odd bins of this lane, paired stores
+      biglu_dual_epilogue(d, tl, acc0[0], acc1[0], acc2[0], acc3[0], b, t, j, pvalid, lane, h);
+    else
+      gconv_epilogue<EPI, MT>(d, tl, acc0, acc1, b, t, j, pvalid, lane, h, mt0, mtiles);
   } else {
     gconv_epilogue<EPI, MT>(d, tail_from_desc(d), acc0, acc1, b, t, j, pvalid, lane, h, mt0, mtiles);
   }
@@ -346,8 +347,8 @@ int pdse_gconv2_launch(const pdse_gconv_desc* d, hipStream_t s) {
     // dual-phase transposed conv: kernel (2,3) -> 4 union taps, odd bins use taps {0,2};
     //                             kernel (2,5) -> 6 union taps, odd bins use taps {0,1,3,4}
     const dim3 block(256), grid(gx, d->B, 1);
-    if (d->w3 == nullptr || (d->out_sf & 1) || (d->ksteps1 & 3)) {
-      pdse_set_error("gconv2: dual phase needs w2 and w3, an even out_sf and ksteps1 % 4 == 0");
+    if (d->w3 == nullptr || (d->out_sf & 1) || (d->ksteps1 & 3) || d->out_cr != 1 || !(d->C2 == 1 || d->C2 == 64)) {
+      pdse_set_error("gconv2: dual phase needs w2 and w3, an even out_sf, ksteps1 % 4 == 0, out_cr 1, C2 in {1, 64}");
       return 1;
     }
     if (nt == 4 && d->p1mask == 5) {

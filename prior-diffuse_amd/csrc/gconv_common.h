@@ -168,6 +168,102 @@ __device__ __forceinline__ void gconv_epilogue_impl(const pdse_gconv_desc& d, co
   }
 }
 
+// BIGLU tail without the stores: y[m2][r] = act(bn(Wc2 (L*mR + R*mL) + bc2)) for C2 <= 64 channels
+// (C2 == 1: y[0][0] on every lane).  Used by the dual-phase transposed conv, which stores the even
+// and the odd output bin of a lane with ONE 8-byte store (two strided 4-byte stores are not merged
+// on their way to HBM: profiles/r01_pmc_traffic_v5.json showed 2x WRITE_SIZE).
+template <typename Sink>   // sink(m2, r, value) is called once per output element, in (m2, r) order
+__device__ __forceinline__ void biglu_tail_values(const pdse_gconv_desc& d, const pdse_tail& tl, const f32x16& accL,
+                                                  const f32x16& accR, const int lane, const int h, Sink&& sink) {
+  f32x16 L = accL, R = accR;
+  const float* pbl = tl.bl + 4 * h;
+  const float* pbr = tl.br + 4 * h;
+  const float* pblc = tl.blc + 4 * h;
+  const float* pbrc = tl.brc + 4 * h;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    L[r] += pbl[PDSE_KR(r)];
+    R[r] += pbr[PDSE_KR(r)];
+  }
+  f32x16 mL, mR;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) mL[r] = mR[r] = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    mL = __builtin_amdgcn_mfma_f32_32x32x2f32(tl.wlc[r * 64 + lane], L[r], mL, 0, 0, 0);
+    mR = __builtin_amdgcn_mfma_f32_32x32x2f32(tl.wrc[r * 64 + lane], R[r], mR, 0, 0, 0);
+  }
+  f32x16 G;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float ml = sigmoid_f(mL[r] + pblc[PDSE_KR(r)]);
+    const float mr = sigmoid_f(mR[r] + pbrc[PDSE_KR(r)]);
+    G[r] = L[r] * mr + R[r] * ml;
+  }
+  if (d.C2 == 1) {
+    const float* pw = tl.wc2 + 4 * h;
+    float part = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part += pw[PDSE_KR(r)] * G[r];
+    float v = part + __shfl_xor(part, 32) + tl.bc2[0];
+    if (tl.ps) v = v * tl.ps[0] + tl.pt[0];
+    sink(0, 0, act_f(v, d.act, d.act_slope));
+  } else {
+#pragma unroll
+    for (int m2 = 0; m2 < 2; ++m2) {
+      f32x16 O;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) O[r] = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        O = __builtin_amdgcn_mfma_f32_32x32x2f32(tl.wc2[(m2 * 16 + r) * 64 + lane], G[r], O, 0, 0, 0);
+      const int c0 = 32 * m2 + 4 * h;
+      const float* pb = tl.bc2 + c0;
+      const float* ps = tl.ps ? tl.ps + c0 : nullptr;
+      const float* pt = tl.ps ? tl.pt + c0 : nullptr;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = O[r] + pb[PDSE_KR(r)];
+        if (ps) v = v * ps[PDSE_KR(r)] + pt[PDSE_KR(r)];
+        sink(m2, r, act_f(v, d.act, d.act_slope));
+      }
+    }
+  }
+}
+
+// one 8-byte store of two neighbouring bins; the address is only 4-byte aligned (odd row lengths),
+// which global_store_dwordx2 accepts
+__device__ __forceinline__ void store_pair(float* p, const float a, const float b) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const f32x2 v = {a, b};
+  asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+}
+
+// Dual-phase epilogue (out_cr == 1, C2 == 64 or 1): even bin at obase, odd bin one bin stride later.
+__device__ __forceinline__ void biglu_dual_epilogue(const pdse_gconv_desc& d, const pdse_tail& tl, const f32x16& a0,
+                                                    const f32x16& a1, const f32x16& a2, const f32x16& a3, const int b,
+                                                    const int t, const int j, const bool pvalid, const int lane,
+                                                    const int h) {
+  // even bins first (kept in registers), then the odd tail streams its values straight into the paired stores
+  float ye[2][16];
+  biglu_tail_values(d, tl, a0, a1, lane, h, [&](const int m2, const int r, const float v) { ye[m2][r] = v; });
+  float* const obase = d.out + ((int64_t)b * d.out_sb + (int64_t)t * d.out_st + (int64_t)j * d.out_sf + d.out_off);
+  const int64_t bin = d.out_sf >> 1;
+  const bool both = pvalid && j < d.Fout1;
+  const int64_t cstep = d.out_sc_hi;
+  const bool one = d.C2 == 1;
+  biglu_tail_values(d, tl, a2, a3, lane, h, [&](const int m2, const int r, const float vo) {
+    if (one && h != 0) return;
+    float* p = one ? obase : obase + (int64_t)(32 * m2 + 4 * h) * cstep + (int64_t)PDSE_KR(r) * cstep;
+    const float ve = ye[m2][r];
+    if (both && bin == 1) store_pair(p, ve, vo);
+    else if (pvalid) {
+      p[0] = ve;
+      if (both) p[bin] = vo;
+    }
+  });
+}
+
 // acc0/acc1: MT accumulator tiles of this wave; (b, t, j) its output position on this lane.
 template <int EPI, int MT>
 __device__ __forceinline__ void gconv_epilogue(const pdse_gconv_desc& d, const pdse_tail& tl, f32x16* acc0,

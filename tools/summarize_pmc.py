@@ -1,0 +1,66 @@
+"""Turn three rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_*) of `bench.py --steps 1 --inflight 1
+--no-graph` into profiles/<name>.json: per-kernel HBM bytes per launch and MFMA-busy fraction, and the
+eps-net totals bench.py reports as roofline.traffic.
+    python tools/summarize_pmc.py <fetch_dir> <write_dir> <sq_dir> <out.json>"""
+import collections
+import csv
+import json
+import re
+import sys
+
+
+def load(path):
+    by, meta = collections.defaultdict(dict), {}
+    for x in csv.DictReader(open(path + "/p_counter_collection.csv")):
+        did = int(x["Dispatch_Id"])
+        by[did][x["Counter_Name"]] = float(x["Counter_Value"])
+        meta[did] = (x["Kernel_Name"], int(x["Grid_Size"]))
+    return by, meta
+
+
+def short(n):
+    m = re.match(r"void (gconv2?_kernel)<(.*)>\(", n)
+    if m:
+        return m.group(1).replace("_kernel", "") + "<" + m.group(2).replace("false", "F").replace("true", "T").replace(" ", "") + ">"
+    return re.sub(r"\(.*", "", n)[:30]
+
+
+f, mf = load(sys.argv[1])
+w, _ = load(sys.argv[2])
+s, _ = load(sys.argv[3])
+ids, idw, idss = sorted(f), sorted(w), sorted(s)
+names = [mf[i][0] for i in ids]
+agg = collections.OrderedDict()
+for k, i in enumerate(ids):
+    a = agg.setdefault((short(mf[i][0]), mf[i][1]), dict(n=0, fetch=0.0, write=0.0, mfma=0.0, gui=0.0))
+    a["n"] += 1
+    a["fetch"] += f[i].get("FETCH_SIZE", 0)
+    a["write"] += w[idw[k]].get("WRITE_SIZE", 0)
+    c = s[idss[k]]
+    a["mfma"] += c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0)
+    a["gui"] += c.get("GRBM_GUI_ACTIVE", 0)
+out = []
+for (name, grid), a in sorted(agg.items(), key=lambda kv: -kv[1]["gui"])[:16]:
+    out.append(dict(kernel=name, grid_threads=grid, launches=a["n"],
+                    fetch_size_mb_per_launch_raw=round(a["fetch"] / a["n"] * 1024 / 1e6, 2),
+                    write_size_mb_per_launch=round(a["write"] / a["n"] * 1024 / 1e6, 2),
+                    mfma_busy_pct=round(a["mfma"] / 1024 / (a["gui"] / 8) * 100 if a["gui"] else 0, 1)))
+i0 = [k for k, n in enumerate(names) if n.startswith("time_embed")][0]
+i1 = [k for k, n in enumerate(names) if n.startswith("compand") and k > i0][0]
+rd = wr = 0.0
+n = 0
+for k in range(i0 + 1, i1):
+    if "gconv" in names[k]:
+        rd += f[ids[k]].get("FETCH_SIZE", 0) * 1024
+        wr += w[idw[k]].get("WRITE_SIZE", 0) * 1024
+        n += 1
+json.dump(dict(
+    note="rocprofv3 --pmc, separate passes (FETCH_SIZE | WRITE_SIZE | SQ_*), first pass of bench.py --steps 1 --inflight 1 "
+         "--no-graph at B=32,T=401.  FETCH_SIZE is raw; MI355X_MICROARCH.md says gfx950 reports 1/2 of wide coalesced "
+         "reads, so fetch_size_bytes_x2 is the corrected figure (an upper bound for our 4-byte gathers).",
+    kernels=out,
+    eps_net_one_pass=dict(launches=n, fetch_size_bytes_raw=rd, fetch_size_bytes_x2=2 * rd, write_size_bytes=wr,
+                          note="all gconv launches of the 6 eps-net forwards of one pass")), open(sys.argv[4], "w"), indent=1)
+print(n, rd / 1e9, wr / 1e9)
+for o in out[:10]:
+    print(o)
