@@ -60,7 +60,15 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        # PDSE_BENCH_BACKEND=gloo + PDSE_BENCH_DEVICE=0: rehearse the N>1 code path with several ranks on ONE GPU
+        # (RCCL refuses two ranks per device); the driver's real runs use nccl, one rank per GPU
+        backend = os.environ.get("PDSE_BENCH_BACKEND", "nccl")
+        if "PDSE_BENCH_DEVICE" in os.environ:
+            local = int(os.environ["PDSE_BENCH_DEVICE"])
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     torch.cuda.set_device(local)
     dev = "cuda:%d" % local
 
@@ -123,7 +131,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     ms_per_step = elapsed / args.steps * 1e3
