@@ -401,3 +401,32 @@ def test_checkpoint_rules_and_cli_surface(L, weights, tmp_path, monkeypatch):
         tr.ComplexDDPMTrainer(args2, config, device=DEV)
     with pytest.raises(ValueError, match="level"):
         main.parse_args_and_config(["--verbose", "loud", "--config", "gcrn.yml"])
+
+
+def test_full_50_step_schedule_at_t401(L, weights, R):
+    """BASELINE config 3 shape: full 50-step reverse schedule at T=401 (one utterance, fp32),
+    tolerance 1e-4 rel-L2 vs the CPU oracle; the step indices it walks are the bit-exact T array."""
+    params = pkg("params").params
+    feat, x_T = pkg("synth").synthetic_spectrogram(1, 401, seed=77)
+    pipe = pkg("pipeline").SamplerPipeline(DEV, "GCRN", weights("GCRN"), weights("DiffUNet1"), 1, T=401,
+                                           fast_sampling=False)
+    assert pipe.nsteps == 50 and np.array_equal(pipe.schedule[4], np.arange(50, dtype=np.float32))
+    spec, init = pipe.sample(feat.to(DEV), x_T.to(DEV))
+    with torch.no_grad():
+        ref, _ = R.sample("GCRN", weights("GCRN"), weights("DiffUNet1"), feat, x_T, params.noise_schedule,
+                          params.inference_noise_schedule, False, False)
+    assert rel_l2(spec.cpu(), ref) < 1e-4
+
+
+def test_long_utterance_t1001(L, weights, R):
+    """BASELINE config 5 shape: 10 s utterances (T = 1001 frames) through the eps-net and the prior."""
+    x = seeded((1, 2, 1001, 161), 91)
+    xi = seeded((1, 2, 1001, 161), 92) * 0.3
+    t = torch.tensor([22.992493])
+    out = pkg("ops").DiffUNet1Op(weights("DiffUNet1"), DEV)(x.to(DEV), xi.to(DEV), t.to(DEV)).cpu()
+    prior = pkg("ops").GCRNOp(weights("GCRN"), DEV)(x.to(DEV)).cpu()
+    with torch.no_grad():
+        ref = R.diffunet1_forward(weights("DiffUNet1"), x, xi, t)
+        ref_p = R.gcrn_forward(weights("GCRN"), x)
+    assert rel_l2(out, ref) < 2e-5
+    assert rel_l2(prior, ref_p) < 5e-5
