@@ -363,7 +363,7 @@ int pdse_gconv2_launch(const pdse_gconv_desc* d, hipStream_t s) {
     if (nt == 2) GO(PDSE_EPI_BIGLU, 2, 4, false, 0, true, true, true);
     if (nt == 4) GO(PDSE_EPI_BIGLU, 4, 2, false, 0, true, true, true);
     if (nt == 6) GO(PDSE_EPI_BIGLU, 6, 2, false, 0, true, true, true);
-    if (nt == 10) GO(PDSE_EPI_BIGLU, 10, 2, false, 0, false, false, false);
+    if (nt == 10) GO(PDSE_EPI_BIGLU, 10, 2, false, 0, false, false, false);   // ping-pong measured equal, 40 more VGPRs
   }
 #undef GO
   pdse_set_error("gconv2: no pipelined instantiation for this (epilogue, taps, sources); pack with korder 0");
