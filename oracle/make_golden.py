@@ -45,6 +45,7 @@ def load_reference():
     ref.diff3 = _load("ref_diff3", REF + "/model/diff3.py")
     ref.gcrn = _load("ref_gcrn", REF + "/model/gcrn.py")
     ref.diff = _load("ref_diff", REF + "/model/diff.py")
+    ref.nocon = _load("ref_piror_grad", REF + "/model/piror_grad.py")
     # the model files force CUDA_VISIBLE_DEVICES=0 at import; undo that side effect
     if saved_env is None:
         os.environ.pop("CUDA_VISIBLE_DEVICES", None)
@@ -203,12 +204,18 @@ def main():
 
         # ---- A4/A5 reverse-loop traces with injected x_T: the reference's own loop
         # body (trainer/complex_ddpm_trainer.py:964-998) driven on the real modules
-        def ref_loop(prior, feat, x_T, fast, use_sigma):
+        nocon = ref.nocon.Nocon(ref.params)
+        nocon.load_state_dict(synth.make_state_dict("Nocon", 1234), strict=True)
+        nocon.eval()
+        outn = nocon(x, t)
+        np.savez(os.path.join(OUT, "nocon_small.npz"), seed_x=11, t=t.numpy(), out=outn.numpy())
+
+        def ref_loop(prior, feat, x_T, fast, use_sigma, deltamu=False):
             alpha, beta, alpha_cum, sigmas, Tarr = ref_inference_schedule(ref, fast)
             c = 11
             init_audio = prior(feat)
             init_audio /= c
-            audio = x_T.clone()
+            audio = x_T + init_audio if deltamu else x_T.clone()
             if use_sigma:
                 tmp = torch.flatten(torch.abs(init_audio), start_dim=2)
                 tmp /= torch.max(tmp, dim=2, keepdim=True).values
@@ -224,7 +231,8 @@ def main():
             for n in range(len(alpha) - 1, -1, -1):
                 c1 = 1 / alpha[n] ** 0.5
                 c2 = beta[n] / (1 - alpha_cum[n]) ** 0.5
-                predicted_noise = eps_net(audio, init_audio, torch.tensor([Tarr[n]]).repeat(N))
+                tn = torch.tensor([Tarr[n]]).repeat(N)
+                predicted_noise = nocon(audio, tn) if deltamu else eps_net(audio, init_audio, tn)
                 audio = c1 * (audio - c2 * predicted_noise)
                 if n > 0:
                     noise = torch.randn_like(audio)
@@ -234,7 +242,8 @@ def main():
                         noise = noise * (mask ** 0.5)
                     audio += newsigma * noise
                 trace.append(audio.clone())
-            audio += init_audio
+            if not deltamu:
+                audio += init_audio
             audio *= c
             init_audio *= c
             return audio, init_audio, trace
@@ -243,8 +252,8 @@ def main():
         x_T = seeded((2, 2, 16, 161), 42)
         for tag, prior, fast, sig in (("gcrn_fast", gcrn, True, False), ("gcrn_full", gcrn, False, False),
                                       ("gcrn_fast_sigma", gcrn, True, True),
-                                      ("diffunet_fast", dprior, True, False)):
-            audio, init, trace = ref_loop(prior, feat, x_T, fast, sig)
+                                      ("diffunet_fast", dprior, True, False), ("gcrn_fast_deltamu", gcrn, True, False)):
+            audio, init, trace = ref_loop(prior, feat, x_T, fast, sig, deltamu=tag.endswith("deltamu"))
             print("sample %-16s out rms %.3f init rms %.3f" % (tag, audio.pow(2).mean().sqrt(),
                                                               init.pow(2).mean().sqrt()))
             keep = {"out": audio.numpy(), "init": init.numpy(), "seed_feat": 41, "seed_xT": 42}

@@ -240,6 +240,14 @@ def diffunet1_forward(sd, x, x_init, t, table=None, taps=None):
     return _unet_trunk(sd, x, temb, taps)
 
 
+def nocon_forward(sd, x, t, table=None):
+    """Alt eps-net of the ``deltamu`` parameterisation (reference: model/piror_grad.py:28-40):
+    DiffUNet1 without Preprocess, forward(x, t)."""
+    if table is None:
+        table = build_time_table(50)
+    return _unet_trunk(sd, x, time_embedding(sd, t, table))
+
+
 def diffunet_forward(sd, x):
     """Prior DiffUNet (reference: model/diff.py:23-33): same trunk, no time input."""
     return _unet_trunk(sd, x, None)
@@ -346,7 +354,7 @@ def sigma_mask(init):
 
 
 def reverse_loop(ddpm_sd, init_scaled, x_T, alpha, beta, alpha_cum, sigmas, T, table=None,
-                 use_sigma=False, trace=None):
+                 use_sigma=False, trace=None, deltamu=False):
     """Runs n = S-1 … 0 on ``audio = x_T`` with ``init_scaled = X_init / 11``.
 
     The n>0 noise term is kept for fidelity: ``newsigma = max(0, σ - c1σ)`` is
@@ -354,7 +362,7 @@ def reverse_loop(ddpm_sd, init_scaled, x_T, alpha, beta, alpha_cum, sigmas, T, t
     """
     if table is None:
         table = build_time_table(50)
-    audio = x_T.clone()
+    audio = x_T + init_scaled if deltamu else x_T.clone()      # reference :947-950
     if use_sigma:
         mask = sigma_mask(init_scaled)
         audio = audio * (mask ** 0.5)
@@ -364,7 +372,8 @@ def reverse_loop(ddpm_sd, init_scaled, x_T, alpha, beta, alpha_cum, sigmas, T, t
     for n in range(len(alpha) - 1, -1, -1):
         c1 = 1 / alpha[n] ** 0.5
         c2 = beta[n] / (1 - alpha_cum[n]) ** 0.5
-        eps = diffunet1_forward(ddpm_sd, audio, init_scaled, torch.tensor([T[n]]).repeat(N), table)
+        tn = torch.tensor([T[n]]).repeat(N)
+        eps = nocon_forward(ddpm_sd, audio, tn, table) if deltamu else diffunet1_forward(ddpm_sd, audio, init_scaled, tn, table)
         audio = float(c1) * (audio - float(c2) * eps)
         if n > 0:
             newsigma = max(0, gamma[n] - c1 * gamma[n])
@@ -375,7 +384,7 @@ def reverse_loop(ddpm_sd, init_scaled, x_T, alpha, beta, alpha_cum, sigmas, T, t
 
 
 def sample(prior_name, prior_sd, ddpm_sd, feat, x_T, noise_schedule, inference_noise_schedule,
-           fast_sampling=True, use_sigma=False, trace=None):
+           fast_sampling=True, use_sigma=False, trace=None, deltamu=False):
     """feat [B,2,T,F] (compressed spectrogram) -> enhanced compressed spectrogram.
 
     reference: trainer/complex_ddpm_trainer.py:941-998.
@@ -385,8 +394,9 @@ def sample(prior_name, prior_sd, ddpm_sd, feat, x_T, noise_schedule, inference_n
     init = PRIORS[prior_name](prior_sd, feat)
     init = init / C_SCALE
     audio = reverse_loop(ddpm_sd, init, x_T, alpha, beta, alpha_cum, sigmas, T, use_sigma=use_sigma,
-                         trace=trace)
-    audio = audio + init
+                         trace=trace, deltamu=deltamu)
+    if not deltamu:                  # ``if self.pirorgrad: audio += init_audio`` (reference :995-996)
+        audio = audio + init
     audio = audio * C_SCALE
     return audio, init * C_SCALE
 

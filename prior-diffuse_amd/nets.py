@@ -161,12 +161,14 @@ class EpsNetPlan(PlanBase):
     ENC_F = [161, 79, 39, 19, 9, 4]
     NSLOT = 16  # 15 stages + en1 real-row bias
 
-    def __init__(self, ctx, sd, B, T, time_cond=True, nsteps=1, plan=None, table=None):
+    def __init__(self, ctx, sd, B, T, time_cond=True, nsteps=1, plan=None, table=None, with_pre=None):
+        """with_pre False + time_cond True: ``Nocon`` (model/piror_grad.py), DiffUNet1 without Preprocess."""
         super().__init__(ctx, plan)
         self.sd, self.B, self.T, self.time_cond, self.nsteps = sd, B, T, time_cond, nsteps
+        self.with_pre = time_cond if with_pre is None else with_pre
         a = ctx.alloc
         self.x = a(B, 2, T, F0)
-        self.x_init = a(B, 2, T, F0) if time_cond else None
+        self.x_init = a(B, 2, T, F0) if self.with_pre else None
         self.out = a(B, 2, T, F0)
         self.H = a(B, 32, T + 1, F0)                 # conv1 output of the current block (+ explicit pad frame)
         self.en = [a(B, 64, T, f) for f in self.ENC_F[1:5]] + [a(B, 64, 4, T)]  # en5 stored [B,64,4,T]
@@ -213,7 +215,7 @@ class EpsNetPlan(PlanBase):
         # slot 15: en1 real rows also carry W1 · b_preprocess (the pad row does not, diff3.py:145-147)
         W1 = self.w("en.conv1.conv1.weight")[:, :, 0, 0]
         wf.append(wf[0])
-        bf.append(bf[0] + W1 @ self.w("preprocess.conv.bias"))
+        bf.append(bf[0] + (W1 @ self.w("preprocess.conv.bias") if self.with_pre else 0.0))
         WF, BF = np.concatenate(wf, 0), np.concatenate(bf, 0)      # [512, 512], [512]
         self.t_p1T = ctx.up(self.w("time_embedding.projection1.weight").T)
         self.t_b1 = ctx.up(self.w("time_embedding.projection1.bias"))
@@ -244,7 +246,7 @@ class EpsNetPlan(PlanBase):
         kw = 5 if k == 1 else 3
         Fout = (Fin - kw) // 2 + 1
         W1 = self.w(p + ".conv1.weight")[:, :, 0, 0]                       # [32, Cin]
-        if k == 1 and self.time_cond:
+        if k == 1 and self.with_pre:
             Wp = self.w("preprocess.conv.weight")[:, :, 0, 0]               # [2, 4]: fold Preprocess into conv1
             W1 = W1 @ Wp
         if self.time_cond:
@@ -393,7 +395,7 @@ class EpsNetPlan(PlanBase):
         s2 = nchw(2, T, F0)
         # encoder: stage 1 reads (x, x_init) through the folded Preprocess 1x1
         src_x = self.src(x, 2, *s2)
-        src_i = self.src(x_init, 2, *s2) if self.time_cond else None
+        src_i = self.src(x_init, 2, *s2) if self.with_pre else None
         Fin = F0
         for k in range(1, 6):
             if k < 5:

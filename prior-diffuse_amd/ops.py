@@ -63,6 +63,29 @@ class DiffUNet1Op(_PlannedOp):
         return net.out.clone()
 
 
+class NoconOp(_PlannedOp):
+    """Alt eps-net of the ``deltamu`` parameterisation: ``Nocon.forward(x, t)`` (model/piror_grad.py:28-40)."""
+
+    def __call__(self, x, t):
+        self._check(x)
+        B, _, T, _ = x.shape
+        tf = t.to(torch.float32)
+        if t.shape != (B,) or float(tf.min()) < 0 or float(tf.max()) > 49:
+            raise IndexError("t must be [B] diffusion steps inside the 50-entry embedding table")
+        key = (B, T)
+        if key not in self._plans:
+            net = nets.EpsNetPlan(nets.Ctx(self.device), self.sd, B, T, time_cond=True, nsteps=1, with_pre=False)
+            net.build_time()
+            net.build_step(0)
+            net.finish()
+            self._plans[key] = net
+        net = self._plans[key]
+        net.x.copy_(x)
+        net.tsteps.copy_(tf.view(1, B))
+        net.plan.run(self._stream())
+        return net.out.clone()
+
+
 class DiffUNetOp(_PlannedOp):
     """Prior ``DiffUNet.forward(x)`` (model/diff.py:23-33)."""
 

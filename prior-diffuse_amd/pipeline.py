@@ -25,7 +25,9 @@ F0 = 161
 
 class SamplerPipeline:
     def __init__(self, device, prior_name, prior_sd, ddpm_sd, B, T=None, L_=None, fast_sampling=True,
-                 use_sigma=False, params=default_params, with_signal=None):
+                 use_sigma=False, params=default_params, with_signal=None, deltamu=False):
+        """deltamu: the alternative parameterisation of utils/params.py:36 — ddpm_sd is a ``Nocon`` state_dict,
+        x_T = noise + X_init/11 (:947-948), eps = Nocon(x, t) (:970-971), no final ``+ X_init`` (:995)."""
         if L_ is not None:
             T = 1 + L_ // 160
         if with_signal is None:
@@ -56,11 +58,14 @@ class SamplerPipeline:
             self.prior = adopt(nets.AiaPlan(ctx, prior_sd, B, T, plan=self.plan))
         else:
             raise ValueError("prior %r not built (GCRN, DiffUNet, aia_complex_trans_ri)" % prior_name)
-        self.eps = adopt(nets.EpsNetPlan(ctx, ddpm_sd, B, T, time_cond=True, nsteps=S, plan=self.plan))
+        self.eps = adopt(nets.EpsNetPlan(ctx, ddpm_sd, B, T, time_cond=True, nsteps=S, plan=self.plan,
+                                         with_pre=not deltamu))
+        self.deltamu = deltamu
         self.istft = adopt(nets.IstftPlan(ctx, B, T, L_, plan=self.plan)) if with_signal else None
 
         self.feat = self.prior.x                     # prior input = compressed spectrogram
-        self.init = self.eps.x_init                  # X_init / 11
+        self.init = self.eps.x_init if not deltamu else ctx.alloc(B, 2, T, F0)   # X_init / 11
+        self.zero = ctx.alloc(B, 2, T, F0, zero=True) if deltamu else None
         self.audio = self.eps.x                      # x_t, updated in place
         self.spec = self.istft.spec if with_signal else ctx.alloc(B, 2, T, F0)
         self.xT_in = ctx.alloc(B, 2, T, F0)          # injected x_T (kept so a replay starts from it)
@@ -92,8 +97,12 @@ class SamplerPipeline:
                 d.maxbuf = ctx.alloc(B * 2).data_ptr()
                 d.plane, d.nplanes = T * F0, B * 2
                 self.eps.add(d, nets.TAG_EW)
+            elif deltamu:
+                ew(L.EW_ADD_MUL, self.xT_in, b=self.init, out=self.audio, s0=1.0)     # randn_like(init) + init
             else:
                 ew(L.EW_COPY, self.xT_in, out=self.audio)
+            if deltamu and use_sigma:
+                raise NotImplementedError("--sigma with deltamu is not built")
             self.eps.build_time()
 
         mark("prologue", prologue)
@@ -103,11 +112,11 @@ class SamplerPipeline:
             nstep = S - 1 - i
 
             def one(i=i, nstep=nstep):
-                self.eps.build_step(i, x=self.audio, x_init=self.init, out=self.eps.out)
+                self.eps.build_step(i, x=self.audio, x_init=None if deltamu else self.init, out=self.eps.out)
                 if nstep > 0:
                     ew(L.EW_UPDATE, self.audio, b=self.eps.out, out=self.audio, s0=float(c1[nstep]), s1=float(c2[nstep]))
                 else:
-                    ew(L.EW_UPDATE_FINAL, self.audio, b=self.eps.out, c=self.init, out=self.spec,
+                    ew(L.EW_UPDATE_FINAL, self.audio, b=self.eps.out, c=self.zero if deltamu else self.init, out=self.spec,
                        s0=float(c1[0]), s1=float(c2[0]), s2=PRIOR_SCALE_C)
 
             mark("step%d" % nstep, one)

@@ -138,6 +138,11 @@ def diffunet1_spec():
     return spec
 
 
+def nocon_spec():
+    """Ordered spec of ``Nocon`` (reference: model/piror_grad.py:15-40): DiffUNet1 without Preprocess."""
+    return [e for e in diffunet1_spec() if not e[0].startswith("preprocess.")]
+
+
 def diffunet_spec():
     """Ordered spec of the prior ``DiffUNet`` (reference: model/diff.py:13-33)."""
     return _unet_body(time_cond=False)
@@ -241,6 +246,7 @@ def aia_complex_trans_ri_spec():
 
 
 ARCH_SPECS = {
+    "Nocon": nocon_spec,
     "aia_complex_trans_ri": aia_complex_trans_ri_spec,
     "DiffUNet1": diffunet1_spec,
     "DiffUNet": diffunet_spec,

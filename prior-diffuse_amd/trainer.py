@@ -28,7 +28,7 @@ from .schedule import inference_schedule as _inference_schedule
 
 
 class ComplexDDPMTrainer(object):
-    def __init__(self, args, config, device=None, prior_state_dict=None, ddpm_state_dict=None):
+    def __init__(self, args, config, device=None, prior_state_dict=None, ddpm_state_dict=None, params=None):
         """args: .retrain .joint .draw .sigma .checkpoint .generated_wav
         config: .model.name, .train.{fft_num, win_size, win_shift, feat_type}
         Weights come from ``<args.checkpoint>/best_checkpoint.pth`` under the reference's
@@ -36,11 +36,12 @@ class ComplexDDPMTrainer(object):
         self.c = PRIOR_SCALE_C                                        # :30
         self.args = deepcopy(args)
         self.config = deepcopy(config)
-        self.params = default_params                                  # :34
+        self.params = default_params if params is None else params    # :34 (override: synthetic runs / deltamu)
         self.pirorgrad = self.params.pirorgrad
         self.deltamu = self.params.deltamu
-        if not self.pirorgrad or self.deltamu:
-            raise NotImplementedError("only the active prior-grad parameterisation is built (utils/params.py:36-37)")
+        if self.pirorgrad == self.deltamu:
+            # :70-75 also has a third branch (neither flag: DiffUNet1 conditioned on the noisy feature); not built
+            raise NotImplementedError("exactly one of pirorgrad (DiffUNet1) / deltamu (Nocon) must be set")
         tr = self.config.train
         if (tr.fft_num, tr.win_size, tr.win_shift) != (320, 320, 160) or tr.feat_type != "sqrt":
             raise NotImplementedError("STFT 320/320/160 with feat_type 'sqrt' is baked into every model of the path")
@@ -60,7 +61,7 @@ class ComplexDDPMTrainer(object):
         if self.prior_sd is None or self.ddpm_sd is None:
             raise ValueError("no weights: pass state_dicts or use --retrain with a best_checkpoint.pth")
         self.model = ops.PRIOR_OPS[self.prior_name](self.prior_sd, self.device)       # :69
-        self.model_ddpm = ops.DiffUNet1Op(self.ddpm_sd, self.device)                  # :71
+        self.model_ddpm = (ops.NoconOp if self.deltamu else ops.DiffUNet1Op)(self.ddpm_sd, self.device)   # :70-73
         self._pipes = {}
 
     # ---- A8 checkpoint rules (:91-97, :906-913) ---------------------------
@@ -85,7 +86,7 @@ class ComplexDDPMTrainer(object):
         if key not in self._pipes:
             self._pipes[key] = SamplerPipeline(self.device, self.prior_name, self.prior_sd, self.ddpm_sd, B, T=T,
                                                L_=L_, fast_sampling=self.params.fast_sampling,
-                                               use_sigma=key[3], params=self.params)
+                                               use_sigma=key[3], params=self.params, deltamu=self.deltamu)
         return self._pipes[key]
 
     def _x_T(self, shape, x_T):

@@ -430,3 +430,28 @@ def test_long_utterance_t1001(L, weights, R):
         ref_p = R.gcrn_forward(weights("GCRN"), x)
     assert rel_l2(out, ref) < 2e-5
     assert rel_l2(prior, ref_p) < 5e-5
+
+
+def test_nocon_and_deltamu_sampling(L, weights):
+    """Nocon eps-net (model/piror_grad.py) and the deltamu parameterisation of the loop."""
+    g0, g = golden("diffunet1_small"), golden("nocon_small")
+    x = seeded((2, 2, 20, 161), g0["seed_x"])
+    out = pkg("ops").NoconOp(weights("Nocon"), DEV)(x.to(DEV), torch.from_numpy(g["t"]).to(DEV))
+    assert rel_l2(out.cpu(), g["out"]) < 2e-5
+    gs = golden("sample_gcrn_fast_deltamu")
+    feat, x_T = seeded((2, 2, 16, 161), gs["seed_feat"]), seeded((2, 2, 16, 161), gs["seed_xT"])
+    pipe = pkg("pipeline").SamplerPipeline(DEV, "GCRN", weights("GCRN"), weights("Nocon"), 2, T=16, deltamu=True)
+    spec, init = pipe.sample(feat.to(DEV), x_T.to(DEV))
+    assert rel_l2(spec.cpu(), gs["out"]) < 1e-4
+    # trainer surface with the flags flipped (utils/params.py:36-37)
+    import argparse
+
+    P = pkg("params")
+    prm = P.AttrDict(dict(P.params))
+    prm.deltamu, prm.pirorgrad = True, False
+    ns = argparse.Namespace
+    t = pkg("trainer").ComplexDDPMTrainer(
+        ns(retrain=False, joint=True, draw=False, sigma=False, checkpoint="x", generated_wav="y"),
+        ns(model=ns(name="GCRN"), train=ns(fft_num=320, win_size=320, win_shift=160, feat_type="sqrt")),
+        device=DEV, prior_state_dict=weights("GCRN"), ddpm_state_dict=weights("Nocon"), params=prm)
+    assert rel_l2(t.sample(feat, x_T).cpu(), gs["out"]) < 1e-4

@@ -189,3 +189,20 @@ def test_aia_prior_with_intermediates(weights):
     assert rel_l2(taps["trans_last"][:, ::8], g["trans_last_c8"]) < 1e-5
     assert rel_l2(taps["aham"][:, ::8], g["aham_c8"]) < 1e-5
     assert rel_l2(out, g["out"]) < 1e-5
+
+
+def test_nocon_and_deltamu_sampling(weights):
+    """the deltamu parameterisation (Nocon eps-net, x_T = noise + X_init, no final + X_init)."""
+    g0 = golden("diffunet1_small")
+    g = golden("nocon_small")
+    x = seeded((2, 2, 20, 161), g0["seed_x"])
+    with torch.no_grad():
+        out = R.nocon_forward(weights("Nocon"), x, torch.from_numpy(g["t"]))
+    assert rel_l2(out, g["out"]) < TOL
+    gs = golden("sample_gcrn_fast_deltamu")
+    params = pkg("params").params
+    feat, x_T = seeded((2, 2, 16, 161), gs["seed_feat"]), seeded((2, 2, 16, 161), gs["seed_xT"])
+    with torch.no_grad():
+        o, init = R.sample("GCRN", weights("GCRN"), weights("Nocon"), feat, x_T, params.noise_schedule,
+                           params.inference_noise_schedule, True, False, deltamu=True)
+    assert rel_l2(o, gs["out"]) < 2e-5
