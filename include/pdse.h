@@ -164,11 +164,14 @@ typedef struct pdse_compand_desc {
   int32_t mode; /* 0: mag**0.5 (compress), 1: mag**2 (decompress) */
 } pdse_compand_desc;
 
-/* waveform front-end: c[b] = sqrt(sum x^2 / L); xpad = reflect_pad(x / c, 160)   (:922-923, stft center=True) */
+/* waveform front-end: c[b] = sqrt(sum x^2 / len_b); xpad = reflect_pad(x / c, 160)   (:922-923, stft center=True).
+ * lens (optional, device int32 [B]): true lengths of zero-padded utterances — the batched twin normalises each
+ * utterance over its own samples before padding (utils/dataset.py:45-58); NULL: len_b = L. */
 typedef struct pdse_wavprep_desc {
   const float* wav; /* [B][L] */
   float* xpad;      /* [B][L + 2*pad] */
   float* c;         /* [B] */
+  const int32_t* lens;
   int32_t B, L, pad, normalize; /* normalize 0: c = 1 */
 } pdse_wavprep_desc;
 

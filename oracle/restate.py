@@ -551,3 +551,24 @@ def aia_complex_trans_ri_forward(sd, x, taps=None):
 
 
 PRIORS["aia_complex_trans_ri"] = aia_complex_trans_ri_forward
+
+
+def enhance_ragged(prior_name, prior_sd, ddpm_sd, wavs, x_T, noise_schedule, inference_noise_schedule,
+                   fast_sampling=True, use_sigma=False):
+    """The batched twin of generate_wav used by the validation loop: per-utterance c = sqrt(len / sum x^2)
+    BEFORE zero-padding (utils/dataset.py:45-58), batched STFT (:59-74), sampling (:441-494), per-utterance
+    ISTFT cut to (frame_num - 1) * 160 samples with frame_num = len // 160 + 1 (utils/metrics.py:553-563,
+    utils/dataset.py:101).  Returns the list of trimmed waveforms, rescaled by 1/c like generate_wav."""
+    lens = [int(w.numel()) for w in wavs]
+    cs = [float(np.sqrt(n / float((w.double() ** 2).sum()))) for w, n in zip(wavs, lens)]
+    batch = torch.nn.utils.rnn.pad_sequence([w * c for w, c in zip(wavs, cs)], batch_first=True)
+    feat = compress_sqrt(stft_ri(batch))
+    spec, _ = sample(prior_name, prior_sd, ddpm_sd, feat, x_T, noise_schedule, inference_noise_schedule,
+                     fast_sampling, use_sigma)
+    com = decompress_square(spec)
+    outs = []
+    for i, n in enumerate(lens):
+        z = torch.complex(com[i, 0], com[i, 1]).permute(1, 0)[None]
+        y = torch.istft(z, n_fft=320, hop_length=160, win_length=320, window=torch.hann_window(320))[0]
+        outs.append(y[: (n // 160) * 160] / cs[i])
+    return outs

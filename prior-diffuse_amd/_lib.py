@@ -63,7 +63,7 @@ class CompandDesc(C.Structure):
 
 
 class WavprepDesc(C.Structure):
-    _fields_ = [("wav", _fp), ("xpad", _fp), ("c", _fp),
+    _fields_ = [("wav", _fp), ("xpad", _fp), ("c", _fp), ("lens", _fp),
                 ("B", _i32), ("L", _i32), ("pad", _i32), ("normalize", _i32)]
 
 

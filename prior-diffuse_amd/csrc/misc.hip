@@ -185,15 +185,16 @@ __global__ __launch_bounds__(1024) void wavprep_kernel(const pdse_wavprep_desc d
   const float* x = d.wav + (size_t)b * d.L;
   float c = 1.f;
   if (d.normalize) {
+    const int len = d.lens ? min(max(d.lens[b], 1), d.L) : d.L;
     float ss = 0.f;
-    for (int i = tid; i < d.L; i += 1024) ss += x[i] * x[i];
+    for (int i = tid; i < len; i += 1024) ss += x[i] * x[i];
     for (int o = 32; o > 0; o >>= 1) ss += __shfl_down(ss, o);
     if ((tid & 63) == 0) red[tid >> 6] = ss;
     __syncthreads();
     if (tid == 0) {
       float tot = 0.f;
       for (int w = 0; w < 16; ++w) tot += red[w];
-      cval = sqrtf(tot / (float)d.L);
+      cval = sqrtf(tot / (float)len);
     }
     __syncthreads();
     c = cval;

@@ -572,6 +572,8 @@ class StftPlan(PlanBase):
         self.wav = ctx.alloc(B, L_)
         self.xpad = ctx.alloc(B, L_ + 320)
         self.c = ctx.alloc(B)
+        self.lens = torch.full((B,), L_, dtype=torch.int32, device=ctx.device)   # true lengths of zero-padded utterances
+        ctx.keep.append(self.lens)
         self.feat = ctx.alloc(B, 2, self.T, F0)
         self.normalize = normalize
 
@@ -579,7 +581,7 @@ class StftPlan(PlanBase):
         B, L_, T = self.B, self.L, self.T
         feat = self.feat if feat is None else feat
         d = L.WavprepDesc()
-        d.wav, d.xpad, d.c = self.wav.data_ptr(), self.xpad.data_ptr(), self.c.data_ptr()
+        d.wav, d.xpad, d.c, d.lens = self.wav.data_ptr(), self.xpad.data_ptr(), self.c.data_ptr(), self.lens.data_ptr()
         d.B, d.L, d.pad, d.normalize = B, L_, 160, 1 if self.normalize else 0
         self.add(d, TAG_SIGNAL)
         Lp = L_ + 320

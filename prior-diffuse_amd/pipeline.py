@@ -159,12 +159,18 @@ class SamplerPipeline:
             self.run("prior", "step0")
         return self.spec.clone(), self.prior.out.clone()
 
-    def enhance(self, wav, x_T, graph=False):
-        """wav [B,L], x_T [B,2,T,161] -> (enhanced wav [B,L], spectrogram [B,2,T,161])."""
+    def enhance(self, wav, x_T, graph=False, lens=None):
+        """wav [B,L], x_T [B,2,T,161] -> (enhanced wav [B,L], spectrogram [B,2,T,161]).
+        lens: true lengths of zero-padded utterances (RMS normalisation over each utterance's own samples,
+        utils/dataset.py:45-58); default: every utterance fills L."""
         if self.stft is None:
             raise ValueError("pipeline was built without the signal front/back end (pass L_)")
         self.stft.wav.copy_(wav)
         self.xT_in.copy_(x_T)
+        if lens is None:
+            self.stft.lens.fill_(self.L)
+        else:
+            self.stft.lens.copy_(torch.as_tensor(lens, dtype=torch.int32))
         self.run(graph=graph)
         return self.istft.wav.clone(), self.spec.clone()
 

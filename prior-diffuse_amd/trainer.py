@@ -109,6 +109,22 @@ class ComplexDDPMTrainer(object):
         out, _ = self._pipe(B, L_=L_).enhance(wav, self._x_T((B, 2, T, 161), x_T))
         return out
 
+    def enhance_batch(self, wavs, x_T=None, trim_to_frames=False):
+        """Ragged batch, the validation loop's convention: every utterance is RMS-normalised
+        over its own samples, zero-padded to the longest (utils/dataset.py:45-58), enhanced in one batch
+        (:408-494) and cut back — to its own length, or with ``trim_to_frames`` to ``(frame_num - 1) * 160``
+        samples as utils/metrics.py:562-563 does.  Returns a list of 1-D tensors (rescaled by c)."""
+        wavs = [torch.as_tensor(w, dtype=torch.float32).flatten() for w in wavs]
+        lens = [int(w.numel()) for w in wavs]
+        if min(lens) < 161:
+            raise ValueError("utterances must be longer than the reflect padding (160 samples)")
+        batch = torch.nn.utils.rnn.pad_sequence(wavs, batch_first=True).to(self.device)
+        B, L_ = batch.shape
+        T = 1 + L_ // 160
+        out, _ = self._pipe(B, L_=L_).enhance(batch, self._x_T((B, 2, T, 161), x_T), lens=lens)
+        cut = [(n // 160) * 160 if trim_to_frames else n for n in lens]
+        return [out[i, :cut[i]].clone() for i in range(B)]
+
     # ---- A2..A7: the reference's entry point --------------------------------
     def generate_wav(self, load_pre_train=True, data_path="data/noisy_testset_wav"):
         """Per-file B=1 enhancement of ``data_path/*.wav`` into ``args.generated_wav``

@@ -260,7 +260,8 @@ def run_compand(d, mem):
 
 def run_wavprep(d, mem):
     x = mem.arr(d.wav, d.B * d.L).reshape(d.B, d.L)
-    c = np.sqrt((x.astype(np.float32) ** 2).sum(1) / np.float32(d.L)) if d.normalize else np.ones(d.B, np.float32)
+    lens = mem.arr(d.lens, d.B, np.int32).astype(np.float32) if d.lens else np.full(d.B, d.L, np.float32)
+    c = np.sqrt((x.astype(np.float32) ** 2).sum(1) / lens) if d.normalize else np.ones(d.B, np.float32)
     if d.c:
         mem.arr(d.c, d.B)[:] = c
     xp = np.pad(x / c[:, None], ((0, 0), (d.pad, d.pad)), mode="reflect")

@@ -455,3 +455,31 @@ def test_nocon_and_deltamu_sampling(L, weights):
         ns(model=ns(name="GCRN"), train=ns(fft_num=320, win_size=320, win_shift=160, feat_type="sqrt")),
         device=DEV, prior_state_dict=weights("GCRN"), ddpm_state_dict=weights("Nocon"), params=prm)
     assert rel_l2(t.sample(feat, x_T).cpu(), gs["out"]) < 1e-4
+
+
+def test_ragged_batch_validation_convention(L, weights, R):
+    """zero-padded ragged batch, per-utterance normalisation over the true length,
+    outputs cut to (frame_num - 1) * 160 samples."""
+    import argparse
+
+    params = pkg("params").params
+    g = torch.Generator().manual_seed(33)
+    wavs = [0.2 * torch.randn(n, generator=g) for n in (3200, 2500, 1111)]
+    T = 1 + 3200 // 160
+    x_T = torch.randn(3, 2, T, 161, generator=g)
+    ns = argparse.Namespace
+    t = pkg("trainer").ComplexDDPMTrainer(
+        ns(retrain=False, joint=True, draw=False, sigma=False, checkpoint="x", generated_wav="y"),
+        ns(model=ns(name="GCRN"), train=ns(fft_num=320, win_size=320, win_shift=160, feat_type="sqrt")),
+        device=DEV, prior_state_dict=weights("GCRN"), ddpm_state_dict=weights("DiffUNet1"))
+    got = t.enhance_batch(wavs, x_T=x_T, trim_to_frames=True)
+    with torch.no_grad():
+        ref = R.enhance_ragged("GCRN", weights("GCRN"), weights("DiffUNet1"), wavs, x_T, params.noise_schedule,
+                               params.inference_noise_schedule, True, False)
+    for a, b, n in zip(got, ref, (3200, 2500, 1111)):
+        assert a.numel() == (n // 160) * 160 == b.numel()
+        assert rel_l2(a.cpu(), b) < 1e-4
+    full = t.enhance_batch(wavs, x_T=x_T)
+    assert [w.numel() for w in full] == [3200, 2500, 1111]
+    with pytest.raises(ValueError):
+        t.enhance_batch([torch.zeros(100)])
