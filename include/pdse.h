@@ -185,6 +185,20 @@ typedef struct pdse_ola_desc {
   int32_t B, T, L, n_fft, hop, pad_;
 } pdse_ola_desc;
 
+/* forward noising of the training step, prior-grad parameterisation (trainer/complex_ddpm_trainer.py:707-727):
+ *   out[b] = a[b] * (label[b] - init[b]) + s[b] * noise[b],  a = sqrt(alpha_bar_t), s = sqrt(1 - alpha_bar_t)
+ * per batch item; every product/sum rounded separately like the reference's tensor ops. */
+typedef struct pdse_qsample_desc {
+  const float* label;
+  const float* init;
+  const float* noise;
+  const float* a; /* [B] */
+  const float* s; /* [B] */
+  float* out;
+  int64_t plane; /* elements per batch item */
+  int32_t B, pad_;
+} pdse_qsample_desc;
+
 /* per-(b,ch) abs-max mask of --sigma (:951-956): out = a * sqrt(|init|/max|init| / 2 + 0.5) */
 typedef struct pdse_sigma_desc {
   const float* init;
@@ -318,7 +332,8 @@ enum pdse_op_kind {
   PDSE_OP_ATTN = 11,
   PDSE_OP_GRU = 12,
   PDSE_OP_GNCOMB = 13,
-  PDSE_OP_AHAM = 14
+  PDSE_OP_AHAM = 14,
+  PDSE_OP_QSAMPLE = 15
 };
 
 int pdse_abi_version(void);
@@ -342,6 +357,7 @@ int pdse_attention_f32(const pdse_attn_desc* d, pdse_stream_t s);
 int pdse_bigru_f32(const pdse_gru_desc* d, pdse_stream_t s);
 int pdse_gn_combine_f32(const pdse_gncomb_desc* d, pdse_stream_t s);
 int pdse_aham_f32(const pdse_aham_desc* d, pdse_stream_t s);
+int pdse_qsample_f32(const pdse_qsample_desc* d, pdse_stream_t s);
 
 /* plans: a recorded operator sequence replayed by one call (and capturable in a hipGraph) */
 typedef struct pdse_plan pdse_plan;

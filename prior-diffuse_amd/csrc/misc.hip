@@ -339,3 +339,29 @@ int pdse_ln_launch(const pdse_ln_desc* d, hipStream_t s) {
   hipLaunchKernelGGL(ln_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, *d);
   return pdse_check_launch("layernorm");
 }
+
+// ---------------------------------------------------------------------------------------
+// q-sample of the training step (trainer/complex_ddpm_trainer.py:707-727, prior-grad branch):
+// per-item scalars, separately rounded operations (bit-exact with the reference's tensor ops).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void qsample_kernel(const pdse_qsample_desc d) {
+  const int b = blockIdx.y;
+  const float a = d.a[b], s = d.s[b];
+  const int64_t off = (int64_t)b * d.plane;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < d.plane; i += (int64_t)gridDim.x * 256) {
+#pragma clang fp contract(off)
+    const float diff = d.label[off + i] - d.init[off + i];
+    const float t1 = a * diff;
+    const float t2 = s * d.noise[off + i];
+    d.out[off + i] = t1 + t2;
+  }
+}
+
+int pdse_qsample_launch(const pdse_qsample_desc* d, hipStream_t s) {
+  REQ(d && d->label && d->init && d->noise && d->a && d->s && d->out, "qsample: null pointer");
+  REQ(d->B > 0 && d->B <= 65535 && d->plane > 0, "qsample: bad sizes");
+  int bx = (int)((d->plane + 255) / 256);
+  if (bx > 128) bx = 128;
+  hipLaunchKernelGGL(qsample_kernel, dim3(bx, d->B), dim3(256), 0, s, *d);
+  return pdse_check_launch("qsample");
+}

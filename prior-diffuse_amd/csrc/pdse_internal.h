@@ -26,4 +26,5 @@ int pdse_attn_launch(const pdse_attn_desc* d, hipStream_t s);
 int pdse_gru_launch(const pdse_gru_desc* d, hipStream_t s);
 int pdse_gncomb_launch(const pdse_gncomb_desc* d, hipStream_t s);
 int pdse_aham_launch(const pdse_aham_desc* d, hipStream_t s);
+int pdse_qsample_launch(const pdse_qsample_desc* d, hipStream_t s);
 #endif

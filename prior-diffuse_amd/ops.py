@@ -141,3 +141,32 @@ class AiaOp(_PlannedOp):
 
 
 PRIOR_OPS = {"GCRN": GCRNOp, "DiffUNet": DiffUNetOp, "aia_complex_trans_ri": AiaOp}
+
+
+def q_sample(label, init, t, noise, noise_schedule=None):
+    """Forward noising of the training step, prior-grad parameterisation (SURVEY §8f rank 4;
+    trainer/complex_ddpm_trainer.py:42-44, :704-727):
+
+        noisy = sqrt(alpha_bar_t) * (label - init) + sqrt(1 - alpha_bar_t) * noise,   t int64 [B]
+
+    ``label`` / ``init`` are already divided by 11 by the caller, like the reference.  Bit-exact with the
+    reference's fp32 tensor arithmetic (alpha_bar is the float32 cumprod the trainer keeps in ``noise_level``)."""
+    import numpy as np
+
+    from .params import params as _p
+
+    if label.device.type != "cuda":
+        raise L.PdseError("q_sample runs on the GPU only (no CPU fallback)")
+    beta = np.array(_p.noise_schedule if noise_schedule is None else noise_schedule)
+    noise_level = torch.tensor(np.cumprod(1 - beta).astype(np.float32), device=label.device)     # :42-44
+    ns = noise_level[t.to(label.device).long()]
+    a, s = ns ** 0.5, (1.0 - ns) ** 0.5
+    out = torch.empty_like(label)
+    d = L.QsampleDesc()
+    d.label, d.init, d.noise, d.out = label.data_ptr(), init.data_ptr(), noise.data_ptr(), out.data_ptr()
+    d.a, d.s, d.plane, d.B = a.data_ptr(), s.data_ptr(), label[0].numel(), label.shape[0]
+    for x in (label, init, noise):
+        if not x.is_contiguous() or x.dtype != torch.float32 or x.shape != label.shape:
+            raise ValueError("label, init, noise must be contiguous fp32 tensors of one shape")
+    L.launch(d, torch.cuda.current_stream(label.device).cuda_stream)
+    return out

@@ -483,3 +483,20 @@ def test_ragged_batch_validation_convention(L, weights, R):
     assert [w.numel() for w in full] == [3200, 2500, 1111]
     with pytest.raises(ValueError):
         t.enhance_batch([torch.zeros(100)])
+
+
+def test_q_sample_bit_exact_and_int_t_forward(L, weights):
+    """the training step's forward noising (bit-exact with the reference's tensor expression,
+    complex_ddpm_trainer.py:704-727) feeding the eps-net's integer-t path (diff3.py:70-71)."""
+    params = pkg("params").params
+    g = torch.Generator().manual_seed(5)
+    label, init, noise = (torch.randn(3, 2, 20, 161, generator=g) for _ in range(3))
+    t = torch.tensor([0, 17, 49])
+    noise_level = torch.tensor(np.cumprod(1 - np.array(params.noise_schedule)).astype(np.float32))
+    ns = noise_level[t].unsqueeze(1).unsqueeze(2).unsqueeze(3)
+    ref = ns ** 0.5 * (label - init) + (1.0 - ns) ** 0.5 * noise
+    got = pkg("ops").q_sample(label.to(DEV), init.to(DEV), t.to(DEV), noise.to(DEV))
+    _sync()
+    assert torch.equal(got.cpu(), ref)
+    eps = pkg("ops").DiffUNet1Op(weights("DiffUNet1"), DEV)(got, init.to(DEV), t.to(DEV))
+    assert eps.shape == label.shape and torch.isfinite(eps).all()
