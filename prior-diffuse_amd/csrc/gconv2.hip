@@ -342,7 +342,7 @@ int pdse_gconv2_launch(const pdse_gconv_desc* d, hipStream_t s) {
     if (nt == 1 && two && xf == 0) GO(PDSE_EPI_GLU, 1, 4, true, 0, true, true, true);
     if (nt == 2 && two && xf == 0) GO(PDSE_EPI_GLU, 2, 2, true, 0, true, true, true);
     if (nt == 3 && !two && xf == 0) GO(PDSE_EPI_GLU, 3, 4, false, 0, true, false, false);
-    if (nt == 5 && !two && xf == 2) GO(PDSE_EPI_GLU, 5, 4, false, 2, true, false, false);
+    if (nt == 5 && !two && xf == 2) GO(PDSE_EPI_GLU, 5, 4, false, 2, false, false, false);
   } else if (d->epi == PDSE_EPI_BIGLU && !two && xf == 0 && d->C2 <= 64 && d->w2 != nullptr) {
     // dual-phase transposed conv: kernel (2,3) -> 4 union taps, odd bins use taps {0,2};
     //                             kernel (2,5) -> 6 union taps, odd bins use taps {0,1,3,4}

@@ -255,6 +255,11 @@ class PipelinedSampler:
         self.n = 0
         self.done = [None] * depth      # event: batch in slot finished
         self.nsteps = self.pipes[0].nsteps
+        if by_batch and graph:          # capture every buffer set's graph now, not inside somebody's timed region
+            for p, st in zip(self.pipes, self.s_batch):
+                with torch.cuda.stream(st):
+                    p.plan.build_graph(st.cuda_stream)
+            torch.cuda.synchronize(self.device)
 
     def submit(self, wav, x_T):
         slot = self.n % self.depth
