@@ -180,6 +180,34 @@ def main():
                 "avg_launch_ms": round(eps_ms / max(1, sum(per_tag[k]["launches"] for k in ("eps_block", "eps_conv1", "tcm"))), 5),
                 "per_stage_ms": per_tag}
 
+    # ---- the single largest launch of the eps-net: algorithmic FLOPs from its descriptor / its own hipEvent time
+    lib = importlib.import_module("prior-diffuse_amd._lib")
+
+    def gconv_flops(d):
+        pos0 = d.B * d.Tout * d.Fout
+        accs = 1 if d.epi == lib.EPI_LINEAR else 2
+        cin = d.in0.C + d.in1.C
+        fl = 2.0 * pos0 * accs * (d.ntaps * cin) * d.Cout
+        if d.epi == lib.EPI_BIGLU:
+            tail = 2.0 * (2 * 32 * 32 + 32 * d.C2)
+            fl += pos0 * tail
+            if d.w2:
+                pos1 = d.B * d.Tout * d.Fout1
+                fl += 2.0 * pos1 * 2 * (bin(d.p1mask).count("1") * cin) * 32 + pos1 * tail
+        return fl
+
+    b0, e0 = pipe.ranges["step%d" % (pipe.nsteps - 1)]
+    ms_ops = [min(col) for col in zip(*[pipe.plan.time_ops(b0, e0, stream) for _ in range(3)])]
+    cand = [(ms_ops[i - b0], i) for i in range(b0, e0) if isinstance(pipe.descs[i][0], lib.GconvDesc)]
+    top_ms, top_i = max(cand)
+    top_d = pipe.descs[top_i][0]
+    top_tf = gconv_flops(top_d) / (top_ms * 1e-3) / 1e12
+    roofline["largest_launch"] = {
+        "kernel": "gconv2_kernel BIGLU%s, %d taps, %d -> 32 -> %d channels, %d x %d x %d positions" % (
+            " dual-phase" if top_d.w2 else "", top_d.ntaps, top_d.in0.C, top_d.C2, top_d.B, top_d.Tout, top_d.Fout),
+        "ms": round(top_ms, 4), "algorithmic_gflop": round(gconv_flops(top_d) / 1e9, 2),
+        "achieved": round(top_tf, 2), "frac": round(top_tf / FP32_MFMA_PEAK_TFLOPS, 4)}
+
     cpu = None
     if not args.no_cpu_baseline:
         from oracle import restate as R
