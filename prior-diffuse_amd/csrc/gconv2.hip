@@ -259,7 +259,8 @@ __global__ __launch_bounds__(256, PDSE_WAVES_PER_EU) void gconv2_kernel(const pd
   if (pvalid) d.out[(int64_t)b * d.out_sb + (int64_t)t * d.out_st + (int64_t)j * d.out_sf + d.out_off] = acc0[0][0] + (DUAL ? acc1[0][3] : 0.f);
 #else
   if constexpr (EPI == PDSE_EPI_BIGLU) {
-    __syncthreads();   // the tail operands staged at launch are in LDS by now
+    __syncthreads();   // the tail operands staged at launch are in LDS by now (fencing right after the copy
+                       // instead measured the same: the barrier is not what the tail costs)
     float* const sw = tail_lds;
     const pdse_tail tl{sw, sw + 1024, sw + 2048, sw + 4096, sw + 4128, sw + 4160, sw + 4192, sw + 4224,
                        d.post_scale ? sw + 4288 : nullptr, sw + 4352};

@@ -286,7 +286,7 @@ class EpsNetPlan(PlanBase):
                    chain=chain, out=out_t, out_strides=out_strides, B=B, Tout=T, Fout=Fout, tag=TAG_EPS_BLOCK)
         return Fout
 
-    def _biconvtransglu(self, step, slot, p, k, in0, in1, Fin, out_t, out_strides_fn, bn_prefix, prelu_key):
+    def _biconvtransglu(self, step, slot, p, k, in0, in1, Fin, out_t, out_strides_fn, bn_prefix, prelu_key, out_off=0):
         """Decoder stage (model/diff3.py:205-212 + :329-351, last frame chomped, BN, PReLU)."""
         B, T = self.B, self.T
         kw = 5 if k == 1 else 3
@@ -321,12 +321,12 @@ class EpsNetPlan(PlanBase):
             ph1 = dict(wk2=P.convT_kmat(self.sd[p + ".l.weight"], kk1), wk3=P.convT_kmat(self.sd[p + ".r.weight"], kk1),
                        mask=mask, ntaps1=len(taps1), Fout1=Fout // 2)
             self.gconv(in0=src_h, Tin=T, Fin=Fin, taps=taps0, sf_in=1, wk0=P.convT_kmat(self.sd[p + ".l.weight"], kk0),
-                       wk1=P.convT_kmat(self.sd[p + ".r.weight"], kk0), out_off=self._out_off, Fout=(Fout + 1) // 2,
+                       wk1=P.convT_kmat(self.sd[p + ".r.weight"], kk0), out_off=out_off, Fout=(Fout + 1) // 2,
                        phase1=ph1, **common)
         else:
             for phase, (kk, taps) in enumerate(((kk0, taps0), (kk1, taps1))):
                 self.gconv(in0=src_h, Tin=T, Fin=Fin, taps=taps, sf_in=1, wk0=P.convT_kmat(self.sd[p + ".l.weight"], kk),
-                           wk1=P.convT_kmat(self.sd[p + ".r.weight"], kk), out_off=phase * osf + self._out_off,
+                           wk1=P.convT_kmat(self.sd[p + ".r.weight"], kk), out_off=phase * osf + out_off,
                            Fout=(Fout - phase + 1) // 2, **common)
         return Fout
 
@@ -423,16 +423,14 @@ class EpsNetPlan(PlanBase):
                     in1 = self.src(skip, 64, *nchw(64, T, self.ENC_F[k]))
                 p = "%s.de%d.0" % (de, k)
                 if k > 1:
-                    o = self.dec[n & 1]
-                    self._out_off = 0
+                    o, ooff = self.dec[n & 1], 0
                     fn = lambda Fo: nchw_out(64, T, Fo)  # noqa: E731
                     bn, pr = "%s.de%d.2" % (de, k), "%s.de%d.3.weight" % (de, k)
                 else:
-                    o = out
-                    self._out_off = di * T * F0
+                    o, ooff = out, di * T * F0
                     fn = lambda Fo: nchw_out(2, T, Fo)   # noqa: E731
                     bn, pr = None, None
-                Fin = self._biconvtransglu(step, 5 + 5 * di + n, p, k, in0, in1, Fin, o, fn, bn, pr)
+                Fin = self._biconvtransglu(step, 5 + 5 * di + n, p, k, in0, in1, Fin, o, fn, bn, pr, out_off=ooff)
                 in0 = self.src(o, 64, *nchw(64, T, Fin))
         return out
 
