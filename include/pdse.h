@@ -286,6 +286,14 @@ typedef struct pdse_gru_desc {
   int32_t B, T, F, H, axis, pad_;
 } pdse_gru_desc;
 
+/* Swap the two inner axes of [N][R][Cc] -> [N][Cc][R] (fp32) through 32x32 LDS tiles: converts between the
+ * model's [B,C,T,F] layout and the frames-innermost [B,C,F,T] layout the row GRU / column attention run on. */
+typedef struct pdse_transpose_desc {
+  const float* in;
+  float* out;
+  int32_t N, R, Cc, pad_;
+} pdse_transpose_desc;
+
 /* GroupNorm(1,C) statistics + the AIA layer update (dbaiat.py:142,147-148):
  *   out = base + k1 * gn(row) + k2 * gn(col);  stats scratch [B][4] (sum,sumsq of row | col). */
 typedef struct pdse_gncomb_desc {
@@ -333,7 +341,8 @@ enum pdse_op_kind {
   PDSE_OP_GRU = 12,
   PDSE_OP_GNCOMB = 13,
   PDSE_OP_AHAM = 14,
-  PDSE_OP_QSAMPLE = 15
+  PDSE_OP_QSAMPLE = 15,
+  PDSE_OP_TRANSPOSE = 16
 };
 
 int pdse_abi_version(void);
@@ -358,6 +367,7 @@ int pdse_bigru_f32(const pdse_gru_desc* d, pdse_stream_t s);
 int pdse_gn_combine_f32(const pdse_gncomb_desc* d, pdse_stream_t s);
 int pdse_aham_f32(const pdse_aham_desc* d, pdse_stream_t s);
 int pdse_qsample_f32(const pdse_qsample_desc* d, pdse_stream_t s);
+int pdse_transpose_f32(const pdse_transpose_desc* d, pdse_stream_t s);
 
 /* plans: a recorded operator sequence replayed by one call (and capturable in a hipGraph) */
 typedef struct pdse_plan pdse_plan;

@@ -414,3 +414,33 @@ int pdse_aham_launch(const pdse_aham_desc* d, hipStream_t s) {
   hipLaunchKernelGGL(aham_merge_kernel, dim3(bx, d->B), dim3(256), 0, s, *d);
   return pdse_check_launch("aham");
 }
+
+// ---------------------------------------------------------------------------------------
+// [N][R][Cc] -> [N][Cc][R] through a padded 32x32 LDS tile: both the read and the write are
+// 128-byte row segments.  HBM-bound (one read + one write of the tensor).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_kernel(const pdse_transpose_desc d) {
+  __shared__ float tile[32][33];
+  const int n = blockIdx.z, r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  const float* src = d.in + (size_t)n * d.R * d.Cc;
+  float* dst = d.out + (size_t)n * d.R * d.Cc;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = r0 + ty + 8 * k, c = c0 + tx;
+    if (r < d.R && c < d.Cc) tile[ty + 8 * k][tx] = src[(size_t)r * d.Cc + c];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = c0 + ty + 8 * k, r = r0 + tx;
+    if (r < d.R && c < d.Cc) dst[(size_t)c * d.R + r] = tile[tx][ty + 8 * k];
+  }
+}
+
+int pdse_transpose_launch(const pdse_transpose_desc* d, hipStream_t s) {
+  REQ(d && d->in && d->out && d->in != d->out, "transpose: null or aliased pointers");
+  REQ(d->N > 0 && d->N <= 65535 && d->R > 0 && d->Cc > 0 && (d->R + 31) / 32 <= 65535, "transpose: bad sizes");
+  hipLaunchKernelGGL(transpose_kernel, dim3((d->Cc + 31) / 32, (d->R + 31) / 32, d->N), dim3(256), 0, s, *d);
+  return pdse_check_launch("transpose");
+}

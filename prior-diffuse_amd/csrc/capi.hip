@@ -40,6 +40,7 @@ union pdse_any_desc {
   pdse_gncomb_desc gncomb;
   pdse_aham_desc aham;
   pdse_qsample_desc qsample;
+  pdse_transpose_desc transpose;
 };
 
 struct pdse_op {
@@ -72,6 +73,7 @@ static int op_size(int kind) {
     case PDSE_OP_GNCOMB: return (int)sizeof(pdse_gncomb_desc);
     case PDSE_OP_AHAM: return (int)sizeof(pdse_aham_desc);
     case PDSE_OP_QSAMPLE: return (int)sizeof(pdse_qsample_desc);
+    case PDSE_OP_TRANSPOSE: return (int)sizeof(pdse_transpose_desc);
     default: return -1;
   }
 }
@@ -94,6 +96,7 @@ static int launch_op(const pdse_op& op, hipStream_t s) {
     case PDSE_OP_GNCOMB: return pdse_gncomb_launch(&op.d.gncomb, s);
     case PDSE_OP_AHAM: return pdse_aham_launch(&op.d.aham, s);
     case PDSE_OP_QSAMPLE: return pdse_qsample_launch(&op.d.qsample, s);
+    case PDSE_OP_TRANSPOSE: return pdse_transpose_launch(&op.d.transpose, s);
     default: pdse_set_error("plan: unknown op kind"); return 1;
   }
 }
@@ -120,6 +123,7 @@ int pdse_bigru_f32(const pdse_gru_desc* d, pdse_stream_t s) { return pdse_gru_la
 int pdse_gn_combine_f32(const pdse_gncomb_desc* d, pdse_stream_t s) { return pdse_gncomb_launch(d, (hipStream_t)s); }
 int pdse_aham_f32(const pdse_aham_desc* d, pdse_stream_t s) { return pdse_aham_launch(d, (hipStream_t)s); }
 int pdse_qsample_f32(const pdse_qsample_desc* d, pdse_stream_t s) { return pdse_qsample_launch(d, (hipStream_t)s); }
+int pdse_transpose_f32(const pdse_transpose_desc* d, pdse_stream_t s) { return pdse_transpose_launch(d, (hipStream_t)s); }
 
 int pdse_plan_create(pdse_plan** out) {
   if (!out) {

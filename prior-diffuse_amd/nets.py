@@ -657,6 +657,7 @@ class AiaPlan(PlanBase):
         self.gn_stats = a(B, 64, 4)
         self.means = a(4, B, 64)
         self.dec_up = a(B, 64, T, F0, zero=True)  # sub-pixel output; bin 0 is the left zero pad, never written
+        self.t_a, self.t_b, self.t_c = a(B, 32, FH, T), a(B, 32, FH, T), a(B, 32, FH, T)   # "ft" staging (frames innermost)
 
     def w(self, k):
         return P._np(self.sd[k])
@@ -668,6 +669,13 @@ class AiaPlan(PlanBase):
         d.gamma, d.beta = self.ctx.up(self.w(norm + ".weight")).data_ptr(), self.ctx.up(self.w(norm + ".bias")).data_ptr()
         d.slope = self.ctx.up(self.w(prelu + ".weight")).data_ptr()
         d.out_sb, d.B, d.C, d.T, d.F, d.eps = dst_sb, self.B, C_, self.T, F_, 1e-5
+        self.add(d, TAG_PRIOR)
+
+    def _swap(self, src, dst, to_ft):
+        """[B,32,T,F] <-> [B,32,F,T] (tile transpose, one read + one write of a 32-channel tensor)."""
+        d = L.TransposeDesc()
+        d.in_, d.out, d.N = src.data_ptr(), dst.data_ptr(), self.B * 32
+        d.R, d.Cc = (self.T, self.FH) if to_ft else (self.FH, self.T)
         self.add(d, TAG_PRIOR)
 
     def _chln(self, src, dst, norm):
@@ -695,8 +703,7 @@ class AiaPlan(PlanBase):
             return
         # lanes along t: the kernel's "frame" index is the bin f, its "bin" index is the frame t
         i_st, i_sf = (1, F_) if in_layout == "tf" else (T, 1)
-        o_st, o_sf = (1, F_) if out_layout == "tf" else (T, 1)
-        assert resid is None or out_layout == "tf"
+        o_st, o_sf = (1, F_) if out_layout == "tf" else (T, 1)     # the residual is addressed like the output
         self.gconv(in0=self.src(src_t, Cin, Cin * plane, plane, i_st, i_sf), Tin=F_, Fin=T, taps=[(0, 0)], sf_in=1,
                    wk0=wk, Cout=Cout, bias0=bias, act=act, act_slope=act_slope, xf=xf, resid=resid, out=out_t,
                    out_strides=(Cout * plane, plane, 0, o_st, o_sf), B=B, Tout=F_, Fout=T, tag=TAG_PRIOR)
@@ -730,20 +737,35 @@ class AiaPlan(PlanBase):
         bi[:32] *= 8 ** -0.5
         att_ft = axis == 1                                            # sequence over frames: operands in "ft"
         lay = "ft" if att_ft else "tf"
-        self._pw(self.n_a, 32, Wi.T, bi, self.qkv, 96, FH, out_layout=lay)
+        if att_ft:
+            # the whole attention sub-block runs frames-innermost: two tile transposes of 32-channel tensors
+            # (in: normed input and the residual; out: the sum) instead of lane-scattered 1x1 launches
+            self._swap(self.n_a, self.t_a, True)
+            self._swap(src_t, self.t_b, True)
+            qkv_in, res_in, s1_out = self.t_a, self.t_b, self.t_c
+        else:
+            qkv_in, res_in, s1_out = self.n_a, src_t, self.s1
+        self._pw(qkv_in, 32, Wi.T, bi, self.qkv, 96, FH, in_layout=lay, out_layout=lay)
         d = L.AttnDesc()
         d.qkv, d.out, d.B, d.E, d.heads, d.axis = self.qkv.data_ptr(), self.att.data_ptr(), B, 32, 4, 0
         d.T, d.F = (FH, T) if att_ft else (T, FH)                     # "ft": the innermost axis is the sequence either way
         self.add(d, TAG_PRIOR)
         self._pw(self.att, 32, self.w(p + ".self_attn.out_proj.weight").T, self.w(p + ".self_attn.out_proj.bias"),
-                 self.s1, 32, FH, resid=src_t, in_layout=lay)         # src + attention
+                 s1_out, 32, FH, resid=res_in, in_layout=lay, out_layout=lay)         # src + attention
+        if att_ft:
+            self._swap(self.t_c, self.s1, False)
         self._chln(self.s1, self.n_b, p + ".norm1")
         g = p + ".gru."
         Wih = np.concatenate([self.w(g + "weight_ih_l0"), self.w(g + "weight_ih_l0_reverse")], 0)   # [384, 32]
         bih = np.concatenate([self.w(g + "bias_ih_l0"), self.w(g + "bias_ih_l0_reverse")], 0)
         gru_ft = axis == 0                                            # sequence over bins: lines = frames -> "ft"
         lay = "ft" if gru_ft else "tf"
-        self._pw(self.n_b, 32, Wih.T, bih, self.gx, 384, FH, out_layout=lay)
+        if gru_ft:
+            self._swap(self.n_b, self.t_a, True)
+            gx_in, s2_out = self.t_a, self.t_b
+        else:
+            gx_in, s2_out = self.n_b, self.s2
+        self._pw(gx_in, 32, Wih.T, bih, self.gx, 384, FH, in_layout=lay, out_layout=lay)
         whh = np.stack([P.pack_a(self.w(g + "weight_hh_l0" + suf).T) for suf in ("", "_reverse")], 0)   # [2,6,32,64]
         bhh = np.stack([self.w(g + "bias_hh_l0"), self.w(g + "bias_hh_l0_reverse")], 0)
         gd = L.GruDesc()
@@ -754,8 +776,10 @@ class AiaPlan(PlanBase):
         self.add(gd, TAG_LSTM)
         # relu -> linear2 -> + residual (the normed tensor); ReLU = the load transform with slope 0, identity affine
         relu = dict(mode=1, scale0=np.ones(128), shift0=np.zeros(128), slope0=0.0)
-        self._pw(self.gy, 128, self.w(p + ".linear2.weight").T, self.w(p + ".linear2.bias"), self.s2, 32, FH,
-                 resid=self.n_b, xf=relu, in_layout=lay)
+        self._pw(self.gy, 128, self.w(p + ".linear2.weight").T, self.w(p + ".linear2.bias"), s2_out, 32, FH,
+                 resid=gx_in, xf=relu, in_layout=lay, out_layout=lay)
+        if gru_ft:
+            self._swap(self.t_b, self.s2, False)
         self._chln(self.s2, dst_t, p + ".norm2")
 
     def build(self, x=None, out=None):
