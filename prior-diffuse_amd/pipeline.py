@@ -23,6 +23,12 @@ from .schedule import inference_schedule, step_coefficients
 F0 = 161
 
 
+def _expect(t, like, name):
+    """Inputs must have exactly the geometry the plan was recorded for (``copy_`` would silently broadcast)."""
+    if tuple(t.shape) != tuple(like.shape) or t.dtype != like.dtype:
+        raise ValueError(f"{name}: expected {tuple(like.shape)} {like.dtype}, got {tuple(t.shape)} {t.dtype}")
+
+
 class SamplerPipeline:
     def __init__(self, device, prior_name, prior_sd, ddpm_sd, B, T=None, L_=None, fast_sampling=True,
                  use_sigma=False, params=default_params, with_signal=None, deltamu=False):
@@ -151,6 +157,8 @@ class SamplerPipeline:
     def sample(self, feat, x_T, graph=False):
         """feat, x_T [B,2,T,161] -> (enhanced compressed spectrogram, X_init); the
         spectrogram-level body of generate_wav (:939-998)."""
+        _expect(feat, self.feat, "feat")
+        _expect(x_T, self.xT_in, "x_T")
         self.feat.copy_(feat)
         self.xT_in.copy_(x_T)
         if graph and self.stft is None:
@@ -165,6 +173,8 @@ class SamplerPipeline:
         utils/dataset.py:45-58); default: every utterance fills L."""
         if self.stft is None:
             raise ValueError("pipeline was built without the signal front/back end (pass L_)")
+        _expect(wav, self.stft.wav, "wav")
+        _expect(x_T, self.xT_in, "x_T")
         self.stft.wav.copy_(wav)
         self.xT_in.copy_(x_T)
         if lens is None:

@@ -500,3 +500,20 @@ def test_q_sample_bit_exact_and_int_t_forward(L, weights):
     assert torch.equal(got.cpu(), ref)
     eps = pkg("ops").DiffUNet1Op(weights("DiffUNet1"), DEV)(got, init.to(DEV), t.to(DEV))
     assert eps.shape == label.shape and torch.isfinite(eps).all()
+
+
+def test_wrong_geometry_is_rejected(L, weights):
+    """A plan is recorded for one geometry: other shapes/dtypes raise instead of silently broadcasting."""
+    P = pkg("pipeline")
+    B, L_ = 2, 1600
+    pipe = P.SamplerPipeline(DEV, "GCRN", weights("GCRN"), weights("DiffUNet1"), B, L_=L_)
+    wav = torch.zeros(B, L_, device=DEV)
+    xT = torch.zeros(B, 2, pipe.T, 161, device=DEV)
+    with pytest.raises(ValueError):
+        pipe.enhance(wav[:1], xT)
+    with pytest.raises(ValueError):
+        pipe.enhance(wav, xT[:, :, :-1])
+    with pytest.raises(ValueError):
+        pipe.enhance(wav.double(), xT)
+    with pytest.raises(Exception):      # reflect padding needs more than 160 samples (torch.stft raises too)
+        P.SamplerPipeline(DEV, "GCRN", weights("GCRN"), weights("DiffUNet1"), 1, L_=160)
