@@ -565,6 +565,9 @@ class StftPlan(PlanBase):
 
     def __init__(self, ctx, B, L_, plan=None, normalize=True):
         super().__init__(ctx, plan)
+        if L_ <= 160:
+            raise ValueError(f"utterance of {L_} samples: the centred STFT reflects 160 samples on each side (torch.stft "
+                             "raises for the same input)")
         self.B, self.L = B, L_
         self.T = 1 + L_ // 160
         self.wav = ctx.alloc(B, L_)
