@@ -294,6 +294,33 @@ typedef struct pdse_transpose_desc {
   int32_t N, R, Cc, pad_;
 } pdse_transpose_desc;
 
+/* One dilated residual block of the eps-net's TCMs (model/diff3.py:215-257) over [B][256][T], fused with the
+ * NEXT block's 1x1 input convolution (csrc/tcm.hip):
+ *   g = main(BN(PReLU(h))) * sigmoid(mask(BN(PReLU(h))));  x_out = conv2(BN(PReLU(g))) + x;  h_out = conv1_next(x_out)
+ * h = conv1(x) comes from the previous launch (a 1x1 gconv for the first block).  h_out NULL: last block.
+ * Packed operands (prior-diffuse_amd/packing.py: pack_tcm_*):
+ *   wbr [2 mi][2 kh][20 g][2 main|mask][64 lanes][4]   K row 2*ks+h = tap*64 + channel, ks = 80*kh + 4*g + e
+ *   wc2 [8 mt][8 g][64 lanes][4]                        K row 2*(4*g+e)+h = gate channel
+ *   wn1 [4 w][2 q][2 mo][4 g][64 lanes][4]              K row = x channel 64*w + 32*q + rho(4*g+e, h)
+ *   xf  [2 main|mask][64][2 scale,shift]; xf2 [64][2]   (BatchNorm1d folded; PReLU slopes are scalars) */
+typedef struct pdse_tcm_desc {
+  const float* x;
+  const float* h;
+  float* x_out;      /* may alias x */
+  float* h_out;      /* must not alias h */
+  const float* wbr;
+  const float* bmain;
+  const float* bmask;
+  const float* xf;
+  const float* wc2;
+  const float* bc2;
+  const float* xf2;
+  const float* wn1;
+  const float* bn1;
+  float slope_main, slope_mask, slope2;
+  int32_t dil, B, T;
+} pdse_tcm_desc;
+
 /* GroupNorm(1,C) statistics + the AIA layer update (dbaiat.py:142,147-148):
  *   out = base + k1 * gn(row) + k2 * gn(col);  stats scratch [B][4] (sum,sumsq of row | col). */
 typedef struct pdse_gncomb_desc {
@@ -342,7 +369,8 @@ enum pdse_op_kind {
   PDSE_OP_GNCOMB = 13,
   PDSE_OP_AHAM = 14,
   PDSE_OP_QSAMPLE = 15,
-  PDSE_OP_TRANSPOSE = 16
+  PDSE_OP_TRANSPOSE = 16,
+  PDSE_OP_TCM = 17
 };
 
 int pdse_abi_version(void);
@@ -368,6 +396,7 @@ int pdse_gn_combine_f32(const pdse_gncomb_desc* d, pdse_stream_t s);
 int pdse_aham_f32(const pdse_aham_desc* d, pdse_stream_t s);
 int pdse_qsample_f32(const pdse_qsample_desc* d, pdse_stream_t s);
 int pdse_transpose_f32(const pdse_transpose_desc* d, pdse_stream_t s);
+int pdse_tcm_f32(const pdse_tcm_desc* d, pdse_stream_t s);
 
 /* plans: a recorded operator sequence replayed by one call (and capturable in a hipGraph) */
 typedef struct pdse_plan pdse_plan;

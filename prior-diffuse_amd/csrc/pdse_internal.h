@@ -28,4 +28,5 @@ int pdse_gncomb_launch(const pdse_gncomb_desc* d, hipStream_t s);
 int pdse_aham_launch(const pdse_aham_desc* d, hipStream_t s);
 int pdse_qsample_launch(const pdse_qsample_desc* d, hipStream_t s);
 int pdse_transpose_launch(const pdse_transpose_desc* d, hipStream_t s);
+int pdse_tcm_launch(const pdse_tcm_desc* d, hipStream_t s);
 #endif

@@ -159,6 +159,7 @@ class EpsNetPlan(PlanBase):
     """
 
     ENC_F = [161, 79, 39, 19, 9, 4]
+    fused_tcm = True        # one launch per TCM residual block (csrc/tcm.hip); False: three gather-GEMM launches
     NSLOT = 16  # 15 stages + en1 real-row bias
 
     def __init__(self, ctx, sd, B, T, time_cond=True, nsteps=1, plan=None, table=None, with_pre=None):
@@ -330,28 +331,34 @@ class EpsNetPlan(PlanBase):
                            Fout=(Fout - phase + 1) // 2, **common)
         return Fout
 
-    def _residual(self, p, dil, xin, xout):
-        """TCM residual block (model/diff3.py:215-257) over [B,256,T] (T on the lanes)."""
+    def _tcm_conv1(self, p, xin, hout):
+        """The 1x1 input convolution of a TCM residual block (diff3.py:223) as its own launch."""
         B, T = self.B, self.T
-        s256 = (256 * T, T, 0, 1)       # sb, sc, st, sf  ("bin" axis = time)
-        s64 = (64 * T, T, 0, 1)
-        o256 = (256 * T, T, 0, 0, 1)    # out_sb, sc_hi, sc_lo, st, sf
-        o64 = (64 * T, T, 0, 0, 1)
-        self.gconv(in0=self.src(xin, 256, *s256), Tin=1, Fin=T, taps=[(0, 0)], sf_in=1,
+        self.gconv(in0=self.src(xin, 256, 256 * T, T, 0, 1), Tin=1, Fin=T, taps=[(0, 0)], sf_in=1,
                    wk0=self.w(p + ".conv1.weight")[:, :, 0].T, Cout=64, bias0=self.w(p + ".conv1.bias"),
-                   out=self.tcm_h, out_strides=o64, B=B, Tout=1, Fout=T, tag=TAG_TCM)
-        taps = [(0, (k - 2) * dil) for k in range(5)]
+                   out=hout, out_strides=(64 * T, T, 0, 0, 1), B=B, Tout=1, Fout=T, tag=TAG_TCM)
 
+    def _tcm_branch_mats(self, p):
         def km(br):
             w = self.w(p + "." + br + ".2.weight")                          # [64, 64, 5]
             return np.concatenate([w[:, :, k].T for k in range(5)], axis=0)
+        return km("mainbranch"), km("maskbranch")
 
+    def _residual(self, p, dil, xin, xout):
+        """TCM residual block (model/diff3.py:215-257) over [B,256,T] (T on the lanes): three launches."""
+        B, T = self.B, self.T
+        s64 = (64 * T, T, 0, 1)
+        o256 = (256 * T, T, 0, 0, 1)    # out_sb, sc_hi, sc_lo, st, sf
+        o64 = (64 * T, T, 0, 0, 1)
+        self._tcm_conv1(p, xin, self.tcm_h)
+        taps = [(0, (k - 2) * dil) for k in range(5)]
+        kmain, kmask = self._tcm_branch_mats(p)
         sm, hm = P.bn_fold(self.sd, p + ".mainbranch.1")
         sk, hk = P.bn_fold(self.sd, p + ".maskbranch.1")
         xf = dict(mode=2, scale0=sm, shift0=hm, slope0=self.w(p + ".mainbranch.0.weight")[0],
                   scale1=sk, shift1=hk, slope1=self.w(p + ".maskbranch.0.weight")[0])
-        self.gconv(in0=self.src(self.tcm_h, 64, *s64), Tin=1, Fin=T, taps=taps, sf_in=1, wk0=km("mainbranch"),
-                   wk1=km("maskbranch"), Cout=64, bias0=self.w(p + ".mainbranch.2.bias"),
+        self.gconv(in0=self.src(self.tcm_h, 64, *s64), Tin=1, Fin=T, taps=taps, sf_in=1, wk0=kmain,
+                   wk1=kmask, Cout=64, bias0=self.w(p + ".mainbranch.2.bias"),
                    bias1=self.w(p + ".maskbranch.2.bias"), epi=L.EPI_GLU, xf=xf, out=self.tcm_g,
                    out_strides=o64, B=B, Tout=1, Fout=T, tag=TAG_TCM)
         s2, h2 = P.bn_fold(self.sd, p + ".conv2.1")
@@ -359,6 +366,33 @@ class EpsNetPlan(PlanBase):
         self.gconv(in0=self.src(self.tcm_g, 64, *s64), Tin=1, Fin=T, taps=[(0, 0)], sf_in=1,
                    wk0=self.w(p + ".conv2.2.weight")[:, :, 0].T, Cout=256, bias0=self.w(p + ".conv2.2.bias"),
                    xf=xf2, resid=xin, out=xout, out_strides=o256, B=B, Tout=1, Fout=T, tag=TAG_TCM)
+
+    def _residual_fused(self, p, dil, xin, xout, hin, hout, p_next):
+        """The same block as ONE launch (csrc/tcm.hip): dilated branches + gate + conv2 + residual, and the next
+        block's conv1 (``p_next``; None for the last block) chained onto the fresh x in registers."""
+        up = self.ctx.up
+        kmain, kmask = self._tcm_branch_mats(p)
+        sm, hm = P.bn_fold(self.sd, p + ".mainbranch.1")
+        sk, hk = P.bn_fold(self.sd, p + ".maskbranch.1")
+        s2, h2 = P.bn_fold(self.sd, p + ".conv2.1")
+        d = L.TcmDesc()
+        d.x, d.h, d.x_out = xin.data_ptr(), hin.data_ptr(), xout.data_ptr()
+        d.wbr = up(P.pack_tcm_branch(kmain, kmask)).data_ptr()
+        d.bmain = up(self.w(p + ".mainbranch.2.bias")).data_ptr()
+        d.bmask = up(self.w(p + ".maskbranch.2.bias")).data_ptr()
+        d.xf = up(np.stack([np.stack([sm, hm], 1), np.stack([sk, hk], 1)], 0).astype(np.float32)).data_ptr()
+        d.wc2 = up(P.pack_tcm_conv2(self.w(p + ".conv2.2.weight")[:, :, 0].T)).data_ptr()
+        d.bc2 = up(self.w(p + ".conv2.2.bias")).data_ptr()
+        d.xf2 = up(np.stack([s2, h2], 1).astype(np.float32)).data_ptr()
+        if p_next is not None:
+            d.h_out = hout.data_ptr()
+            d.wn1 = up(P.pack_tcm_next(self.w(p_next + ".conv1.weight")[:, :, 0])).data_ptr()
+            d.bn1 = up(self.w(p_next + ".conv1.bias")).data_ptr()
+        d.slope_main = float(self.w(p + ".mainbranch.0.weight")[0])
+        d.slope_mask = float(self.w(p + ".maskbranch.0.weight")[0])
+        d.slope2 = float(self.w(p + ".conv2.0.weight")[0])
+        d.dil, d.B, d.T = dil, self.B, self.T
+        self.add(d, TAG_TCM)
 
     def build_step(self, step=0, x=None, x_init=None, out=None):
         """Append one forward.  x / x_init / out default to the plan's own buffers.
@@ -406,10 +440,20 @@ class EpsNetPlan(PlanBase):
             src_x, src_i = self.src(o, 64, *nchw(64, T, Fin)), None
         # TCMs over [B,256,T]
         cur, nxt = self.en[4], self.tcm_a
-        for i in range(3):
-            for j, dil in enumerate((1, 2, 4, 8, 16, 32)):
-                self._residual("TCMs.%d.residual%d" % (i, j + 1), dil, cur, nxt)
+        names = [("TCMs.%d.residual%d" % (i, j + 1), dil) for i in range(3) for j, dil in enumerate((1, 2, 4, 8, 16, 32))]
+        if self.force_generic or not self.fused_tcm:
+            for p, dil in names:
+                self._residual(p, dil, cur, nxt)
                 cur, nxt = nxt, (self.tcm_b if nxt is self.tcm_a else self.tcm_a)
+        else:
+            # one launch per block; each also produces the next block's conv1 output (h ping-pongs: halo reads)
+            hcur, hnxt = self.tcm_h, self.tcm_g
+            self._tcm_conv1(names[0][0], cur, hcur)
+            for n, (p, dil) in enumerate(names):
+                p_next = names[n + 1][0] if n + 1 < len(names) else None
+                self._residual_fused(p, dil, cur, nxt, hcur, hnxt, p_next)
+                cur, nxt = nxt, (self.tcm_b if nxt is self.tcm_a else self.tcm_a)
+                hcur, hnxt = hnxt, hcur
         tcm_out = cur
         # decoders
         for di, de in enumerate(("de_real", "de_imag")):

@@ -185,3 +185,40 @@ def istft_kmat(n_fft=320):
     out[0::2] = re
     out[1::2] = im
     return out
+
+
+# ------------------------------------------------------------------------------------------
+# fused TCM residual block (csrc/tcm.hip, include/pdse.h: pdse_tcm_desc)
+# ------------------------------------------------------------------------------------------
+_RHO = np.array([[(r & 3) + 8 * (r >> 2) + 4 * h for h in (0, 1)] for r in range(16)])
+
+
+def pack_tcm_branch(k_main, k_mask):
+    """k_* [320, 64] (row = tap*64 + channel) -> [2 mi][2 kh][20 g][2][64 lanes][4]."""
+    out = np.zeros((2, 2, 20, 2, 64, 4), np.float32)
+    for which, km in enumerate((k_main, k_mask)):
+        km = np.asarray(km, np.float32).reshape(160, 2, 2, 32)            # [ks, h, mi, col]
+        km = km.reshape(2, 20, 4, 2, 2, 32)                               # [kh, g, e, h, mi, col]
+        out[:, :, :, which] = km.transpose(4, 0, 1, 3, 5, 2).reshape(2, 2, 20, 64, 4)
+    return out
+
+
+def pack_tcm_conv2(k2):
+    """k2 [64, 256] (row = gate channel) -> [8 mt][8 g][64 lanes][4]."""
+    k = np.asarray(k2, np.float32).reshape(8, 4, 2, 8, 32)                # [g, e, h, mt, col]
+    return np.ascontiguousarray(k.transpose(3, 0, 2, 4, 1).reshape(8, 8, 64, 4))
+
+
+def pack_tcm_next(w1):
+    """w1 [64 out, 256 in] -> [4 w][2 q][2 mo][4 g][64 lanes][4]: K row = 64*w + 32*q + rho(4*g+e, h)."""
+    w1 = np.asarray(w1, np.float32)
+    out = np.zeros((4, 2, 2, 4, 2, 32, 4), np.float32)                    # [w, q, mo, g, h, col, e]
+    for g in range(4):
+        for e in range(4):
+            for h in (0, 1):
+                rows = _RHO[4 * g + e, h]
+                for w in range(4):
+                    for q in range(2):
+                        cin = 64 * w + 32 * q + rows
+                        out[w, q, :, g, h, :, e] = w1[:, cin].reshape(2, 32)
+    return out.reshape(4, 2, 2, 4, 64, 4)

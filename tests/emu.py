@@ -329,7 +329,44 @@ def run_lstm(d, mem):
             yflat[idx] = h
 
 
-RUNNERS = {L.GconvDesc: run_gconv, L.TimeDesc: run_time, L.EwDesc: run_ew, L.CompandDesc: run_compand,
+def run_tcm(d, mem):
+    """pdse_tcm_desc: fused TCM residual block + the next block's conv1, from the packed operands."""
+    B, T, dil = d.B, d.T, d.dil
+    x = mem.arr(d.x, B * 256 * T).reshape(B, 256, T).astype(np.float64)
+    h = mem.arr(d.h, B * 64 * T).reshape(B, 64, T).astype(np.float64)
+    wbr = mem.arr(d.wbr, 2 * 2 * 20 * 2 * 64 * 4).reshape(2, 2, 20, 2, 2, 32, 4)      # [mi, kh, g, which, hh, col, e]
+    km = wbr.transpose(3, 1, 2, 6, 4, 0, 5).reshape(2, 320, 64)                       # [which][(kh,g,e,hh)][(mi,col)]
+    xf = mem.arr(d.xf, 256).reshape(2, 64, 2)
+    xf2 = mem.arr(d.xf2, 128).reshape(64, 2)
+    pre = []
+    for which, slope in ((0, d.slope_main), (1, d.slope_mask)):
+        v = np.where(h > 0, h, np.float32(slope) * h) * xf[which, :, 0][None, :, None] + xf[which, :, 1][None, :, None]
+        vp = np.zeros((B, 64, T + 4 * dil))
+        vp[:, :, 2 * dil:2 * dil + T] = v
+        cols = np.concatenate([vp[:, :, k * dil:k * dil + T] for k in range(5)], axis=1)   # [B, 320, T], row = tap*64 + c
+        pre.append(np.einsum("bkt,ko->bot", cols, km[which]))
+    main = pre[0] + mem.arr(d.bmain, 64)[None, :, None]
+    mask = pre[1] + mem.arr(d.bmask, 64)[None, :, None]
+    g = main * _sig(mask)
+    g = np.where(g > 0, g, np.float32(d.slope2) * g) * xf2[:, 0][None, :, None] + xf2[:, 1][None, :, None]
+    wc2 = mem.arr(d.wc2, 8 * 8 * 64 * 4).reshape(8, 8, 2, 32, 4)                      # [mt, g, hh, col, e]
+    k2 = wc2.transpose(1, 4, 2, 0, 3).reshape(64, 256)                                # [(g,e,hh)][(mt,col)]
+    xo = np.einsum("bkt,ko->bot", g, k2) + mem.arr(d.bc2, 256)[None, :, None] + x
+    if d.h_out:
+        wn = mem.arr(d.wn1, 4 * 2 * 2 * 4 * 64 * 4).reshape(4, 2, 2, 4, 2, 32, 4)     # [w, q, mo, g, hh, col, e]
+        w1 = np.zeros((64, 256))
+        for gi in range(4):
+            for e in range(4):
+                for hh in (0, 1):
+                    for w in range(4):
+                        for q in range(2):
+                            w1[:, 64 * w + 32 * q + RHO[4 * gi + e, hh]] = wn[w, q, :, gi, hh, :, e].reshape(64)
+        ho = np.einsum("bkt,ok->bot", xo, w1) + mem.arr(d.bn1, 64)[None, :, None]
+        mem.arr(d.h_out, B * 64 * T)[:] = ho.astype(np.float32).reshape(-1)
+    mem.arr(d.x_out, B * 256 * T)[:] = xo.astype(np.float32).reshape(-1)
+
+
+RUNNERS = {L.TcmDesc: run_tcm, L.GconvDesc: run_gconv, L.TimeDesc: run_time, L.EwDesc: run_ew, L.CompandDesc: run_compand,
            L.WavprepDesc: run_wavprep, L.OlaDesc: run_ola, L.SigmaDesc: run_sigma, L.LnDesc: run_ln,
            L.LstmDesc: run_lstm}
 

@@ -114,7 +114,12 @@ def test_step_descriptors_are_cloned_not_repacked(weights):
     assert len(second) == len(first)
     delta = 2 * 1 * net.NSLOT * 32 * 4
     moved = 0
+    L = pkg("_lib")
     for a, b in zip(first, second):
+        assert type(a) is type(b)
+        if isinstance(a, L.TcmDesc):                       # fused TCM blocks carry no time bias: identical clones
+            assert bytes(a) == bytes(b)
+            continue
         assert a.w0 == b.w0 and a.out == b.out
         if a.bias0 != b.bias0:
             assert b.bias0 - a.bias0 == delta

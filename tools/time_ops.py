@@ -34,4 +34,19 @@ sel = [i for i, (d, tag) in enumerate(net.descs) if tag == nets.TAG_EPS_BLOCK][:
       [i for i, (d, tag) in enumerate(net.descs) if tag == nets.TAG_TCM][:3] + \
       [i for i, (d, tag) in enumerate(net.descs) if tag == nets.TAG_EPS_CONV1][:3]
 print(os.environ.get("PDSE_LIB", "default"), " total %.0f us" % sum(med), {k: round(v) for k, v in tot.items()})
-print("   ", " ".join("%s%d:nt%d=%.0f" % (names.get(net.descs[i][1], "?")[0], i, net.descs[i][0].ntaps, med[i]) for i in sel))
+print("   ", " ".join("%s%d:nt%d=%.0f" % (names.get(net.descs[i][1], "?")[0], i, getattr(net.descs[i][0], "ntaps", 0), med[i]) for i in sel))
+
+# hot-cache repeat of single launches (same weights every time): separates cold-operand latency from the kernel itself
+if os.environ.get("HOT"):
+    st = torch.cuda.current_stream()
+    for i in [i for i, (d, tag) in enumerate(net.descs) if tag == nets.TAG_TCM][:4]:
+        d = net.descs[i][0]
+        for _ in range(5):
+            L.launch(d, st.cuda_stream)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(200):
+            L.launch(d, st.cuda_stream)
+        e1.record()
+        torch.cuda.synchronize()
+        print("hot  op %d (%s): %.1f us per launch" % (i, type(d).__name__, e0.elapsed_time(e1) * 5))
