@@ -202,6 +202,29 @@ def main():
                  row0=caps["row0"].numpy(), col0=caps["col0"].numpy(), trans_last_c8=caps["trans"][0][:, ::8].numpy(),
                  aham_c8=caps["aham"][:, ::8].numpy(), out=outa.numpy())
 
+        # ---- A3'' dual-branch DB-AIAT prior (dual_aia_trans_merge_crm), with intermediates
+        dual = ref.dbaiat.dual_aia_trans_merge_crm()
+        dual.load_state_dict(synth.make_state_dict("dual_aia_trans_merge_crm", 1234), strict=True)
+        dual.eval()
+        xd = seeded((2, 2, 12, 161), 71)
+        caps = {}
+        hk = [dual.en_ri.register_forward_hook(lambda m, i, o: caps.__setitem__("en_ri", o)),
+              dual.en_mag.register_forward_hook(lambda m, i, o: caps.__setitem__("en_mag", o)),
+              dual.aia_trans_merge.register_forward_hook(lambda m, i, o: caps.__setitem__("trans", o)),
+              dual.aham.register_forward_hook(lambda m, i, o: caps.__setitem__("aham", o)),
+              dual.aham_mag.register_forward_hook(lambda m, i, o: caps.__setitem__("aham_mag", o)),
+              dual.de_mag_mask.register_forward_hook(lambda m, i, o: caps.__setitem__("mask", o))]
+        outdual = dual(xd)
+        for h in hk:
+            h.remove()
+        print("dual out rms %.3f en_mag %.3f trans_last mag %.3f ri %.3f aham %.3f mask mean %.3f std %.3f" % (
+            outdual.pow(2).mean().sqrt(), caps["en_mag"].pow(2).mean().sqrt(), caps["trans"][0].pow(2).mean().sqrt(),
+            caps["trans"][2].pow(2).mean().sqrt(), caps["aham"].pow(2).mean().sqrt(), caps["mask"].mean(), caps["mask"].std()))
+        np.savez(os.path.join(OUT, "dual_aia_small.npz"), seed_x=71, en_ri_c8=caps["en_ri"][:, ::8].numpy(),
+                 en_mag_c8=caps["en_mag"][:, ::8].numpy(), trans_last_mag_c8=caps["trans"][0][:, ::8].numpy(),
+                 trans_last_ri_c8=caps["trans"][2][:, ::8].numpy(), aham_c8=caps["aham"][:, ::8].numpy(),
+                 aham_mag_c8=caps["aham_mag"][:, ::8].numpy(), mask=caps["mask"].numpy(), out=outdual.numpy())
+
         # ---- A4/A5 reverse-loop traces with injected x_T: the reference's own loop
         # body (trainer/complex_ddpm_trainer.py:964-998) driven on the real modules
         nocon = ref.nocon.Nocon(ref.params)

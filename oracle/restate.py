@@ -436,13 +436,13 @@ def dense_block(sd, p, x):
     return out
 
 
-def dense_encoder(sd, x):
-    """reference: model/dbaiat.py:481-501."""
-    out = F.conv2d(x, sd["en_ri.inp_conv.weight"], sd["en_ri.inp_conv.bias"])
-    out = F.prelu(_ln_last(sd, "en_ri.inp_norm", out), sd["en_ri.inp_prelu.weight"])
-    out = dense_block(sd, "en_ri.enc_dense1", out)
-    out = F.conv2d(out, sd["en_ri.enc_conv1.weight"], sd["en_ri.enc_conv1.bias"], stride=(1, 2))
-    return F.prelu(_ln_last(sd, "en_ri.enc_norm1", out), sd["en_ri.enc_prelu1.weight"])
+def dense_encoder(sd, x, p="en_ri"):
+    """reference: model/dbaiat.py:481-501 (dense_encoder) and :504-524 (dense_encoder_mag: one input channel)."""
+    out = F.conv2d(x, sd[p + ".inp_conv.weight"], sd[p + ".inp_conv.bias"])
+    out = F.prelu(_ln_last(sd, p + ".inp_norm", out), sd[p + ".inp_prelu.weight"])
+    out = dense_block(sd, p + ".enc_dense1", out)
+    out = F.conv2d(out, sd[p + ".enc_conv1.weight"], sd[p + ".enc_conv1.bias"], stride=(1, 2))
+    return F.prelu(_ln_last(sd, p + ".enc_norm1", out), sd[p + ".enc_prelu1.weight"])
 
 
 def gru_layer(x, w_ih, w_hh, b_ih, b_hh, reverse=False):
@@ -519,9 +519,10 @@ def aia_transformer(sd, x, taps=None):
     return outs
 
 
-def aham(sd, outs):
-    """reference: model/dbaiat.py:266-288 — softmax over the 4 layer outputs of conv1(avgpool(x_i))."""
-    ys = [F.conv2d(o.mean(dim=(2, 3), keepdim=True), sd["aham.conv1.weight"], sd["aham.conv1.bias"]) for o in outs]
+def aham(sd, outs, p="aham"):
+    """reference: model/dbaiat.py:266-288 (AHAM) / :308-330 (AHAM_ori, same arithmetic) — softmax over the 4 layer
+    outputs of conv1(avgpool(x_i))."""
+    ys = [F.conv2d(o.mean(dim=(2, 3), keepdim=True), sd[p + ".conv1.weight"], sd[p + ".conv1.bias"]) for o in outs]
     w = torch.softmax(torch.cat(ys, dim=1), dim=1)                  # [B,4,1,1]
     merged = sum(w[:, i:i + 1] * outs[i] for i in range(4))
     return outs[-1] + merged
@@ -551,6 +552,75 @@ def aia_complex_trans_ri_forward(sd, x, taps=None):
 
 
 PRIORS["aia_complex_trans_ri"] = aia_complex_trans_ri_forward
+
+
+# --------------------------------------------------------------------------
+# A3''  dual-branch prior dual_aia_trans_merge_crm  (reference: model/dbaiat.py:373-413)
+# --------------------------------------------------------------------------
+def aia_transformer_merge(sd, x_mag, x_ri, p="aia_trans_merge"):
+    """reference: model/dbaiat.py:200-246 (AIA_Transformer_merge.forward), both branches as written there:
+    layer i of either branch reads, for i >= 1, the SUM of the two branches' previous outputs, and adds its
+    normalised row/column results to the shared input projection (not to a running state)."""
+    b, c, dim2, dim1 = x_mag.shape
+    merge = torch.cat((x_mag, x_ri), dim=1)
+    inp = F.prelu(F.conv2d(merge, sd[p + ".input.0.weight"], sd[p + ".input.0.bias"]), sd[p + ".input.1.weight"])
+    input_mag, input_ri = inp, inp                                   # the same module applied to the same tensor (:206-207)
+
+    def layer(i, u, base):
+        row_in = u.permute(3, 0, 2, 1).contiguous().view(dim1, b * dim2, -1)
+        row = aia_encoder_layer(sd, "%s.row_trans.%d" % (p, i), row_in)
+        row = row.view(dim1, b, dim2, -1).permute(1, 3, 2, 0).contiguous()
+        row = F.group_norm(row, 1, sd["%s.row_norm.%d.weight" % (p, i)], sd["%s.row_norm.%d.bias" % (p, i)], 1e-8)
+        col_in = u.permute(2, 0, 3, 1).contiguous().view(dim2, b * dim1, -1)
+        col = aia_encoder_layer(sd, "%s.col_trans.%d" % (p, i), col_in)
+        col = col.view(dim2, b, dim1, -1).permute(1, 3, 0, 2).contiguous()
+        col = F.group_norm(col, 1, sd["%s.col_norm.%d.weight" % (p, i)], sd["%s.col_norm.%d.bias" % (p, i)], 1e-8)
+        o = base + sd[p + ".k1"] * row + sd[p + ".k2"] * col
+        return F.conv2d(F.prelu(o, sd[p + ".output.0.weight"]), sd[p + ".output.1.weight"], sd[p + ".output.1.bias"])
+
+    list_mag, list_ri = [], []
+    for i in range(4):
+        u_mag = input_mag if i == 0 else list_mag[-1] + list_ri[-1]
+        list_mag.append(layer(i, u_mag, input_mag))
+        u_ri = input_ri if i == 0 else list_ri[-1] + list_mag[-2]
+        list_ri.append(layer(i, u_ri, input_ri))
+    return list_mag, list_ri
+
+
+def dense_decoder_masking(sd, p, x):
+    """reference: model/dbaiat.py:551-584 — dense block, sub-pixel up-convolution, LayerNorm/PReLU, 64->1, then the
+    scalar gate sigmoid(maskconv(sigmoid(mask1(o)) * tanh(mask2(o))))."""
+    out = dense_block(sd, p + ".dec_dense1", x)
+    out = F.conv2d(F.pad(out, (1, 1, 0, 0)), sd[p + ".dec_conv1.conv.weight"], sd[p + ".dec_conv1.conv.bias"])
+    bsz, nch, H, W = out.shape
+    out = out.view(bsz, 2, nch // 2, H, W).permute(0, 2, 3, 4, 1).contiguous().view(bsz, nch // 2, H, -1)
+    out = F.pad(out, (1, 0, 0, 0))
+    out = F.prelu(_ln_last(sd, p + ".dec_norm1", out), sd[p + ".dec_prelu1.weight"])
+    out = F.conv2d(out, sd[p + ".out_conv.weight"], sd[p + ".out_conv.bias"])
+    m1 = torch.sigmoid(F.conv2d(out, sd[p + ".mask1.0.weight"], sd[p + ".mask1.0.bias"]))
+    m2 = torch.tanh(F.conv2d(out, sd[p + ".mask2.0.weight"], sd[p + ".mask2.0.bias"]))
+    return torch.sigmoid(F.conv2d(m1 * m2, sd[p + ".maskconv.weight"], sd[p + ".maskconv.bias"]))
+
+
+def dual_aia_trans_merge_crm_forward(sd, x, taps=None):
+    """reference: model/dbaiat.py:386-413."""
+    x_mag_ori = torch.norm(x, dim=1)
+    x_phase_ori = torch.atan2(x[:, -1], x[:, 0])
+    x_ri = dense_encoder(sd, x, "en_ri")
+    x_mag_en = dense_encoder(sd, x_mag_ori.unsqueeze(1), "en_mag")
+    list_mag, list_ri = aia_transformer_merge(sd, x_mag_en, x_ri)
+    m_ri = aham(sd, list_ri, "aham")
+    m_mag = aham(sd, list_mag, "aham_mag")
+    mask = dense_decoder_masking(sd, "de_mag_mask", m_mag).squeeze(1)
+    real = dense_decoder(sd, "de1", m_ri).squeeze(1)
+    imag = dense_decoder(sd, "de2", m_ri).squeeze(1)
+    if taps is not None:
+        taps.update(en_ri=x_ri, en_mag=x_mag_en, trans_last=list_ri[-1], aham=m_ri, aham_mag=m_mag, mask=mask)
+    x_mag_out = mask * x_mag_ori
+    return torch.stack((x_mag_out * torch.cos(x_phase_ori) + real, x_mag_out * torch.sin(x_phase_ori) + imag), dim=1)
+
+
+PRIORS["dual_aia_trans_merge_crm"] = dual_aia_trans_merge_crm_forward
 
 
 def enhance_ragged(prior_name, prior_sd, ddpm_sd, wavs, x_T, noise_schedule, inference_noise_schedule,

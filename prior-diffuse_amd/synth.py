@@ -191,24 +191,74 @@ def _dense_block(prefix, width_f):
     return out
 
 
-def _aia_layer(prefix):
-    # reference: model/dbaiat.py:41-88 (TransformerEncoderLayer, d_model 32, 4 heads, biGRU 32->64)
+def _aia_layer(prefix, d=32):
+    # reference: model/dbaiat.py:41-88 (TransformerEncoderLayer, d_model d, 4 heads, biGRU d -> 2d)
     out = [
-        (prefix + ".self_attn.in_proj_weight", (96, 32), "w", 32, 1.5),
-        (prefix + ".self_attn.in_proj_bias", (96,), "bias"),
+        (prefix + ".self_attn.in_proj_weight", (3 * d, d), "w", d, 1.5),
+        (prefix + ".self_attn.in_proj_bias", (3 * d,), "bias"),
     ]
-    out += _conv(prefix + ".self_attn.out_proj", (32, 32), 32, 1.0)
+    out += _conv(prefix + ".self_attn.out_proj", (d, d), d, 1.0)
     for suf in ("", "_reverse"):
         out += [
-            (prefix + ".gru.weight_ih_l0" + suf, (192, 32), "w", 32, 1.5),
-            (prefix + ".gru.weight_hh_l0" + suf, (192, 64), "w", 64, 1.5),
-            (prefix + ".gru.bias_ih_l0" + suf, (192,), "bias"),
-            (prefix + ".gru.bias_hh_l0" + suf, (192,), "bias"),
+            (prefix + ".gru.weight_ih_l0" + suf, (6 * d, d), "w", d, 1.5),
+            (prefix + ".gru.weight_hh_l0" + suf, (6 * d, 2 * d), "w", 2 * d, 1.5),
+            (prefix + ".gru.bias_ih_l0" + suf, (6 * d,), "bias"),
+            (prefix + ".gru.bias_hh_l0" + suf, (6 * d,), "bias"),
         ]
-    out += _conv(prefix + ".linear2", (32, 128), 128, 1.5)
+    out += _conv(prefix + ".linear2", (d, 4 * d), 4 * d, 1.5)
     for n in (1, 2, 3):
-        out += [(prefix + ".norm%d.weight" % n, (32,), "bn_w"), (prefix + ".norm%d.bias" % n, (32,), "bn_b")]
+        out += [(prefix + ".norm%d.weight" % n, (d,), "bn_w"), (prefix + ".norm%d.bias" % n, (d,), "bn_b")]
     return out
+
+
+def _dense_encoder(p, cin):
+    # reference: model/dbaiat.py:481-501 (cin 2) / :504-524 (cin 1)
+    spec = _conv(p + ".inp_conv", (64, cin, 1, 1), cin, 1.0)
+    spec += [(p + ".inp_norm.weight", (161,), "bn_w"), (p + ".inp_norm.bias", (161,), "bn_b"),
+             (p + ".inp_prelu.weight", (64,), "prelu")]
+    spec += _dense_block(p + ".enc_dense1", 161)
+    spec += _conv(p + ".enc_conv1", (64, 64, 1, 3), 64 * 3, 1.5)
+    spec += [(p + ".enc_norm1.weight", (80,), "bn_w"), (p + ".enc_norm1.bias", (80,), "bn_b"),
+             (p + ".enc_prelu1.weight", (64,), "prelu")]
+    return spec
+
+
+def _dense_decoder(de):
+    spec = _dense_block(de + ".dec_dense1", 80)
+    spec += _conv(de + ".dec_conv1.conv", (128, 64, 1, 3), 64 * 3, 1.5)
+    spec += [(de + ".dec_norm1.weight", (161,), "bn_w"), (de + ".dec_norm1.bias", (161,), "bn_b"),
+             (de + ".dec_prelu1.weight", (64,), "prelu")]
+    return spec
+
+
+def dual_aia_trans_merge_crm_spec():
+    """Ordered spec of the dual-branch DB-AIAT prior (reference: model/dbaiat.py:373-413): ri + magnitude encoders,
+    AIA_Transformer_merge (d_model 64, :157-246), two AHAM_ori, two dense decoders and the masking decoder (:551-584)."""
+    spec = _dense_encoder("en_ri", 2) + _dense_encoder("en_mag", 1)
+    p = "aia_trans_merge"
+    spec += [(p + ".k1", (1,), "gain1"), (p + ".k2", (1,), "gain1")]
+    spec += _conv(p + ".input.0", (64, 128, 1, 1), 128, 1.4)
+    spec += [(p + ".input.1.weight", (1,), "prelu")]
+    for kind in ("row_trans", "col_trans"):
+        for i in range(4):
+            spec += _aia_layer("%s.%s.%d" % (p, kind, i), 64)
+    for kind in ("row_norm", "col_norm"):
+        for i in range(4):
+            spec += [("%s.%s.%d.weight" % (p, kind, i), (64,), "bn_w"), ("%s.%s.%d.bias" % (p, kind, i), (64,), "bn_b")]
+    spec += [(p + ".output.0.weight", (1,), "prelu")]
+    spec += _conv(p + ".output.1", (64, 64, 1, 1), 64, 0.7)
+    for ah in ("aham", "aham_mag"):
+        spec += [(ah + ".k3", (1,), "gain1")]
+        spec += _conv(ah + ".conv1", (1, 64, 1, 1), 64, 4.0)
+    for de in ("de1", "de2"):
+        spec += _dense_decoder(de)
+        spec += _conv(de + ".out_conv", (1, 64, 1, 1), 64, 1.0)
+    de = "de_mag_mask"
+    spec += _dense_decoder(de)
+    for m in ("mask1.0", "mask2.0", "maskconv"):
+        spec += _conv("%s.%s" % (de, m), (1, 1, 1, 1), 1, 1.0)
+    spec += _conv(de + ".out_conv", (1, 64, 1, 1), 64, 1.0)
+    return spec
 
 
 def aia_complex_trans_ri_spec():
@@ -247,6 +297,7 @@ def aia_complex_trans_ri_spec():
 
 ARCH_SPECS = {
     "Nocon": nocon_spec,
+    "dual_aia_trans_merge_crm": dual_aia_trans_merge_crm_spec,
     "aia_complex_trans_ri": aia_complex_trans_ri_spec,
     "DiffUNet1": diffunet1_spec,
     "DiffUNet": diffunet_spec,

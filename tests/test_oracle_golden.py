@@ -191,6 +191,25 @@ def test_aia_prior_with_intermediates(weights):
     assert rel_l2(out, g["out"]) < 1e-5
 
 
+def test_dual_branch_aia_prior_with_intermediates(weights):
+    """Dual-branch DB-AIAT prior (model/dbaiat.py dual_aia_trans_merge_crm): magnitude encoder, the interacting
+    AIA_Transformer_merge (d_model 64), two AHAM merges, the masking decoder and the magnitude/phase recombination."""
+    g = golden("dual_aia_small")
+    sd = weights("dual_aia_trans_merge_crm")
+    taps = {}
+    with torch.no_grad():
+        out = R.dual_aia_trans_merge_crm_forward(sd, seeded((2, 2, 12, 161), g["seed_x"]), taps=taps)
+    assert rel_l2(taps["en_ri"][:, ::8], g["en_ri_c8"]) < TOL
+    assert rel_l2(taps["en_mag"][:, ::8], g["en_mag_c8"]) < TOL
+    assert rel_l2(taps["trans_last"][:, ::8], g["trans_last_ri_c8"]) < 1e-5
+    assert rel_l2(taps["aham"][:, ::8], g["aham_c8"]) < 1e-5
+    assert rel_l2(taps["aham_mag"][:, ::8], g["aham_mag_c8"]) < 1e-5
+    assert rel_l2(taps["mask"], g["mask"][:, 0]) < 1e-5
+    assert rel_l2(out, g["out"]) < 1e-5
+    # the reference's two branch lists carry the same values (layer i >= 1 of either branch reads the same sum)
+    assert np.array_equal(g["trans_last_mag_c8"], g["trans_last_ri_c8"])
+
+
 def test_nocon_and_deltamu_sampling(weights):
     """the deltamu parameterisation (Nocon eps-net, x_T = noise + X_init, no final + X_init)."""
     g0 = golden("diffunet1_small")
