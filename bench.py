@@ -39,7 +39,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=4.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--prior", default="GCRN", choices=["GCRN", "DiffUNet", "aia_complex_trans_ri"],
+    ap.add_argument("--prior", default="GCRN", choices=["GCRN", "DiffUNet", "aia_complex_trans_ri", "dual_aia_trans_merge_crm"],
                     help="discriminative prior (BASELINE configs 1-3: GCRN; config 4: aia_complex_trans_ri)")
     ap.add_argument("--inflight", type=int, default=3,
                     help="batches in flight, each on its own HIP stream (1: strictly sequential, hipGraph replay). "
@@ -216,7 +216,7 @@ def main():
         # the GPU box gives one GPU a 16-core share of the host; never oversubscribe it
         nthreads = max(1, min(16, len(os.sched_getaffinity(0))))
         torch.set_num_threads(nthreads)
-        cb = 16 if args.prior != "aia_complex_trans_ri" else 4   # about 10-15 s of host work
+        cb = 16 if "aia" not in args.prior else 4   # about 10-15 s of host work
         note("cpu baseline: oracle on %d host threads, %d utterances" % (nthreads, cb))
         w_cpu, x_cpu = synth.synthetic_waveforms(B * world, L_, seed=1234)
         w_cpu, x_cpu = w_cpu[:cb], x_cpu[:cb]

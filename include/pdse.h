@@ -294,6 +294,20 @@ typedef struct pdse_transpose_desc {
   int32_t N, R, Cc, pad_;
 } pdse_transpose_desc;
 
+/* Magnitude front end and complex-ratio-mask back end of the dual-branch DB-AIAT prior (model/dbaiat.py:389-411).
+ * mode 0: out[b][q] = sqrt(re^2 + im^2)                                  (torch.norm(x, dim=1), :389)
+ * mode 1: mask = sigmoid(a3 * (sigmoid(a1*o + b1) * tanh(a2*o + b2)) + b3)  (dense_decoder_masking :579-582)
+ *         out[b][0|1][q] = mask * |x| * cos|sin(atan2(im, re)) + ri[b][0|1][q]   (:407-409; cos/sin taken as re/|x|,
+ *         im/|x|, and 1, 0 where |x| = 0 as atan2(0,0) = 0) */
+typedef struct pdse_crm_desc {
+  const float* x;    /* [B][2][plane] */
+  const float* o;    /* [B][plane]      mode 1 */
+  const float* ri;   /* [B][2][plane]   mode 1 */
+  float* out;
+  float a1, b1, a2, b2, a3, b3;
+  int32_t plane, B, mode, pad_;
+} pdse_crm_desc;
+
 /* One dilated residual block of the eps-net's TCMs (model/diff3.py:215-257) over [B][256][T], fused with the
  * NEXT block's 1x1 input convolution (csrc/tcm.hip):
  *   g = main(BN(PReLU(h))) * sigmoid(mask(BN(PReLU(h))));  x_out = conv2(BN(PReLU(g))) + x;  h_out = conv1_next(x_out)
@@ -370,7 +384,8 @@ enum pdse_op_kind {
   PDSE_OP_AHAM = 14,
   PDSE_OP_QSAMPLE = 15,
   PDSE_OP_TRANSPOSE = 16,
-  PDSE_OP_TCM = 17
+  PDSE_OP_TCM = 17,
+  PDSE_OP_CRM = 18
 };
 
 int pdse_abi_version(void);
@@ -397,6 +412,7 @@ int pdse_aham_f32(const pdse_aham_desc* d, pdse_stream_t s);
 int pdse_qsample_f32(const pdse_qsample_desc* d, pdse_stream_t s);
 int pdse_transpose_f32(const pdse_transpose_desc* d, pdse_stream_t s);
 int pdse_tcm_f32(const pdse_tcm_desc* d, pdse_stream_t s);
+int pdse_crm_f32(const pdse_crm_desc* d, pdse_stream_t s);
 
 /* plans: a recorded operator sequence replayed by one call (and capturable in a hipGraph) */
 typedef struct pdse_plan pdse_plan;

@@ -119,29 +119,33 @@ int pdse_chln_launch(const pdse_chln_desc* d, hipStream_t s) {
 // 1024 threads (4 waves per SIMD hide the LDS latency of the serial key loop); keys are taken
 // four at a time so the running maximum is rescaled once per block instead of once per key.
 #define ATTN_THREADS 1024
+// HD = head dimension (8: d_model 32, 16: d_model 64; always 4 heads).  A workgroup handles one 32-channel window
+// of one line (32 / HD heads), so K and V of the window fit LDS for sequences up to 640 positions.
+template <int HD>
 __global__ __launch_bounds__(ATTN_THREADS) void attn_kernel(const pdse_attn_desc d) {
-  extern __shared__ float kv[];  // [S][E] keys, then [S][E] values
-  const int E = d.E, HD = 8;
-  const int b = blockIdx.y, line = blockIdx.x;
+  extern __shared__ float kv[];  // [S][32] keys, then [S][32] values
+  constexpr int W = 32, HW = W / HD;
+  const int E = d.E;
+  const int b = blockIdx.y, line = blockIdx.x, c0 = blockIdx.z * W;
   const int S = d.axis == 0 ? d.F : d.T;
   const int64_t plane = (int64_t)d.T * d.F;
   const int64_t base = (int64_t)b * 3 * E * plane + (d.axis == 0 ? (int64_t)line * d.F : (int64_t)line);
   const int64_t ss = d.axis == 0 ? 1 : d.F;
   float* ks = kv;
-  float* vs = kv + (size_t)S * E;
-  for (int i = threadIdx.x; i < S * E; i += ATTN_THREADS) {
+  float* vs = kv + (size_t)S * W;
+  for (int i = threadIdx.x; i < S * W; i += ATTN_THREADS) {
     const int e = i / S, sp = i - e * S;  // consecutive threads -> consecutive sequence positions
-    ks[sp * E + e] = d.qkv[base + (int64_t)(E + e) * plane + (int64_t)sp * ss];
-    vs[sp * E + e] = d.qkv[base + (int64_t)(2 * E + e) * plane + (int64_t)sp * ss];
+    ks[sp * W + e] = d.qkv[base + (int64_t)(E + c0 + e) * plane + (int64_t)sp * ss];
+    vs[sp * W + e] = d.qkv[base + (int64_t)(2 * E + c0 + e) * plane + (int64_t)sp * ss];
   }
   __syncthreads();
   const int64_t obase = (int64_t)b * E * plane + (d.axis == 0 ? (int64_t)line * d.F : (int64_t)line);
-  for (int idx = threadIdx.x; idx < S * d.heads; idx += ATTN_THREADS) {
+  for (int idx = threadIdx.x; idx < S * HW; idx += ATTN_THREADS) {
     const int hd = idx / S, sq = idx - hd * S;
     float q[HD], acc[HD];
 #pragma unroll
     for (int e = 0; e < HD; ++e) {
-      q[e] = d.qkv[base + (int64_t)(hd * HD + e) * plane + (int64_t)sq * ss];
+      q[e] = d.qkv[base + (int64_t)(c0 + hd * HD + e) * plane + (int64_t)sq * ss];
       acc[e] = 0.f;
     }
     float m = -1e30f, l = 0.f;
@@ -152,9 +156,13 @@ __global__ __launch_bounds__(ATTN_THREADS) void attn_kernel(const pdse_attn_desc
       float sc[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const float4 k0 = *reinterpret_cast<const float4*>(kh + (sp + u) * E);
-        const float4 k1 = *reinterpret_cast<const float4*>(kh + (sp + u) * E + 4);
-        sc[u] = q[0] * k0.x + q[1] * k0.y + q[2] * k0.z + q[3] * k0.w + q[4] * k1.x + q[5] * k1.y + q[6] * k1.z + q[7] * k1.w;
+        float a = 0.f;
+#pragma unroll
+        for (int e4 = 0; e4 < HD; e4 += 4) {
+          const float4 k0 = *reinterpret_cast<const float4*>(kh + (sp + u) * W + e4);
+          a += q[e4] * k0.x + q[e4 + 1] * k0.y + q[e4 + 2] * k0.z + q[e4 + 3] * k0.w;
+        }
+        sc[u] = a;
       }
       const float mn = fmaxf(fmaxf(m, fmaxf(sc[0], sc[1])), fmaxf(sc[2], sc[3]));
       const float corr = aia_exp(m - mn);
@@ -164,22 +172,23 @@ __global__ __launch_bounds__(ATTN_THREADS) void attn_kernel(const pdse_attn_desc
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const float pw = aia_exp(sc[u] - mn);
-        const float4 v0 = *reinterpret_cast<const float4*>(vh + (sp + u) * E);
-        const float4 v1 = *reinterpret_cast<const float4*>(vh + (sp + u) * E + 4);
         l += pw;
-        acc[0] += pw * v0.x; acc[1] += pw * v0.y; acc[2] += pw * v0.z; acc[3] += pw * v0.w;
-        acc[4] += pw * v1.x; acc[5] += pw * v1.y; acc[6] += pw * v1.z; acc[7] += pw * v1.w;
+#pragma unroll
+        for (int e4 = 0; e4 < HD; e4 += 4) {
+          const float4 v0 = *reinterpret_cast<const float4*>(vh + (sp + u) * W + e4);
+          acc[e4] += pw * v0.x; acc[e4 + 1] += pw * v0.y; acc[e4 + 2] += pw * v0.z; acc[e4 + 3] += pw * v0.w;
+        }
       }
       m = mn;
     }
     for (; sp < S; ++sp) {
-      const float* kr = kh + sp * E;
+      const float* kr = kh + sp * W;
       float s1 = 0.f;
 #pragma unroll
       for (int e = 0; e < HD; ++e) s1 += q[e] * kr[e];
       const float mn = fmaxf(m, s1);
       const float corr = aia_exp(m - mn), pw = aia_exp(s1 - mn);
-      const float* vr = vh + sp * E;
+      const float* vr = vh + sp * W;
       l = l * corr + pw;
 #pragma unroll
       for (int e = 0; e < HD; ++e) acc[e] = acc[e] * corr + pw * vr[e];
@@ -187,36 +196,43 @@ __global__ __launch_bounds__(ATTN_THREADS) void attn_kernel(const pdse_attn_desc
     }
     const float inv = 1.0f / l;
 #pragma unroll
-    for (int e = 0; e < HD; ++e) d.out[obase + (int64_t)(hd * HD + e) * plane + (int64_t)sq * ss] = acc[e] * inv;
+    for (int e = 0; e < HD; ++e) d.out[obase + (int64_t)(c0 + hd * HD + e) * plane + (int64_t)sq * ss] = acc[e] * inv;
   }
 }
 
 int pdse_attn_launch(const pdse_attn_desc* d, hipStream_t s) {
   REQ(d && d->qkv && d->out, "attention: null pointer");
-  REQ(d->B > 0 && d->B <= 65535 && d->T > 0 && d->F > 0 && d->E == 32 && d->heads == 4, "attention: E = 32, 4 heads");
+  REQ(d->B > 0 && d->B <= 65535 && d->T > 0 && d->F > 0 && d->heads == 4 && (d->E == 32 || d->E == 64),
+      "attention: 4 heads, d_model 32 or 64 (dbaiat.py:123-126, :186-189)");
   REQ(d->axis == 0 || d->axis == 1, "attention: axis 0 (bins) or 1 (frames)");
   const int S = d->axis == 0 ? d->F : d->T, lines = d->axis == 0 ? d->T : d->F;
-  const size_t lds = (size_t)2 * S * d->E * sizeof(float);
+  const size_t lds = (size_t)2 * S * 32 * sizeof(float);
   REQ(lds <= 160 * 1024, "attention: sequence too long for one LDS image (S <= 640)");
+  const void* fn = d->E == 32 ? (const void*)attn_kernel<8> : (const void*)attn_kernel<16>;
   if (lds > 64 * 1024)
-    if (pdse_check_hip(hipFuncSetAttribute((const void*)attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
-                       "attention lds attribute"))
+    if (pdse_check_hip(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "attention lds attribute"))
       return 1;
-  hipLaunchKernelGGL(attn_kernel, dim3(lines, d->B), dim3(ATTN_THREADS), lds, s, *d);
+  const dim3 grid(lines, d->B, d->E / 32);
+  if (d->E == 32)
+    hipLaunchKernelGGL(attn_kernel<8>, grid, dim3(ATTN_THREADS), lds, s, *d);
+  else
+    hipLaunchKernelGGL(attn_kernel<16>, grid, dim3(ATTN_THREADS), lds, s, *d);
   return pdse_check_launch("attention");
 }
 
 // ---------------------------------------------------------------------------------------
-// Bidirectional GRU, hidden 64 (dbaiat.py:45,83), persistent over the sequence: a workgroup
-// owns 32 lines of one direction for all S steps, so the recurrence needs no inter-workgroup
-// synchronisation.  Waves 0..5 hold one 32-row tile of W_hh each in registers (A operand) and
-// multiply it with the state h [64 x 32 lines] kept in LDS (B operand, conflict-free rows);
-// all 8 waves then apply the gates (r,z,n order, n = tanh(x_n + r * (W_hn h + b_hn))).
+// Bidirectional GRU, hidden H = 64 (d_model 32, dbaiat.py:45,83) or 128 (d_model 64, :186-189), persistent over
+// the sequence: a workgroup owns 32 lines of one direction for all S steps, so the recurrence needs no
+// inter-workgroup synchronisation.  Waves 0..3H/32-1 hold one 32-row tile of W_hh each in registers (A operand)
+// and multiply it with the state h [H x 32 lines] kept in LDS (B operand, conflict-free rows); all 8H threads
+// then apply the gates (r,z,n order, n = tanh(x_n + r * (W_hn h + b_hn))).
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void gru_kernel(const pdse_gru_desc d) {
-  constexpr int H = 64, G3 = 192;
-  __shared__ float hs[H][32];
-  __shared__ float gh[G3][33];
+template <int H>
+__global__ __launch_bounds__(8 * H) void gru_kernel(const pdse_gru_desc d) {
+  constexpr int G3 = 3 * H, NT = 8 * H, KS = H / 2, MW = G3 / 32;
+  extern __shared__ float gru_lds[];
+  float (*hs)[32] = reinterpret_cast<float (*)[32]>(gru_lds);             // [H][32]
+  float (*gh)[33] = reinterpret_cast<float (*)[33]>(gru_lds + H * 32);     // [3H][33]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = lane & 31, hh = lane >> 5;
   const int dir = blockIdx.y;
@@ -226,29 +242,27 @@ __global__ __launch_bounds__(512) void gru_kernel(const pdse_gru_desc d) {
   const int64_t plane = (int64_t)d.T * d.F;
   const int64_t ss = d.axis == 0 ? 1 : d.F;
 
-  float a[32];
-  if (wave < 6) {
-    const float* A = d.whh + ((size_t)(dir * 6 + wave) * 32) * 64 + lane;
+  float a[KS];
+  if (wave < MW) {
+    const float* A = d.whh + ((size_t)(dir * MW + wave) * KS) * 64 + lane;
 #pragma unroll
-    for (int ks = 0; ks < 32; ++ks) a[ks] = A[(size_t)ks * 64];
+    for (int ks = 0; ks < KS; ++ks) a[ks] = A[(size_t)ks * 64];
   }
-  for (int i = threadIdx.x; i < H * 32; i += 512) (&hs[0][0])[i] = 0.f;
+  for (int i = threadIdx.x; i < H * 32; i += NT) (&hs[0][0])[i] = 0.f;
 
   // gate work of this thread: 4 (unit, line) items, lines fastest
   int64_t gbase[4], ybase[4];
-  int unit[4], ln[4];
   bool live[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const int it = threadIdx.x + 512 * k;
-    unit[k] = it >> 5;
-    ln[k] = it & 31;
-    const int L = blockIdx.x * 32 + ln[k];
-    live[k] = L < nlines;
-    const int b = live[k] ? L / per_b : 0, w = live[k] ? L - b * per_b : 0;
+    const int it = threadIdx.x + NT * k;
+    const int unit = it >> 5, ln = it & 31;
+    const int Lg = blockIdx.x * 32 + ln;
+    live[k] = Lg < nlines;
+    const int b = live[k] ? Lg / per_b : 0, w = live[k] ? Lg - b * per_b : 0;
     const int64_t pos = d.axis == 0 ? (int64_t)w * d.F : (int64_t)w;
-    gbase[k] = (int64_t)b * 6 * H * plane + pos + (int64_t)(dir * G3 + unit[k]) * plane;
-    ybase[k] = (int64_t)b * 2 * H * plane + pos + (int64_t)(dir * H + unit[k]) * plane;
+    gbase[k] = (int64_t)b * 6 * H * plane + pos + (int64_t)(dir * G3 + unit) * plane;
+    ybase[k] = (int64_t)b * 2 * H * plane + pos + (int64_t)(dir * H + unit) * plane;
   }
   const float* bh = d.bhh + dir * G3;
   __syncthreads();
@@ -263,12 +277,12 @@ __global__ __launch_bounds__(512) void gru_kernel(const pdse_gru_desc d) {
       xz[k] = live[k] ? d.gx[o + (int64_t)H * plane] : 0.f;
       xn[k] = live[k] ? d.gx[o + (int64_t)2 * H * plane] : 0.f;
     }
-    if (wave < 6) {
+    if (wave < MW) {
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-      for (int ks = 0; ks < 32; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks], hs[2 * ks + hh][col], acc, 0, 0, 0);
+      for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks], hs[2 * ks + hh][col], acc, 0, 0, 0);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * hh;
@@ -279,7 +293,8 @@ __global__ __launch_bounds__(512) void gru_kernel(const pdse_gru_desc d) {
     float hn[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int u = unit[k], l = ln[k];
+      const int it = threadIdx.x + NT * k;
+      const int u = it >> 5, l = it & 31;
       const float r = aia_sigmoid(xr[k] + gh[u][l]);
       const float z = aia_sigmoid(xz[k] + gh[H + u][l]);
       const float n = tanhf(xn[k] + r * gh[2 * H + u][l]);
@@ -288,7 +303,8 @@ __global__ __launch_bounds__(512) void gru_kernel(const pdse_gru_desc d) {
     __syncthreads();   // every MFMA wave has consumed hs, every gate thread has read gh
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      hs[unit[k]][ln[k]] = hn[k];
+      const int it = threadIdx.x + NT * k;
+      hs[it >> 5][it & 31] = hn[k];
       if (live[k]) d.y[ybase[k] + (int64_t)sq * ss] = hn[k];
     }
     __syncthreads();
@@ -297,10 +313,19 @@ __global__ __launch_bounds__(512) void gru_kernel(const pdse_gru_desc d) {
 
 int pdse_gru_launch(const pdse_gru_desc* d, hipStream_t s) {
   REQ(d && d->gx && d->whh && d->bhh && d->y, "bigru: null pointer");
-  REQ(d->B > 0 && d->T > 0 && d->F > 0 && d->H == 64, "bigru: hidden size 64 (dbaiat.py:45)");
+  REQ(d->B > 0 && d->T > 0 && d->F > 0 && (d->H == 64 || d->H == 128), "bigru: hidden size 64 or 128 (dbaiat.py:45)");
   REQ(d->axis == 0 || d->axis == 1, "bigru: axis 0 (bins) or 1 (frames)");
   const int nlines = d->B * (d->axis == 0 ? d->T : d->F);
-  hipLaunchKernelGGL(gru_kernel, dim3((nlines + 31) / 32, 2), dim3(512), 0, s, *d);
+  const size_t lds = (size_t)(d->H * 32 + 3 * d->H * 33) * sizeof(float);
+  const dim3 grid((nlines + 31) / 32, 2);
+  if (d->H == 64) {
+    hipLaunchKernelGGL(gru_kernel<64>, grid, dim3(512), lds, s, *d);
+  } else {
+    if (pdse_check_hip(hipFuncSetAttribute((const void*)gru_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                       "bigru lds attribute"))
+      return 1;
+    hipLaunchKernelGGL(gru_kernel<128>, grid, dim3(1024), lds, s, *d);
+  }
   return pdse_check_launch("bigru");
 }
 
@@ -443,4 +468,35 @@ int pdse_transpose_launch(const pdse_transpose_desc* d, hipStream_t s) {
   REQ(d->N > 0 && d->N <= 65535 && d->R > 0 && d->Cc > 0 && (d->R + 31) / 32 <= 65535, "transpose: bad sizes");
   hipLaunchKernelGGL(transpose_kernel, dim3((d->Cc + 31) / 32, (d->R + 31) / 32, d->N), dim3(256), 0, s, *d);
   return pdse_check_launch("transpose");
+}
+
+// ---------------------------------------------------------------------------------------
+// Dual-branch prior: magnitude of the input (mode 0) and the masked-magnitude / decoded real-imag
+// recombination (mode 1), dbaiat.py:389, :403-411.  Elementwise, HBM-bound.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void crm_kernel(const pdse_crm_desc d) {
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (q >= d.plane) return;
+  const float re = d.x[((int64_t)b * 2) * d.plane + q], im = d.x[((int64_t)b * 2 + 1) * d.plane + q];
+  const float mag = sqrtf(re * re + im * im);
+  if (d.mode == 0) {
+    d.out[(int64_t)b * d.plane + q] = mag;
+    return;
+  }
+  const float o = d.o[(int64_t)b * d.plane + q];
+  const float m1 = 1.0f / (1.0f + expf(-(d.a1 * o + d.b1)));
+  const float m2 = tanhf(d.a2 * o + d.b2);
+  const float mask = 1.0f / (1.0f + expf(-(d.a3 * (m1 * m2) + d.b3)));
+  const float cs = mag > 0.f ? re / mag : 1.f, sn = mag > 0.f ? im / mag : 0.f;
+  const float mo = mask * mag;
+  d.out[((int64_t)b * 2) * d.plane + q] = mo * cs + d.ri[((int64_t)b * 2) * d.plane + q];
+  d.out[((int64_t)b * 2 + 1) * d.plane + q] = mo * sn + d.ri[((int64_t)b * 2 + 1) * d.plane + q];
+}
+
+int pdse_crm_launch(const pdse_crm_desc* d, hipStream_t s) {
+  REQ(d && d->x && d->out && (d->mode == 0 || (d->mode == 1 && d->o && d->ri)), "crm: null pointer or bad mode");
+  REQ(d->B > 0 && d->B <= 65535 && d->plane > 0, "crm: bad sizes");
+  hipLaunchKernelGGL(crm_kernel, dim3((unsigned)((d->plane + 255) / 256), d->B), dim3(256), 0, s, *d);
+  return pdse_check_launch("crm");
 }

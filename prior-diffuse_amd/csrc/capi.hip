@@ -42,6 +42,7 @@ union pdse_any_desc {
   pdse_qsample_desc qsample;
   pdse_transpose_desc transpose;
   pdse_tcm_desc tcm;
+  pdse_crm_desc crm;
 };
 
 struct pdse_op {
@@ -76,6 +77,7 @@ static int op_size(int kind) {
     case PDSE_OP_QSAMPLE: return (int)sizeof(pdse_qsample_desc);
     case PDSE_OP_TRANSPOSE: return (int)sizeof(pdse_transpose_desc);
     case PDSE_OP_TCM: return (int)sizeof(pdse_tcm_desc);
+    case PDSE_OP_CRM: return (int)sizeof(pdse_crm_desc);
     default: return -1;
   }
 }
@@ -100,6 +102,7 @@ static int launch_op(const pdse_op& op, hipStream_t s) {
     case PDSE_OP_QSAMPLE: return pdse_qsample_launch(&op.d.qsample, s);
     case PDSE_OP_TRANSPOSE: return pdse_transpose_launch(&op.d.transpose, s);
     case PDSE_OP_TCM: return pdse_tcm_launch(&op.d.tcm, s);
+    case PDSE_OP_CRM: return pdse_crm_launch(&op.d.crm, s);
     default: pdse_set_error("plan: unknown op kind"); return 1;
   }
 }
@@ -128,6 +131,7 @@ int pdse_aham_f32(const pdse_aham_desc* d, pdse_stream_t s) { return pdse_aham_l
 int pdse_qsample_f32(const pdse_qsample_desc* d, pdse_stream_t s) { return pdse_qsample_launch(d, (hipStream_t)s); }
 int pdse_transpose_f32(const pdse_transpose_desc* d, pdse_stream_t s) { return pdse_transpose_launch(d, (hipStream_t)s); }
 int pdse_tcm_f32(const pdse_tcm_desc* d, pdse_stream_t s) { return pdse_tcm_launch(d, (hipStream_t)s); }
+int pdse_crm_f32(const pdse_crm_desc* d, pdse_stream_t s) { return pdse_crm_launch(d, (hipStream_t)s); }
 
 int pdse_plan_create(pdse_plan** out) {
   if (!out) {

@@ -678,9 +678,10 @@ class AiaPlan(PlanBase):
 
     FH = 80  # bins after the stride-2 encoder conv
 
-    def __init__(self, ctx, sd, B, T, plan=None):
+    def __init__(self, ctx, sd, B, T, plan=None, d=32):
+        """d: d_model of the transformer layers (32: AIA_Transformer(64, 64); 64: AIA_Transformer_merge(128, 64))."""
         super().__init__(ctx, plan)
-        self.sd, self.B, self.T = sd, B, T
+        self.sd, self.B, self.T, self.d = sd, B, T, d
         a = ctx.alloc
         FH = self.FH
         self.x = a(B, 2, T, F0)
@@ -690,21 +691,21 @@ class AiaPlan(PlanBase):
         self.D161 = a(B, 320, T, F0)            # dense buffer [out4,out3,out2,out1,x]
         self.D80 = a(B, 320, T, FH)
         self.x_ri = a(B, 64, T, FH)
-        self.cur = a(B, 32, T, FH)               # AIA state ("output" in dbaiat.py:138)
-        self.nxt = a(B, 32, T, FH)
-        self.n_a, self.n_b = a(B, 32, T, FH), a(B, 32, T, FH)
-        self.qkv = a(B, 96, T, FH)
-        self.att = a(B, 32, T, FH)
-        self.gx = a(B, 384, T, FH)
-        self.gy = a(B, 128, T, FH)
-        self.s1, self.s2 = a(B, 32, T, FH), a(B, 32, T, FH)
-        self.br = [a(B, 32, T, FH), a(B, 32, T, FH)]      # row / col branch outputs
+        self.cur = a(B, d, T, FH)                # AIA state ("output" in dbaiat.py:138)
+        self.nxt = a(B, d, T, FH)
+        self.n_a, self.n_b = a(B, d, T, FH), a(B, d, T, FH)
+        self.qkv = a(B, 3 * d, T, FH)
+        self.att = a(B, d, T, FH)
+        self.gx = a(B, 12 * d, T, FH)            # both directions x (r, z, n) x hidden 2d
+        self.gy = a(B, 4 * d, T, FH)
+        self.s1, self.s2 = a(B, d, T, FH), a(B, d, T, FH)
+        self.br = [a(B, d, T, FH), a(B, d, T, FH)]        # row / col branch outputs
         self.outs = [a(B, 64, T, FH) for _ in range(4)]
         self.merged = a(B, 64, T, FH)
         self.gn_stats = a(B, 64, 4)
         self.means = a(4, B, 64)
         self.dec_up = a(B, 64, T, F0, zero=True)  # sub-pixel output; bin 0 is the left zero pad, never written
-        self.t_a, self.t_b, self.t_c = a(B, 32, FH, T), a(B, 32, FH, T), a(B, 32, FH, T)   # "ft" staging (frames innermost)
+        self.t_a, self.t_b, self.t_c = a(B, d, FH, T), a(B, d, FH, T), a(B, d, FH, T)   # "ft" staging (frames innermost)
 
     def w(self, k):
         return P._np(self.sd[k])
@@ -719,9 +720,9 @@ class AiaPlan(PlanBase):
         self.add(d, TAG_PRIOR)
 
     def _swap(self, src, dst, to_ft):
-        """[B,32,T,F] <-> [B,32,F,T] (tile transpose, one read + one write of a 32-channel tensor)."""
+        """[B,d,T,F] <-> [B,d,F,T] (tile transpose, one read + one write of a d-channel tensor)."""
         d = L.TransposeDesc()
-        d.in_, d.out, d.N = src.data_ptr(), dst.data_ptr(), self.B * 32
+        d.in_, d.out, d.N = src.data_ptr(), dst.data_ptr(), self.B * self.d
         d.R, d.Cc = (self.T, self.FH) if to_ft else (self.FH, self.T)
         self.add(d, TAG_PRIOR)
 
@@ -729,7 +730,7 @@ class AiaPlan(PlanBase):
         d = L.ChlnDesc()
         d.in_, d.out = src.data_ptr(), dst.data_ptr()
         d.gamma, d.beta = self.ctx.up(self.w(norm + ".weight")).data_ptr(), self.ctx.up(self.w(norm + ".bias")).data_ptr()
-        d.plane, d.B, d.C, d.eps = self.T * self.FH, self.B, 32, 1e-5
+        d.plane, d.B, d.C, d.eps = self.T * self.FH, self.B, self.d, 1e-5
         self.add(d, TAG_PRIOR)
 
     def _pw(self, src_t, Cin, wk, bias, out_t, Cout, F_, resid=None, act=L.ACT_NONE, act_slope=0.0, xf=None,
@@ -744,7 +745,7 @@ class AiaPlan(PlanBase):
         T, B = self.T, self.B
         plane = T * F_
         if in_layout == "tf" and out_layout == "tf":
-            self.gconv(in0=self.src(src_t, Cin, *nchw(Cin, T, F_)), Tin=T, Fin=F_, taps=[(0, 0)], sf_in=1,
+            self.gconv(in0=self.src(src_t, Cin, *nchw(Cin, T, F_)), Tin=T, Fin=F_, taps=[(0, 0)], sf_in=1, cin1=Cin == 1,
                        wk0=wk, Cout=Cout, bias0=bias, act=act, act_slope=act_slope, xf=xf, resid=resid, out=out_t,
                        out_strides=nchw_out(Cout, T, F_), B=B, Tout=T, Fout=F_, tag=TAG_PRIOR)
             return
@@ -777,11 +778,11 @@ class AiaPlan(PlanBase):
 
         Attention over frames and the GRU over bins run on "ft" operands with the kernels'
         coalesced code path (attention axis 0 / GRU axis 1 on the swapped tensor)."""
-        B, T, FH = self.B, self.T, self.FH
+        B, T, FH, dm = self.B, self.T, self.FH, self.d
         self._chln(src_t, self.n_a, p + ".norm3")
         Wi, bi = self.w(p + ".self_attn.in_proj_weight").copy(), self.w(p + ".self_attn.in_proj_bias").copy()
-        Wi[:32] *= 8 ** -0.5                                          # q scaled by head_dim^-0.5 inside the projection
-        bi[:32] *= 8 ** -0.5
+        Wi[:dm] *= (dm // 4) ** -0.5                                  # q scaled by head_dim^-0.5 inside the projection
+        bi[:dm] *= (dm // 4) ** -0.5
         att_ft = axis == 1                                            # sequence over frames: operands in "ft"
         lay = "ft" if att_ft else "tf"
         if att_ft:
@@ -792,18 +793,18 @@ class AiaPlan(PlanBase):
             qkv_in, res_in, s1_out = self.t_a, self.t_b, self.t_c
         else:
             qkv_in, res_in, s1_out = self.n_a, src_t, self.s1
-        self._pw(qkv_in, 32, Wi.T, bi, self.qkv, 96, FH, in_layout=lay, out_layout=lay)
+        self._pw(qkv_in, dm, Wi.T, bi, self.qkv, 3 * dm, FH, in_layout=lay, out_layout=lay)
         d = L.AttnDesc()
-        d.qkv, d.out, d.B, d.E, d.heads, d.axis = self.qkv.data_ptr(), self.att.data_ptr(), B, 32, 4, 0
+        d.qkv, d.out, d.B, d.E, d.heads, d.axis = self.qkv.data_ptr(), self.att.data_ptr(), B, dm, 4, 0
         d.T, d.F = (FH, T) if att_ft else (T, FH)                     # "ft": the innermost axis is the sequence either way
         self.add(d, TAG_PRIOR)
-        self._pw(self.att, 32, self.w(p + ".self_attn.out_proj.weight").T, self.w(p + ".self_attn.out_proj.bias"),
-                 s1_out, 32, FH, resid=res_in, in_layout=lay, out_layout=lay)         # src + attention
+        self._pw(self.att, dm, self.w(p + ".self_attn.out_proj.weight").T, self.w(p + ".self_attn.out_proj.bias"),
+                 s1_out, dm, FH, resid=res_in, in_layout=lay, out_layout=lay)         # src + attention
         if att_ft:
             self._swap(self.t_c, self.s1, False)
         self._chln(self.s1, self.n_b, p + ".norm1")
         g = p + ".gru."
-        Wih = np.concatenate([self.w(g + "weight_ih_l0"), self.w(g + "weight_ih_l0_reverse")], 0)   # [384, 32]
+        Wih = np.concatenate([self.w(g + "weight_ih_l0"), self.w(g + "weight_ih_l0_reverse")], 0)   # [12d, d]
         bih = np.concatenate([self.w(g + "bias_ih_l0"), self.w(g + "bias_ih_l0_reverse")], 0)
         gru_ft = axis == 0                                            # sequence over bins: lines = frames -> "ft"
         lay = "ft" if gru_ft else "tf"
@@ -812,85 +813,164 @@ class AiaPlan(PlanBase):
             gx_in, s2_out = self.t_a, self.t_b
         else:
             gx_in, s2_out = self.n_b, self.s2
-        self._pw(gx_in, 32, Wih.T, bih, self.gx, 384, FH, in_layout=lay, out_layout=lay)
-        whh = np.stack([P.pack_a(self.w(g + "weight_hh_l0" + suf).T) for suf in ("", "_reverse")], 0)   # [2,6,32,64]
+        self._pw(gx_in, dm, Wih.T, bih, self.gx, 12 * dm, FH, in_layout=lay, out_layout=lay)
+        whh = np.stack([P.pack_a(self.w(g + "weight_hh_l0" + suf).T) for suf in ("", "_reverse")], 0)   # [2, 3H/32, H/2, 64]
         bhh = np.stack([self.w(g + "bias_hh_l0"), self.w(g + "bias_hh_l0_reverse")], 0)
         gd = L.GruDesc()
         gd.gx, gd.y = self.gx.data_ptr(), self.gy.data_ptr()
         gd.whh, gd.bhh = self.ctx.up(whh).data_ptr(), self.ctx.up(bhh).data_ptr()
-        gd.B, gd.H, gd.axis = B, 64, 1                                # lines on the innermost axis, sequence on the outer
+        gd.B, gd.H, gd.axis = B, 2 * dm, 1                            # lines on the innermost axis, sequence on the outer
         gd.T, gd.F = (FH, T) if gru_ft else (T, FH)
         self.add(gd, TAG_LSTM)
         # relu -> linear2 -> + residual (the normed tensor); ReLU = the load transform with slope 0, identity affine
-        relu = dict(mode=1, scale0=np.ones(128), shift0=np.zeros(128), slope0=0.0)
-        self._pw(self.gy, 128, self.w(p + ".linear2.weight").T, self.w(p + ".linear2.bias"), s2_out, 32, FH,
+        relu = dict(mode=1, scale0=np.ones(4 * dm), shift0=np.zeros(4 * dm), slope0=0.0)
+        self._pw(self.gy, 4 * dm, self.w(p + ".linear2.weight").T, self.w(p + ".linear2.bias"), s2_out, dm, FH,
                  resid=gx_in, xf=relu, in_layout=lay, out_layout=lay)
         if gru_ft:
             self._swap(self.t_b, self.s2, False)
         self._chln(self.s2, dst_t, p + ".norm2")
 
+    def _dense_encoder(self, p, src_t, cin, dst):
+        """dense_encoder / dense_encoder_mag (dbaiat.py:481-524): src [B,cin,T,161] -> dst [B,64,T,80]."""
+        B, T, FH, sd = self.B, self.T, self.FH, self.sd
+        self._pw(src_t, cin, self.w(p + ".inp_conv.weight")[:, :, 0, 0].T, self.w(p + ".inp_conv.bias"), self.tmp161, 64, F0)
+        self._rowln(self.tmp161, self.D161, 320 * T * F0, 64, F0, p + ".inp_norm", p + ".inp_prelu", dst_off=256 * T * F0)
+        self._dense_block(p + ".enc_dense1", self.D161, F0, self.tmp161)
+        kk, taps = P.conv_taps(1, 3, 0)
+        self.gconv(in0=self.src(self.D161, 64, *nchw(320, T, F0)), Tin=T, Fin=F0, taps=taps, sf_in=2,
+                   wk0=P.conv_kmat(sd[p + ".enc_conv1.weight"], kk), Cout=64, bias0=self.w(p + ".enc_conv1.bias"),
+                   out=self.tmp80, out_strides=nchw_out(64, T, FH), B=B, Tout=T, Fout=FH, tag=TAG_PRIOR)
+        self._rowln(self.tmp80, dst, 64 * T * FH, 64, FH, p + ".enc_norm1", p + ".enc_prelu1")
+
+    def _aham(self, p, outs, dst):
+        """AHAM / AHAM_ori (dbaiat.py:266-288, :308-330)."""
+        ah = L.AhamDesc()
+        for i in range(4):
+            ah.x[i] = outs[i].data_ptr()
+        ah.w, ah.bias = self.ctx.up(self.w(p + ".conv1.weight").reshape(64)).data_ptr(), float(self.w(p + ".conv1.bias")[0])
+        ah.means, ah.out, ah.plane, ah.B, ah.C = self.means.data_ptr(), dst.data_ptr(), self.T * self.FH, self.B, 64
+        self.add(ah, TAG_PRIOR)
+
+    def _dense_decoder(self, de, merged, out, out_C, out_off):
+        """dense_decoder (dbaiat.py:527-548) with the sub-pixel up-convolution (:587-602); its 64 -> 1 output goes to
+        channel ``out_off // (T*161)`` of ``out`` [B,out_C,T,161].  (The masking decoder :551-584 is the same up to
+        its scalar gate, which the CRM operator applies.)"""
+        B, T, FH, sd = self.B, self.T, self.FH, self.sd
+        for b in range(B):                # merged -> channel block 4 of every batch item (one strided copy per item)
+            c = L.EwDesc()
+            c.a, c.out = Ctx.ptr(merged, b * 64 * T * FH), Ctx.ptr(self.D80, (b * 320 + 256) * T * FH)
+            c.n, c.op = 64 * T * FH, L.EW_COPY
+            self.add(c, TAG_EW)
+        self._dense_block(de + ".dec_dense1", self.D80, FH, self.tmp80)
+        taps = [(0, kf - 1) for kf in range(3)]                   # pad (1,1) in bins
+        kk = [(0, kf) for kf in range(3)]
+        # co = r*64 + c  ->  channel c, bin 1 + 2w + r   (sub-pixel r = 2, then one zero bin on the left)
+        self.gconv(in0=self.src(self.D80, 64, *nchw(320, T, FH)), Tin=T, Fin=FH, taps=taps, sf_in=1,
+                   wk0=P.conv_kmat(sd[de + ".dec_conv1.conv.weight"], kk), Cout=128,
+                   bias0=self.w(de + ".dec_conv1.conv.bias"), out=self.dec_up,
+                   out_strides=(64 * T * F0, 1, T * F0, F0, 2), out_cr=64, out_off=1, B=B, Tout=T, Fout=FH,
+                   tag=TAG_PRIOR)
+        self._rowln(self.dec_up, self.tmp161, 64 * T * F0, 64, F0, de + ".dec_norm1", de + ".dec_prelu1")
+        self.gconv(in0=self.src(self.tmp161, 64, *nchw(64, T, F0)), Tin=T, Fin=F0, taps=[(0, 0)], sf_in=1,
+                   wk0=self.w(de + ".out_conv.weight")[:, :, 0, 0].T, Cout=1, bias0=self.w(de + ".out_conv.bias"),
+                   out=out, out_strides=nchw_out(out_C, T, F0), out_off=out_off, B=B, Tout=T, Fout=F0, tag=TAG_PRIOR)
+
+    def _gncomb(self, p, i, base, out):
+        g = L.GncombDesc()
+        up = self.ctx.up
+        g.base, g.row, g.col, g.out = base.data_ptr(), self.br[0].data_ptr(), self.br[1].data_ptr(), out.data_ptr()
+        g.g_row, g.b_row = up(self.w("%s.row_norm.%d.weight" % (p, i))).data_ptr(), up(self.w("%s.row_norm.%d.bias" % (p, i))).data_ptr()
+        g.g_col, g.b_col = up(self.w("%s.col_norm.%d.weight" % (p, i))).data_ptr(), up(self.w("%s.col_norm.%d.bias" % (p, i))).data_ptr()
+        g.stats, g.plane, g.B, g.C = self.gn_stats.data_ptr(), self.T * self.FH, self.B, self.d
+        g.k1, g.k2, g.eps = float(self.w(p + ".k1")[0]), float(self.w(p + ".k2")[0]), 1e-8
+        self.add(g, TAG_PRIOR)
+
     def build(self, x=None, out=None):
         B, T, FH = self.B, self.T, self.FH
         x = self.x if x is None else x
         out = self.out if out is None else out
-        sd = self.sd
-        # ---- dense_encoder (dbaiat.py:481-501)
-        self._pw(x, 2, self.w("en_ri.inp_conv.weight")[:, :, 0, 0].T, self.w("en_ri.inp_conv.bias"), self.tmp161, 64, F0)
-        self._rowln(self.tmp161, self.D161, 320 * T * F0, 64, F0, "en_ri.inp_norm", "en_ri.inp_prelu",
-                    dst_off=256 * T * F0)
-        self._dense_block("en_ri.enc_dense1", self.D161, F0, self.tmp161)
-        kk, taps = P.conv_taps(1, 3, 0)
-        self.gconv(in0=self.src(self.D161, 64, *nchw(320, T, F0)), Tin=T, Fin=F0, taps=taps, sf_in=2,
-                   wk0=P.conv_kmat(sd["en_ri.enc_conv1.weight"], kk), Cout=64, bias0=self.w("en_ri.enc_conv1.bias"),
-                   out=self.tmp80, out_strides=nchw_out(64, T, FH), B=B, Tout=T, Fout=FH, tag=TAG_PRIOR)
-        self._rowln(self.tmp80, self.x_ri, 64 * T * FH, 64, FH, "en_ri.enc_norm1", "en_ri.enc_prelu1")
+        self._dense_encoder("en_ri", x, 2, self.x_ri)
         # ---- AIA_Transformer (dbaiat.py:133-154)
         p = "dual_trans"
         self._pw(self.x_ri, 64, self.w(p + ".input.0.weight")[:, :, 0, 0].T, self.w(p + ".input.0.bias"), self.cur, 32, FH,
                  act=L.ACT_PRELU, act_slope=float(self.w(p + ".input.1.weight")[0]))
-        k1, k2 = float(self.w(p + ".k1")[0]), float(self.w(p + ".k2")[0])
         slope_o = float(self.w(p + ".output.0.weight")[0])
         ident = dict(mode=1, scale0=np.ones(32), shift0=np.zeros(32), slope0=slope_o)   # PReLU on load
         cur, nxt = self.cur, self.nxt
         for i in range(4):
             self._encoder_layer("%s.row_trans.%d" % (p, i), 0, cur, self.br[0])
             self._encoder_layer("%s.col_trans.%d" % (p, i), 1, cur, self.br[1])
-            g = L.GncombDesc()
-            g.base, g.row, g.col, g.out = cur.data_ptr(), self.br[0].data_ptr(), self.br[1].data_ptr(), nxt.data_ptr()
-            up = self.ctx.up
-            g.g_row, g.b_row = up(self.w("%s.row_norm.%d.weight" % (p, i))).data_ptr(), up(self.w("%s.row_norm.%d.bias" % (p, i))).data_ptr()
-            g.g_col, g.b_col = up(self.w("%s.col_norm.%d.weight" % (p, i))).data_ptr(), up(self.w("%s.col_norm.%d.bias" % (p, i))).data_ptr()
-            g.stats, g.plane, g.B, g.C, g.k1, g.k2, g.eps = self.gn_stats.data_ptr(), T * FH, B, 32, k1, k2, 1e-8
-            self.add(g, TAG_PRIOR)
+            self._gncomb(p, i, cur, nxt)
             cur, nxt = nxt, cur
             self._pw(cur, 32, self.w(p + ".output.1.weight")[:, :, 0, 0].T, self.w(p + ".output.1.bias"), self.outs[i], 64,
                      FH, xf=ident)
-        # ---- AHAM (dbaiat.py:266-288)
-        ah = L.AhamDesc()
-        for i in range(4):
-            ah.x[i] = self.outs[i].data_ptr()
-        ah.w, ah.bias = self.ctx.up(self.w("aham.conv1.weight").reshape(64)).data_ptr(), float(self.w("aham.conv1.bias")[0])
-        ah.means, ah.out, ah.plane, ah.B, ah.C = self.means.data_ptr(), self.merged.data_ptr(), T * FH, B, 64
-        self.add(ah, TAG_PRIOR)
-        # ---- two dense_decoders (dbaiat.py:527-548) with the sub-pixel up-convolution (:587-602)
+        self._aham("aham", self.outs, self.merged)
         for ch, de in enumerate(("de1", "de2")):
-            # merged -> channel block 4 of every batch item (strided over batch: one copy per item)
-            for b in range(B):
-                c = L.EwDesc()
-                c.a, c.out = Ctx.ptr(self.merged, b * 64 * T * FH), Ctx.ptr(self.D80, (b * 320 + 256) * T * FH)
-                c.n, c.op = 64 * T * FH, L.EW_COPY
-                self.add(c, TAG_EW)
-            self._dense_block(de + ".dec_dense1", self.D80, FH, self.tmp80)
-            taps = [(0, kf - 1) for kf in range(3)]                   # pad (1,1) in bins
-            kk = [(0, kf) for kf in range(3)]
-            # co = r*64 + c  ->  channel c, bin 1 + 2w + r   (sub-pixel r = 2, then one zero bin on the left)
-            self.gconv(in0=self.src(self.D80, 64, *nchw(320, T, FH)), Tin=T, Fin=FH, taps=taps, sf_in=1,
-                       wk0=P.conv_kmat(sd[de + ".dec_conv1.conv.weight"], kk), Cout=128,
-                       bias0=self.w(de + ".dec_conv1.conv.bias"), out=self.dec_up,
-                       out_strides=(64 * T * F0, 1, T * F0, F0, 2), out_cr=64, out_off=1, B=B, Tout=T, Fout=FH,
-                       tag=TAG_PRIOR)
-            self._rowln(self.dec_up, self.tmp161, 64 * T * F0, 64, F0, de + ".dec_norm1", de + ".dec_prelu1")
-            self.gconv(in0=self.src(self.tmp161, 64, *nchw(64, T, F0)), Tin=T, Fin=F0, taps=[(0, 0)], sf_in=1,
-                       wk0=self.w(de + ".out_conv.weight")[:, :, 0, 0].T, Cout=1, bias0=self.w(de + ".out_conv.bias"),
-                       out=out, out_strides=nchw_out(2, T, F0), out_off=ch * T * F0, B=B, Tout=T, Fout=F0, tag=TAG_PRIOR)
+            self._dense_decoder(de, self.merged, out, 2, ch * T * F0)
+        return out
+
+
+class DualAiaPlan(AiaPlan):
+    """dual_aia_trans_merge_crm (model/dbaiat.py:373-413): ri and magnitude encoders -> AIA_Transformer_merge
+    (d_model 64, :157-246) -> AHAM_ori x2 -> two dense decoders + the masking decoder -> magnitude/phase recombination.
+
+    The reference runs the merge transformer twice per layer, once per branch; the two runs are the same
+    computation: layer 0 of both reads the shared input projection (:206-207), layer i >= 1 of the magnitude
+    branch reads mag[i-1] + ri[i-1] (:211) and of the ri branch ri[i-1] + mag[i-1] (:229, ``[-2]`` after the
+    append), and IEEE addition commutes.  The golden vectors of the reference module confirm that the two output
+    lists are bit-identical (tests/test_oracle_golden.py), so each layer is evaluated once."""
+
+    def __init__(self, ctx, sd, B, T, plan=None):
+        super().__init__(ctx, sd, B, T, plan, d=64)
+        a = ctx.alloc
+        self.mag = a(B, 1, T, F0)
+        self.x_mag_en = a(B, 64, T, self.FH)
+        self.inp = a(B, 64, T, self.FH)          # shared input projection ("input_mag" == "input_ri")
+        self.merged_mag = a(B, 64, T, self.FH)
+        self.ri_dec = a(B, 2, T, F0)
+        self.o_mask = a(B, 1, T, F0)
+
+    def build(self, x=None, out=None):
+        B, T, FH = self.B, self.T, self.FH
+        x = self.x if x is None else x
+        out = self.out if out is None else out
+        c = L.CrmDesc()
+        c.x, c.out, c.plane, c.B, c.mode = x.data_ptr(), self.mag.data_ptr(), T * F0, B, 0
+        self.add(c, TAG_PRIOR)
+        self._dense_encoder("en_ri", x, 2, self.x_ri)
+        self._dense_encoder("en_mag", self.mag, 1, self.x_mag_en)
+        p = "aia_trans_merge"
+        # input projection over cat(mag, ri) (dbaiat.py:205-207): two-source 1x1 + PReLU
+        self.gconv(in0=self.src(self.x_mag_en, 64, *nchw(64, T, FH)), in1=self.src(self.x_ri, 64, *nchw(64, T, FH)), Tin=T,
+                   Fin=FH, taps=[(0, 0)], sf_in=1, wk0=self.w(p + ".input.0.weight")[:, :, 0, 0].T, Cout=64,
+                   bias0=self.w(p + ".input.0.bias"), act=L.ACT_PRELU, act_slope=float(self.w(p + ".input.1.weight")[0]),
+                   out=self.inp, out_strides=nchw_out(64, T, FH), B=B, Tout=T, Fout=FH, tag=TAG_PRIOR)
+        slope_o = float(self.w(p + ".output.0.weight")[0])
+        ident = dict(mode=1, scale0=np.ones(64), shift0=np.zeros(64), slope0=slope_o)   # PReLU on load
+        u = self.inp
+        for i in range(4):
+            self._encoder_layer("%s.row_trans.%d" % (p, i), 0, u, self.br[0])
+            self._encoder_layer("%s.col_trans.%d" % (p, i), 1, u, self.br[1])
+            self._gncomb(p, i, self.inp, self.nxt)                    # input + k1 * row + k2 * col  (:225, :243)
+            self._pw(self.nxt, 64, self.w(p + ".output.1.weight")[:, :, 0, 0].T, self.w(p + ".output.1.bias"), self.outs[i],
+                     64, FH, xf=ident)
+            if i < 3:                                                 # next layer reads mag[i] + ri[i] = out + out
+                e = L.EwDesc()
+                e.a, e.b, e.out = self.outs[i].data_ptr(), self.outs[i].data_ptr(), self.cur.data_ptr()
+                e.n, e.op, e.s0 = self.outs[i].numel(), L.EW_ADD_MUL, 1.0
+                self.add(e, TAG_EW)
+                u = self.cur
+        self._aham("aham", self.outs, self.merged)
+        self._aham("aham_mag", self.outs, self.merged_mag)
+        self._dense_decoder("de1", self.merged, self.ri_dec, 2, 0)
+        self._dense_decoder("de2", self.merged, self.ri_dec, 2, T * F0)
+        self._dense_decoder("de_mag_mask", self.merged_mag, self.o_mask, 1, 0)
+        c = L.CrmDesc()
+        c.x, c.o, c.ri, c.out = x.data_ptr(), self.o_mask.data_ptr(), self.ri_dec.data_ptr(), out.data_ptr()
+        de = "de_mag_mask."
+        c.a1, c.b1 = float(self.w(de + "mask1.0.weight").reshape(-1)[0]), float(self.w(de + "mask1.0.bias")[0])
+        c.a2, c.b2 = float(self.w(de + "mask2.0.weight").reshape(-1)[0]), float(self.w(de + "mask2.0.bias")[0])
+        c.a3, c.b3 = float(self.w(de + "maskconv.weight").reshape(-1)[0]), float(self.w(de + "maskconv.bias")[0])
+        c.plane, c.B, c.mode = T * F0, B, 1
+        self.add(c, TAG_PRIOR)
         return out

@@ -125,12 +125,14 @@ class GCRNOp(_PlannedOp):
 class AiaOp(_PlannedOp):
     """Prior ``aia_complex_trans_ri.forward(x)`` (model/dbaiat.py:461-478, conf/dbaiat.yml:13)."""
 
+    PLAN = "AiaPlan"
+
     def __call__(self, x):
         self._check(x)
         B, _, T, _ = x.shape
         key = (B, T)
         if key not in self._plans:
-            net = nets.AiaPlan(nets.Ctx(self.device), self.sd, B, T)
+            net = getattr(nets, self.PLAN)(nets.Ctx(self.device), self.sd, B, T)
             net.build()
             net.finish()
             self._plans[key] = net
@@ -140,7 +142,13 @@ class AiaOp(_PlannedOp):
         return net.out.clone()
 
 
-PRIOR_OPS = {"GCRN": GCRNOp, "DiffUNet": DiffUNetOp, "aia_complex_trans_ri": AiaOp}
+class DualAiaOp(AiaOp):
+    """Prior ``dual_aia_trans_merge_crm.forward(x)`` (model/dbaiat.py:386-413), the dual-branch DB-AIAT model."""
+
+    PLAN = "DualAiaPlan"
+
+
+PRIOR_OPS = {"GCRN": GCRNOp, "DiffUNet": DiffUNetOp, "aia_complex_trans_ri": AiaOp, "dual_aia_trans_merge_crm": DualAiaOp}
 
 
 def q_sample(label, init, t, noise, noise_schedule=None):

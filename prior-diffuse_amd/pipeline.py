@@ -62,8 +62,10 @@ class SamplerPipeline:
             self.prior = adopt(nets.EpsNetPlan(ctx, prior_sd, B, T, time_cond=False, plan=self.plan))
         elif prior_name == "aia_complex_trans_ri":
             self.prior = adopt(nets.AiaPlan(ctx, prior_sd, B, T, plan=self.plan))
+        elif prior_name == "dual_aia_trans_merge_crm":
+            self.prior = adopt(nets.DualAiaPlan(ctx, prior_sd, B, T, plan=self.plan))
         else:
-            raise ValueError("prior %r not built (GCRN, DiffUNet, aia_complex_trans_ri)" % prior_name)
+            raise ValueError("prior %r not built (GCRN, DiffUNet, aia_complex_trans_ri, dual_aia_trans_merge_crm)" % prior_name)
         self.eps = adopt(nets.EpsNetPlan(ctx, ddpm_sd, B, T, time_cond=True, nsteps=S, plan=self.plan,
                                          with_pre=not deltamu))
         self.deltamu = deltamu
@@ -84,7 +86,7 @@ class SamplerPipeline:
 
         if with_signal:
             mark("stft", lambda: self.stft.build(feat=self.feat))
-        if prior_name in ("GCRN", "aia_complex_trans_ri"):
+        if prior_name in ("GCRN", "aia_complex_trans_ri", "dual_aia_trans_merge_crm"):
             mark("prior", lambda: self.prior.build(x=self.feat, out=self.prior.out))
         else:
             mark("prior", lambda: self.prior.build_step(0, x=self.feat, out=self.prior.out))

@@ -332,6 +332,27 @@ def test_aia_prior_golden_and_oracle(L, weights, R):
     assert rel_l2(big, ref) < 1e-4
 
 
+def test_dual_branch_aia_prior_golden_and_oracle(L, weights, R):
+    """Dual-branch DB-AIAT prior (dual_aia_trans_merge_crm, d_model 64): golden vectors of the reference module
+    at T=12 with intermediates, then the oracle at T=401 (attention and GRU over 401 frames)."""
+    g = golden("dual_aia_small")
+    op = pkg("ops").DualAiaOp(weights("dual_aia_trans_merge_crm"), DEV)
+    out = op(seeded((2, 2, 12, 161), g["seed_x"]).to(DEV))
+    net = op._plans[(2, 12)]
+    _sync()
+    assert rel_l2(net.x_ri.cpu()[:, ::8], g["en_ri_c8"]) < 2e-5
+    assert rel_l2(net.x_mag_en.cpu()[:, ::8], g["en_mag_c8"]) < 2e-5
+    assert rel_l2(net.outs[3].cpu()[:, ::8], g["trans_last_ri_c8"]) < 5e-5
+    assert rel_l2(net.merged.cpu()[:, ::8], g["aham_c8"]) < 5e-5
+    assert rel_l2(net.merged_mag.cpu()[:, ::8], g["aham_mag_c8"]) < 5e-5
+    assert rel_l2(out.cpu(), g["out"]) < 5e-5
+    x = seeded((1, 2, 401, 161), 62)
+    big = op(x.to(DEV)).cpu()
+    with torch.no_grad():
+        ref = R.dual_aia_trans_merge_crm_forward(weights("dual_aia_trans_merge_crm"), x)
+    assert rel_l2(big, ref) < 1e-4
+
+
 def test_sample_with_aia_prior(L, weights, R):
     params = pkg("params").params
     feat, x_T = pkg("synth").synthetic_spectrogram(2, 24, seed=3)
