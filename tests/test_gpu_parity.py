@@ -353,14 +353,14 @@ def test_dual_branch_aia_prior_golden_and_oracle(L, weights, R):
     assert rel_l2(big, ref) < 1e-4
 
 
-def test_sample_with_aia_prior(L, weights, R):
+@pytest.mark.parametrize("prior", ["aia_complex_trans_ri", "dual_aia_trans_merge_crm"])
+def test_sample_with_aia_prior(L, weights, R, prior):
     params = pkg("params").params
     feat, x_T = pkg("synth").synthetic_spectrogram(2, 24, seed=3)
-    pipe = pkg("pipeline").SamplerPipeline(DEV, "aia_complex_trans_ri", weights("aia_complex_trans_ri"),
-                                           weights("DiffUNet1"), 2, T=24)
+    pipe = pkg("pipeline").SamplerPipeline(DEV, prior, weights(prior), weights("DiffUNet1"), 2, T=24)
     spec, init = pipe.sample(feat.to(DEV), x_T.to(DEV))
     with torch.no_grad():
-        ref, ref_init = R.sample("aia_complex_trans_ri", weights("aia_complex_trans_ri"), weights("DiffUNet1"), feat, x_T,
+        ref, ref_init = R.sample(prior, weights(prior), weights("DiffUNet1"), feat, x_T,
                                  params.noise_schedule, params.inference_noise_schedule, True, False)
     assert rel_l2(init.cpu(), ref_init) < 5e-5
     assert rel_l2(spec.cpu(), ref) < 1e-4

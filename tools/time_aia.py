@@ -1,4 +1,4 @@
-"""Diagnostic: per-operator hipEvent timings of the DB-AIAT prior at B=32, T=401."""
+"""Diagnostic: per-operator hipEvent timings of the DB-AIAT prior at B=32, T=401 (DUAL=1: the dual-branch model)."""
 import importlib
 import os
 import statistics
@@ -11,7 +11,10 @@ nets = importlib.import_module("prior-diffuse_amd.nets")
 synth = importlib.import_module("prior-diffuse_amd.synth")
 
 B, T = int(os.environ.get("B", 32)), int(os.environ.get("T", 401))
-net = nets.AiaPlan(nets.Ctx("cuda:0"), synth.make_state_dict("aia_complex_trans_ri"), B, T)
+if os.environ.get("DUAL"):
+    net = nets.DualAiaPlan(nets.Ctx("cuda:0"), synth.make_state_dict("dual_aia_trans_merge_crm"), B, T)
+else:
+    net = nets.AiaPlan(nets.Ctx("cuda:0"), synth.make_state_dict("aia_complex_trans_ri"), B, T)
 net.build()
 net.finish()
 net.x.copy_(torch.randn(B, 2, T, 161))
