@@ -50,7 +50,7 @@ i1 = [k for k, n in enumerate(names) if n.startswith("compand") and k > i0][0]
 rd = wr = 0.0
 n = 0
 for k in range(i0 + 1, i1):
-    if "gconv" in names[k]:
+    if "gconv" in names[k] or "tcm_block" in names[k]:
         rd += f[ids[k]].get("FETCH_SIZE", 0) * 1024
         wr += w[idw[k]].get("WRITE_SIZE", 0) * 1024
         n += 1
@@ -60,7 +60,7 @@ json.dump(dict(
          "reads, so fetch_size_bytes_x2 is the corrected figure (an upper bound for our 4-byte gathers).",
     kernels=out,
     eps_net_one_pass=dict(launches=n, fetch_size_bytes_raw=rd, fetch_size_bytes_x2=2 * rd, write_size_bytes=wr,
-                          note="all gconv launches of the 6 eps-net forwards of one pass")), open(sys.argv[4], "w"), indent=1)
+                          note="all gconv / tcm_block launches of the 6 eps-net forwards of one pass")), open(sys.argv[4], "w"), indent=1)
 print(n, rd / 1e9, wr / 1e9)
 for o in out[:10]:
     print(o)

@@ -50,3 +50,33 @@ if os.environ.get("HOT"):
         e1.record()
         torch.cuda.synchronize()
         print("hot  op %d (%s): %.1f us per launch" % (i, type(d).__name__, e0.elapsed_time(e1) * 5))
+
+# per-launch efficiency table of the step: algorithmic GFLOP (from the descriptor), time, TFLOP/s
+if os.environ.get("TABLE"):
+    def gflop(d):
+        if isinstance(d, L.TcmDesc):
+            return 2.0 * d.B * d.T * (2 * 320 * 64 + 64 * 256 + (256 * 64 if d.h_out else 0)) / 1e9
+        if not isinstance(d, L.GconvDesc):
+            return 0.0
+        pos0 = d.B * d.Tout * d.Fout
+        accs = 1 if d.epi == L.EPI_LINEAR else 2
+        cin = d.in0.C + d.in1.C
+        fl = 2.0 * pos0 * accs * (d.ntaps * cin) * d.Cout
+        if d.epi == L.EPI_BIGLU:
+            tail = 2.0 * (2 * 32 * 32 + 32 * d.C2)
+            fl += pos0 * tail
+            if d.w2:
+                pos1 = d.B * d.Tout * d.Fout1
+                fl += 2.0 * pos1 * 2 * (bin(d.p1mask).count("1") * cin) * 32 + pos1 * tail
+        return fl / 1e9
+    print("%4s %-6s %-4s %5s %5s %5s %6s %9s %8s %7s" % ("op", "tag", "epi", "taps", "cin", "cout", "Fout", "GFLOP", "us", "TF/s"))
+    for i, (d, tag) in enumerate(net.descs):
+        g = gflop(d)
+        if med[i] < 15:
+            continue
+        if isinstance(d, L.GconvDesc):
+            print("%4d %-6s %-4d %5d %5d %5d %6d %9.2f %8.1f %7.1f" % (i, names.get(tag, "?"), d.epi, d.ntaps, d.in0.C + d.in1.C, d.Cout,
+                                                                  d.Fout, g, med[i], g / med[i] * 1e3))
+        else:
+            print("%4d %-6s %-4s %5s %5s %5s %6s %9.2f %8.1f %7.1f" % (i, names.get(tag, "?"), type(d).__name__[:4], "", "", "", "", g, med[i],
+                                                                  g / med[i] * 1e3))
