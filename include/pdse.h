@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PDSE_ABI_VERSION 1
+#define PDSE_ABI_VERSION 2
 
 typedef void* pdse_stream_t; /* hipStream_t */
 
@@ -117,6 +117,23 @@ typedef struct pdse_gconv_desc {
   const float* w3;
   int32_t p1mask;
   int32_t Fout1;
+  /* Chained 1x1 convolutions (BIGLU with C2 == 64, korder 1 only): the block output y (64 channels, after the
+     folded BatchNorm and the activation) feeds, register to register, nx_n <= 3 further 1x1 convolutions of 32
+     output channels each - the NEXT stage's conv1 (model/diff3.py:146-149, :343-345) and, in the encoder, the
+     skip-connection halves of the two decoders' conv1 (the 128-channel concat of :343 split by linearity):
+         z_i = Wn_i y + nx_bias[i][b] (+ nx_add[i] at the same address),  stored to nx_out[i].
+     nx_w: [nx_n][2][16][64] chain-packed like wc2.  Element address of channel c, frame t, bin q:
+         nx_out[i] + b*nx_sb[i] + c*nx_sc[i] + t*nx_st[i] + q*nx_sf[i] + nx_off[i]
+     (dual-phase launches: q = 2j, 2j+1; nx_n == 1 there).  nx_row0 >= 0: that tile also gets its bias written to
+     "frame -1" (address without nx_off) by the lanes of frame 0 - the encoder's explicit pad frame.
+     nx_keep == 0: y itself is not stored (nobody else reads it). */
+  const float* nx_w;
+  const float* nx_bias[3];
+  const float* nx_add[3];
+  float* nx_out[3];
+  int64_t nx_bias_sb[3];
+  int64_t nx_sb[3], nx_sc[3], nx_st[3], nx_sf[3], nx_off[3];
+  int32_t nx_n, nx_keep, nx_row0, nx_pad_;
 } pdse_gconv_desc;
 
 /* Diffusion-step embedding + every per-stage time bias folded through the following 1x1

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PDSE_LIB") or os.path.join(_HERE, "libpdse.so")   # PDSE_LIB: diagnostic builds only
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 ACT_NONE, ACT_PRELU, ACT_ELU, ACT_SIGMOID = 0, 1, 2, 3
 EPI_LINEAR, EPI_GLU, EPI_BIGLU = 0, 1, 2
@@ -44,6 +44,9 @@ class GconvDesc(C.Structure):
         ("out_sf", _i64), ("out_off", _i64),
         ("out_cr", _i32), ("B", _i32), ("Tout", _i32), ("Fout", _i32),
         ("korder", _i32), ("ksteps1", _i32), ("w2", _fp), ("w3", _fp), ("p1mask", _i32), ("Fout1", _i32),
+        ("nx_w", _fp), ("nx_bias", _fp * 3), ("nx_add", _fp * 3), ("nx_out", _fp * 3), ("nx_bias_sb", _i64 * 3),
+        ("nx_sb", _i64 * 3), ("nx_sc", _i64 * 3), ("nx_st", _i64 * 3), ("nx_sf", _i64 * 3), ("nx_off", _i64 * 3),
+        ("nx_n", _i32), ("nx_keep", _i32), ("nx_row0", _i32), ("nx_pad_", _i32),
     ]
 
 

@@ -171,6 +171,16 @@ int pdse_gconv_launch(const pdse_gconv_desc* d, hipStream_t s) {
     PDSE_REQUIRE(d->xf_mode != 2 || (d->xf_scale1 && d->xf_shift1), "xf_mode 2 without second set");
   }
   PDSE_REQUIRE((d->post_scale == nullptr) == (d->post_shift == nullptr), "post_scale/post_shift must come together");
+  if (d->nx_n != 0) {
+    PDSE_REQUIRE(d->nx_n > 0 && d->nx_n <= 3 && d->nx_w, "nx: 1..3 chained tiles and their weights");
+    PDSE_REQUIRE(d->epi == PDSE_EPI_BIGLU && d->korder == 1 && d->C2 == 64 && d->out_cr == 1,
+                 "nx: chained 1x1 tiles need the pipelined BIGLU kernel with a 64-channel block output");
+    for (int i = 0; i < d->nx_n; ++i) PDSE_REQUIRE(d->nx_bias[i] && d->nx_out[i], "nx: bias / output pointer missing");
+    PDSE_REQUIRE(d->nx_row0 < d->nx_n, "nx_row0 out of range");
+    PDSE_REQUIRE(d->w2 == nullptr || (d->nx_n == 1 && d->nx_keep == 0 && d->nx_row0 < 0),
+                 "nx: a dual-phase launch chains one tile and does not keep its own output");
+    PDSE_REQUIRE(d->nx_keep == 0 || d->out, "nx_keep without an output pointer");
+  }
   if (d->korder == 1) {
     PDSE_REQUIRE(!d->cin1, "korder 1 needs Cin >= 2");
     return pdse_gconv2_launch(d, s);

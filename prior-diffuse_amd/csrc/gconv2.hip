@@ -53,7 +53,7 @@ __device__ __forceinline__ float f4get(const float4& q, const int i) {
 // PP: ping-pong two register sets (layers with few waves per SIMD need the ILP); otherwise one
 //     set per chunk and the other resident waves hide the load latency.
 // P1MASK != 0: dual-phase transposed conv — taps in the mask also feed the odd output bins.
-template <int EPI, int MT, int NT, int CP, bool SRC2, int XF, bool PP, int P1MASK = 0>
+template <int EPI, int MT, int NT, int CP, bool SRC2, int XF, bool PP, int P1MASK = 0, bool NX = false>
 __global__ __launch_bounds__(256, PDSE_WAVES_PER_EU) void gconv2_kernel(const pdse_gconv_desc d) {
   constexpr bool DUAL = (EPI != PDSE_EPI_LINEAR);
   constexpr int N = NT * CP;
@@ -94,6 +94,12 @@ __global__ __launch_bounds__(256, PDSE_WAVES_PER_EU) void gconv2_kernel(const pd
         tail_lds[4288 + tid] = d.post_scale[tid];
         tail_lds[4352 + tid] = d.post_shift[tid];
       }
+    }
+    if (d.nx_n > 0) {   // chained next-stage 1x1 tiles + their biases for this batch item
+      for (int i = tid; i < d.nx_n * 2048; i += 256) tail_lds[PDSE_TAIL_NXW + i] = d.nx_w[i];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+        if (i < d.nx_n && tid < 32) tail_lds[PDSE_TAIL_NXB + 32 * i + tid] = d.nx_bias[i][(int64_t)b * d.nx_bias_sb[i] + tid];
     }
   }
 
@@ -263,9 +269,11 @@ __global__ __launch_bounds__(256, PDSE_WAVES_PER_EU) void gconv2_kernel(const pd
                        // instead measured the same: the barrier is not what the tail costs)
     float* const sw = tail_lds;
     const pdse_tail tl{sw, sw + 1024, sw + 2048, sw + 4096, sw + 4128, sw + 4160, sw + 4192, sw + 4224,
-                       d.post_scale ? sw + 4288 : nullptr, sw + 4352};
+                       d.post_scale ? sw + 4288 : nullptr, sw + 4352, sw + PDSE_TAIL_NXW, sw + PDSE_TAIL_NXB};
     if constexpr (P1MASK != 0)   // even + odd bins of this lane, paired stores
-      biglu_dual_epilogue(d, tl, acc0[0], acc1[0], acc2[0], acc3[0], b, t, j, pvalid, lane, h);
+      biglu_dual_epilogue<NX>(d, tl, acc0[0], acc1[0], acc2[0], acc3[0], b, t, j, pvalid, lane, h);
+    else if (d.nx_n > 0)         // block output chained into the next stage's 1x1 convolutions
+      biglu_nx_epilogue(d, tl, acc0[0], acc1[0], b, t, j, pvalid, lane, h);
     else
       gconv_epilogue<EPI, MT>(d, tl, acc0, acc1, b, t, j, pvalid, lane, h, mt0, mtiles);
   } else {
@@ -353,10 +361,13 @@ int pdse_gconv2_launch(const pdse_gconv_desc* d, hipStream_t s) {
       return 1;
     }
     if (nt == 4 && d->p1mask == 5) {
-      hipLaunchKernelGGL((gconv2_kernel<PDSE_EPI_BIGLU, 1, 4, 2, false, 0, true, 5>), grid, block, 0, s, *d);
+      if (d->nx_n > 0)
+        hipLaunchKernelGGL((gconv2_kernel<PDSE_EPI_BIGLU, 1, 4, 2, false, 0, true, 5, true>), grid, block, 0, s, *d);
+      else
+        hipLaunchKernelGGL((gconv2_kernel<PDSE_EPI_BIGLU, 1, 4, 2, false, 0, true, 5>), grid, block, 0, s, *d);
       return pdse_check_launch("gconv2");
     }
-    if (nt == 6 && d->p1mask == 27) {
+    if (nt == 6 && d->p1mask == 27 && d->nx_n == 0) {
       hipLaunchKernelGGL((gconv2_kernel<PDSE_EPI_BIGLU, 1, 6, 2, false, 0, false, 27>), grid, block, 0, s, *d);
       return pdse_check_launch("gconv2");
     }

@@ -49,12 +49,16 @@ struct pdse_tail {
   const float* bc2;
   const float* ps;  // nullptr: no folded BatchNorm
   const float* pt;
+  const float* nxw; // chained next-stage 1x1 tiles [nx_n][2][16][64]
+  const float* nxb; // their biases of this workgroup's batch item [nx_n][32]
 };
-// LDS image: [wlc 1024][wrc 1024][wc2 2048][bl 32][br 32][blc 32][brc 32][bc2 64][ps 64][pt 64]
-#define PDSE_TAIL_FLOATS (1024 + 1024 + 2048 + 4 * 32 + 3 * 64)
+// LDS image: [wlc 1024][wrc 1024][wc2 2048][bl 32][br 32][blc 32][brc 32][bc2 64][ps 64][pt 64][nxw 3*2048][nxb 3*32]
+#define PDSE_TAIL_NXW (1024 + 1024 + 2048 + 4 * 32 + 3 * 64)
+#define PDSE_TAIL_NXB (PDSE_TAIL_NXW + 3 * 2048)
+#define PDSE_TAIL_FLOATS (PDSE_TAIL_NXB + 3 * 32)
 
 __device__ __forceinline__ pdse_tail tail_from_desc(const pdse_gconv_desc& d) {
-  return pdse_tail{d.wlc, d.wrc, d.wc2, d.bias0, d.bias1, d.blc, d.brc, d.bc2, d.post_scale, d.post_shift};
+  return pdse_tail{d.wlc, d.wrc, d.wc2, d.bias0, d.bias1, d.blc, d.brc, d.bc2, d.post_scale, d.post_shift, nullptr, nullptr};
 }
 
 template <int EPI, int MT, bool CR1>
@@ -231,6 +235,67 @@ __device__ __forceinline__ void biglu_tail_values(const pdse_gconv_desc& d, cons
   }
 }
 
+// One chained 1x1 tile: z = z0 + Wn_i y over the 64 channels of the block output held in accumulator order.
+__device__ __forceinline__ f32x16 nx_tile_acc(const pdse_tail& tl, const int i, const float (&Y)[2][16], const int lane,
+                                              f32x16 Z) {
+  const float* w = tl.nxw + (size_t)i * 2048 + lane;
+#pragma unroll
+  for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Z = __builtin_amdgcn_mfma_f32_32x32x2f32(w[(m2 * 16 + r) * 64], Y[m2][r], Z, 0, 0, 0);
+  return Z;
+}
+
+__device__ __forceinline__ f32x16 nx_tile(const pdse_tail& tl, const int i, const float (&Y)[2][16], const int lane) {
+  f32x16 Z;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) Z[r] = 0.f;
+  const float* w = tl.nxw + (size_t)i * 2048 + lane;
+#pragma unroll
+  for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Z = __builtin_amdgcn_mfma_f32_32x32x2f32(w[(m2 * 16 + r) * 64], Y[m2][r], Z, 0, 0, 0);
+  return Z;
+}
+
+// Single-phase BIGLU tail with chained next-stage 1x1 convolutions (pdse.h: nx_*); out_cr == 1, C2 == 64.
+__device__ __forceinline__ void biglu_nx_epilogue(const pdse_gconv_desc& d, const pdse_tail& tl, const f32x16& a0,
+                                                  const f32x16& a1, const int b, const int t, const int j,
+                                                  const bool pvalid, const int lane, const int h) {
+  float Y[2][16];
+  float* const obase = d.out + ((int64_t)b * d.out_sb + (int64_t)t * d.out_st + (int64_t)j * d.out_sf + d.out_off);
+  const int64_t cstep = d.out_sc_hi;
+  const bool keep = d.nx_keep != 0 && pvalid;
+  biglu_tail_values(d, tl, a0, a1, lane, h, [&](const int m2, const int r, const float v) {
+    Y[m2][r] = v;
+    if (keep) obase[(int64_t)(32 * m2 + 4 * h) * cstep + (int64_t)PDSE_KR(r) * cstep] = v;
+  });
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    if (i >= d.nx_n) break;
+    const f32x16 Z = nx_tile(tl, i, Y, lane);
+    const int64_t sc = d.nx_sc[i];
+    const int64_t rowbase = (int64_t)b * d.nx_sb[i] + (int64_t)j * d.nx_sf[i] + (int64_t)(4 * h) * sc;
+    const int64_t off = rowbase + (int64_t)t * d.nx_st[i] + d.nx_off[i];
+    float* const zb = d.nx_out[i] + off;
+    const float* const ab = d.nx_add[i] ? d.nx_add[i] + off : nullptr;
+    const float* const pb = tl.nxb + 32 * i + 4 * h;
+    if (pvalid) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = Z[r] + pb[PDSE_KR(r)];
+        if (ab) v += ab[(int64_t)PDSE_KR(r) * sc];
+        zb[(int64_t)PDSE_KR(r) * sc] = v;
+      }
+      if (i == d.nx_row0 && t == 0) {   // explicit pad frame of the next encoder stage: conv1(0 + tp) = the folded bias
+        float* const z0 = d.nx_out[i] + rowbase;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z0[(int64_t)PDSE_KR(r) * sc] = pb[PDSE_KR(r)];
+      }
+    }
+  }
+}
+
 // one 8-byte store of two neighbouring bins; the address is only 4-byte aligned (odd row lengths),
 // which global_store_dwordx2 accepts
 __device__ __forceinline__ void store_pair(float* p, const float a, const float b) {
@@ -240,10 +305,46 @@ __device__ __forceinline__ void store_pair(float* p, const float a, const float 
 }
 
 // Dual-phase epilogue (out_cr == 1, C2 == 64 or 1): even bin at obase, odd bin one bin stride later.
+// NX: the launch chains the next stage's conv1 (its own register budget: a separate instantiation).
+template <bool NX>
 __device__ __forceinline__ void biglu_dual_epilogue(const pdse_gconv_desc& d, const pdse_tail& tl, const f32x16& a0,
                                                     const f32x16& a1, const f32x16& a2, const f32x16& a3, const int b,
                                                     const int t, const int j, const bool pvalid, const int lane,
                                                     const int h) {
+  if constexpr (NX) {
+    // the 64-channel output of either phase only feeds the chained next-stage conv1 (nx_keep == 0): nothing of it is
+    // stored.  The addend (the encoder's skip half + time bias) is requested BEFORE the tail whose MFMAs hide its
+    // latency, one phase at a time (16 registers each), and seeds the chained tile's accumulator.
+    const int64_t sc = d.nx_sc[0], nbin = d.nx_sf[0] >> 1;
+    const int64_t off = (int64_t)b * d.nx_sb[0] + (int64_t)t * d.nx_st[0] + (int64_t)j * d.nx_sf[0] + d.nx_off[0] + (int64_t)(4 * h) * sc;
+    float* const zb = d.nx_out[0] + off;
+    const float* const ab = d.nx_add[0] ? d.nx_add[0] + off : nullptr;
+    const float* const pb = tl.nxb + 4 * h;
+    const bool two = pvalid && j < d.Fout1;
+    float Y[2][16];
+    f32x16 Z0, Z1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Z0[r] = (ab && pvalid) ? ab[(int64_t)PDSE_KR(r) * sc] : 0.f;
+    __builtin_amdgcn_sched_barrier(0);
+    biglu_tail_values(d, tl, a0, a1, lane, h, [&](const int m2, const int r, const float v) { Y[m2][r] = v; });
+    Z0 = nx_tile_acc(tl, 0, Y, lane, Z0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Z1[r] = (ab && two) ? ab[(int64_t)PDSE_KR(r) * sc + nbin] : 0.f;
+    __builtin_amdgcn_sched_barrier(0);
+    biglu_tail_values(d, tl, a2, a3, lane, h, [&](const int m2, const int r, const float v) { Y[m2][r] = v; });
+    Z1 = nx_tile_acc(tl, 0, Y, lane, Z1);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float* p = zb + (int64_t)PDSE_KR(r) * sc;
+      const float ve = Z0[r] + pb[PDSE_KR(r)], vo = Z1[r] + pb[PDSE_KR(r)];
+      if (two && nbin == 1) store_pair(p, ve, vo);
+      else if (pvalid) {
+        p[0] = ve;
+        if (two) p[nbin] = vo;
+      }
+    }
+    return;
+  }
   // even bins first (kept in registers), then the odd tail streams its values straight into the paired stores
   float ye[2][16];
   biglu_tail_values(d, tl, a0, a1, lane, h, [&](const int m2, const int r, const float v) { ye[m2][r] = v; });

@@ -71,9 +71,11 @@ class PlanBase:
     def gconv(self, *, in0, in1=None, Tin, Fin, taps, sf_in, wk0, wk1=None, Cout, bias0=None, bias0_sb=0,
               bias1=None, bias1_sb=0, epi=L.EPI_LINEAR, act=L.ACT_NONE, act_slope=0.0, post=None,
               padrow=None, padrow_sb=0, padrow_off=0, xf=None, cin1=False, chain=None, resid=None, out,
-              out_strides, out_off=0, out_cr=1, B, Tout, Fout, tag=TAG_NONE, bias0_off=0, phase1=None):
+              out_strides, out_off=0, out_cr=1, B, Tout, Fout, tag=TAG_NONE, bias0_off=0, phase1=None, nx=None):
         """wk0/wk1: [K, Cout] float64 k-major matrices (packed here); biases/post: numpy or device tensors.
-        phase1 (dual-phase transposed conv, BIGLU): dict(wk2, wk3, mask, ntaps1, Fout1)."""
+        phase1 (dual-phase transposed conv, BIGLU): dict(wk2, wk3, mask, ntaps1, Fout1).
+        nx (BIGLU, C2 == 64): dict(keep, row0, tiles=[dict(w [32,64], bias, bias_off, bias_sb, out, strides (sb, sc, st,
+        sf), off, add)]) - 1x1 convolutions chained onto the block output (include/pdse.h: nx_*)."""
         ctx = self.ctx
         d = L.GconvDesc()
         d.in0 = in0
@@ -129,6 +131,20 @@ class PlanBase:
             else:
                 d.wc2 = ctx.up(P.pack_chain(chain["wc2"])).data_ptr()
             d.bc2 = ctx.up(chain["bc2"]).data_ptr()
+        if nx is not None:
+            tiles = nx["tiles"]
+            d.nx_n, d.nx_keep, d.nx_row0 = len(tiles), 1 if nx.get("keep") else 0, nx.get("row0", -1)
+            packs = []
+            for i, tl in enumerate(tiles):
+                w = np.asarray(tl["w"], np.float64)                       # [32 out, 64 in]
+                packs.append(np.concatenate([P.pack_chain(w[:, :32]), P.pack_chain(w[:, 32:])], 0))   # [2,16,64]
+                d.nx_bias[i] = Ctx.ptr(dev(tl["bias"]), tl.get("bias_off", 0))
+                d.nx_bias_sb[i] = tl.get("bias_sb", 0)
+                d.nx_out[i] = Ctx.ptr(tl["out"])
+                d.nx_sb[i], d.nx_sc[i], d.nx_st[i], d.nx_sf[i] = tl["strides"]
+                d.nx_off[i] = tl.get("off", 0)
+                d.nx_add[i] = Ctx.ptr(tl.get("add"))
+            d.nx_w = ctx.up(np.stack(packs, 0)).data_ptr()
         d.resid = Ctx.ptr(resid)
         d.out = Ctx.ptr(out)
         d.out_sb, d.out_sc_hi, d.out_sc_lo, d.out_st, d.out_sf = out_strides
@@ -160,6 +176,7 @@ class EpsNetPlan(PlanBase):
 
     ENC_F = [161, 79, 39, 19, 9, 4]
     fused_tcm = True        # one launch per TCM residual block (csrc/tcm.hip); False: three gather-GEMM launches
+    chain_conv1 = True      # every stage's 1x1 input convolution rides on the previous stage's tail (pdse.h: nx_*)
     NSLOT = 16  # 15 stages + en1 real-row bias
 
     def __init__(self, ctx, sd, B, T, time_cond=True, nsteps=1, plan=None, table=None, with_pre=None):
@@ -172,6 +189,10 @@ class EpsNetPlan(PlanBase):
         self.x_init = a(B, 2, T, F0) if self.with_pre else None
         self.out = a(B, 2, T, F0)
         self.H = a(B, 32, T + 1, F0)                 # conv1 output of the current block (+ explicit pad frame)
+        self.H2 = a(B, 32, T + 1, F0)                # ... of the next block, written by the current block's tail (chain_conv1)
+        # skip halves of the decoders' conv1 (+ time bias), produced by the encoder tails: [real|imag][stage 1..4]
+        self.Pskip = [[None] + [a(B, 32, T, self.ENC_F[k]) for k in range(1, 5)] for _ in range(2)]
+        self.zero32 = a(32, zero=True)
         self.en = [a(B, 64, T, f) for f in self.ENC_F[1:5]] + [a(B, 64, 4, T)]  # en5 stored [B,64,4,T]
         self.tcm_a, self.tcm_b = a(B, 256, T), a(B, 256, T)
         self.tcm_h, self.tcm_g = a(B, 64, T), a(B, 64, T)
@@ -240,9 +261,11 @@ class EpsNetPlan(PlanBase):
         """(tensor-or-array, element offset, batch stride) of a stage's conv1 bias."""
         return self.tbias, (step * self.B) * self.NSLOT * 32 + slot * 32, self.NSLOT * 32
 
-    def _biconvglu(self, step, k, src_x, src_init, Fin, out_t, out_strides):
-        """Encoder stage k (model/diff3.py:144-166 + :307-326 + BN + PReLU)."""
+    def _biconvglu(self, step, k, src_x, src_init, Fin, out_t, out_strides, H=None, do_conv1=True, nx=None):
+        """Encoder stage k (model/diff3.py:144-166 + :307-326 + BN + PReLU).  do_conv1 False: H already holds this
+        stage's conv1 output (chained onto the previous stage's tail); nx: 1x1 tiles chained onto this stage's tail."""
         B, T = self.B, self.T
+        H = self.H if H is None else H
         p = "en.conv%d" % k
         kw = 5 if k == 1 else 3
         Fout = (Fin - kw) // 2 + 1
@@ -262,34 +285,39 @@ class EpsNetPlan(PlanBase):
         # conv1(0 + tp) = the folded bias.  Rows 1..T hold the real frames.
         HT = T + 1
         h_out = (32 * HT * Fin, HT * Fin, 0, Fin, 1)
-        if k == 1 and self.time_cond:
+        if not do_conv1:
+            pass
+        elif k == 1 and self.time_cond:
             # real frames carry W1*b_preprocess in their bias (slot 15), the pad frame does not (slot 0)
             self.gconv(in0=src_x, in1=src_init, Tin=T, Fin=Fin, taps=[(0, 0)], sf_in=1, wk0=W1.T, Cout=32,
-                       bias0=bias0, bias0_off=off_real, bias0_sb=sbb, out=self.H, out_strides=h_out, out_off=Fin,
+                       bias0=bias0, bias0_off=off_real, bias0_sb=sbb, out=H, out_strides=h_out, out_off=Fin,
                        B=B, Tout=T, Fout=Fin, tag=TAG_EPS_CONV1)
             self.gconv(in0=src_x, in1=src_init, Tin=T, Fin=Fin, taps=[(-(T + 1), 0)], sf_in=1, wk0=W1.T, Cout=32,
-                       bias0=pad, bias0_off=off_pad, bias0_sb=sbb, out=self.H, out_strides=h_out,
+                       bias0=pad, bias0_off=off_pad, bias0_sb=sbb, out=H, out_strides=h_out,
                        B=B, Tout=1, Fout=Fin, tag=TAG_EPS_CONV1)
         else:
             # same bias for every frame: one launch over T+1 output frames reading input frame r-1
             self.gconv(in0=src_x, in1=src_init, Tin=T, Fin=Fin, taps=[(-1, 0)], sf_in=1, wk0=W1.T, Cout=32,
-                       bias0=bias0, bias0_off=off_real, bias0_sb=sbb, out=self.H, out_strides=h_out,
+                       bias0=bias0, bias0_off=off_real, bias0_sb=sbb, out=H, out_strides=h_out,
                        B=B, Tout=HT, Fout=Fin, tag=TAG_EPS_CONV1)
         kk, taps = P.conv_taps(2, kw, 0)            # H row r = frame r-1: weight row kt reads H row t + kt
         post = P.bn_fold(self.sd, "en.en%d.0" % k)
         chain = dict(C2=64, wlc=self.w(p + ".l_conv.weight")[:, :, 0, 0], blc=self.w(p + ".l_conv.bias"),
                      wrc=self.w(p + ".r_conv.weight")[:, :, 0, 0], brc=self.w(p + ".r_conv.bias"),
                      wc2=self.w(p + ".conv2.weight")[:, :, 0, 0], bc2=self.w(p + ".conv2.bias"))
-        self.gconv(in0=self.src(self.H, 32, *nchw(32, HT, Fin)), Tin=HT, Fin=Fin, taps=taps, sf_in=2,
+        self.gconv(in0=self.src(H, 32, *nchw(32, HT, Fin)), Tin=HT, Fin=Fin, taps=taps, sf_in=2,
                    wk0=P.conv_kmat(self.sd[p + ".l.weight"], kk), wk1=P.conv_kmat(self.sd[p + ".r.weight"], kk),
                    Cout=32, bias0=self.w(p + ".l.bias"), bias1=self.w(p + ".r.bias"), epi=L.EPI_BIGLU,
                    act=L.ACT_PRELU, act_slope=float(self.w("en.en%d.1.weight" % k)[0]), post=post,
-                   chain=chain, out=out_t, out_strides=out_strides, B=B, Tout=T, Fout=Fout, tag=TAG_EPS_BLOCK)
+                   chain=chain, out=out_t, out_strides=out_strides, B=B, Tout=T, Fout=Fout, tag=TAG_EPS_BLOCK, nx=nx)
         return Fout
 
-    def _biconvtransglu(self, step, slot, p, k, in0, in1, Fin, out_t, out_strides_fn, bn_prefix, prelu_key, out_off=0):
-        """Decoder stage (model/diff3.py:205-212 + :329-351, last frame chomped, BN, PReLU)."""
+    def _biconvtransglu(self, step, slot, p, k, in0, in1, Fin, out_t, out_strides_fn, bn_prefix, prelu_key, out_off=0,
+                        H=None, do_conv1=True, nx=None):
+        """Decoder stage (model/diff3.py:205-212 + :329-351, last frame chomped, BN, PReLU).  do_conv1 / nx as in
+        ``_biconvglu``."""
         B, T = self.B, self.T
+        H = self.H if H is None else H
         kw = 5 if k == 1 else 3
         Fout = 2 * (Fin - 1) + kw
         W1 = self.w(p + ".conv1.weight")[:, :, 0, 0].T                      # [32, 128]
@@ -298,9 +326,10 @@ class EpsNetPlan(PlanBase):
             bias0 = tb
         else:
             bias0, off, sbb = self.w(p + ".conv1.bias"), 0, 0
-        self.gconv(in0=in0, in1=in1, Tin=T, Fin=Fin, taps=[(0, 0)], sf_in=1, wk0=W1.T, Cout=32, bias0=bias0,
-                   bias0_off=off, bias0_sb=sbb, out=self.H, out_strides=nchw_out(32, T, Fin), B=B, Tout=T,
-                   Fout=Fin, tag=TAG_EPS_CONV1)
+        if do_conv1:
+            self.gconv(in0=in0, in1=in1, Tin=T, Fin=Fin, taps=[(0, 0)], sf_in=1, wk0=W1.T, Cout=32, bias0=bias0,
+                       bias0_off=off, bias0_sb=sbb, out=H, out_strides=nchw_out(32, T, Fin), B=B, Tout=T,
+                       Fout=Fin, tag=TAG_EPS_CONV1)
         C2 = 64 if k > 1 else 1
         post = P.bn_fold(self.sd, bn_prefix) if bn_prefix else None
         wc2 = self.w(p + ".conv2.weight")[:, :, 0, 0].T                     # [C2, 32]
@@ -312,7 +341,7 @@ class EpsNetPlan(PlanBase):
                       act=L.ACT_PRELU if prelu_key else L.ACT_NONE,
                       act_slope=float(self.w(prelu_key)[0]) if prelu_key else 0.0, post=post, chain=chain, out=out_t,
                       out_strides=(osb, osc, 0, ost, 2 * osf), B=B, Tout=T, tag=TAG_EPS_BLOCK)
-        src_h = self.src(self.H, 32, *nchw(32, T, Fin))
+        src_h = self.src(H, 32, *nchw(32, T, Fin))
         kk0, taps0 = P.convT_phase_taps(2, kw, 0)
         kk1, taps1 = P.convT_phase_taps(2, kw, 1)
         if not self.force_generic:
@@ -323,7 +352,7 @@ class EpsNetPlan(PlanBase):
                        mask=mask, ntaps1=len(taps1), Fout1=Fout // 2)
             self.gconv(in0=src_h, Tin=T, Fin=Fin, taps=taps0, sf_in=1, wk0=P.convT_kmat(self.sd[p + ".l.weight"], kk0),
                        wk1=P.convT_kmat(self.sd[p + ".r.weight"], kk0), out_off=out_off, Fout=(Fout + 1) // 2,
-                       phase1=ph1, **common)
+                       phase1=ph1, nx=nx, **common)
         else:
             for phase, (kk, taps) in enumerate(((kk0, taps0), (kk1, taps1))):
                 self.gconv(in0=src_h, Tin=T, Fin=Fin, taps=taps, sf_in=1, wk0=P.convT_kmat(self.sd[p + ".l.weight"], kk),
@@ -417,6 +446,10 @@ class EpsNetPlan(PlanBase):
                         v = getattr(d2, f)
                         if v and lo <= v < hi:
                             setattr(d2, f, v + delta)
+                    for i in range(d2.nx_n):
+                        v = d2.nx_bias[i]
+                        if v and lo <= v < hi:
+                            d2.nx_bias[i] = v + delta
                 self.add(d2, tag)
             return out
         begin = len(self.descs)
@@ -427,16 +460,39 @@ class EpsNetPlan(PlanBase):
     def _build_step(self, step, x, x_init, out):
         B, T = self.B, self.T
         s2 = nchw(2, T, F0)
+        chained = self.chain_conv1 and not self.force_generic
         # encoder: stage 1 reads (x, x_init) through the folded Preprocess 1x1
         src_x = self.src(x, 2, *s2)
         src_i = self.src(x_init, 2, *s2) if self.with_pre else None
         Fin = F0
+        Hc, Hn = self.H, self.H2
         for k in range(1, 6):
             if k < 5:
                 o, ostr = self.en[k - 1], nchw_out(64, T, self.ENC_F[k])
             else:
                 o, ostr = self.en[4], (64 * 4 * T, 4 * T, 0, 1, T)           # [B,64,4,T]: channel c*4+f of [B,256,T]
-            Fin = self._biconvglu(step, k, src_x, src_i, Fin, o, ostr)
+            nx = None
+            if chained and k < 5:
+                # this stage's 64-channel output is only ever read by 1x1 convolutions - the next stage's conv1 and the
+                # skip half of the two decoders' conv1 (diff3.py:343: conv1(cat(x, skip) + tp), split by linearity) -
+                # so its tail evaluates those in registers and the output itself is never written
+                Fo, HT = self.ENC_F[k], T + 1
+                bias_of = (lambda slot: dict(zip(("bias", "bias_off", "bias_sb"), self._bias_for(step, slot)))) \
+                    if self.time_cond else None
+                pn = "en.conv%d" % (k + 1)
+                t0 = dict(w=self.w(pn + ".conv1.weight")[:, :, 0, 0], out=Hn, strides=(32 * HT * Fo, HT * Fo, Fo, 1), off=Fo)
+                t0.update(bias_of(k) if self.time_cond else dict(bias=self.w(pn + ".conv1.bias")))
+                tiles = [t0]
+                for di, de in enumerate(("de_real", "de_imag")):
+                    pd = "%s.de%d.0" % (de, k)
+                    tl = dict(w=self.w(pd + ".conv1.weight")[:, :, 0, 0].T[:, 64:], out=self.Pskip[di][k],   # ConvTranspose: [in, out]
+                              strides=(32 * T * Fo, T * Fo, Fo, 1))
+                    tl.update(bias_of(5 + 5 * di + (5 - k)) if self.time_cond else dict(bias=self.w(pd + ".conv1.bias")))
+                    tiles.append(tl)
+                nx = dict(keep=False, row0=0, tiles=tiles)
+            Fin = self._biconvglu(step, k, src_x, src_i, Fin, o, ostr, H=Hc, do_conv1=(k == 1 or not chained), nx=nx)
+            if chained:
+                Hc, Hn = Hn, Hc
             src_x, src_i = self.src(o, 64, *nchw(64, T, Fin)), None
         # TCMs over [B,256,T]
         cur, nxt = self.en[4], self.tcm_a
@@ -459,6 +515,7 @@ class EpsNetPlan(PlanBase):
         for di, de in enumerate(("de_real", "de_imag")):
             in0 = self.src(tcm_out, 64, 256 * T, 4 * T, 1, T)               # [B,64,4,T] viewed as [B,64,T,4]
             Fin = 4
+            Hc, Hn = self.H, self.H2
             for n, k in enumerate((5, 4, 3, 2, 1)):
                 skip = self.en[k - 1]
                 if k == 5:
@@ -474,7 +531,17 @@ class EpsNetPlan(PlanBase):
                     o, ooff = out, di * T * F0
                     fn = lambda Fo: nchw_out(2, T, Fo)   # noqa: E731
                     bn, pr = None, None
-                Fin = self._biconvtransglu(step, 5 + 5 * di + n, p, k, in0, in1, Fin, o, fn, bn, pr, out_off=ooff)
+                nx = None
+                if chained and k > 1:
+                    # stage k-1's conv1 = W[:, :64] * (this stage's output) + the skip half the encoder left in Pskip
+                    Fo = 2 * (Fin - 1) + 3
+                    wn = self.w("%s.de%d.0.conv1.weight" % (de, k - 1))[:, :, 0, 0].T[:, :64]   # ConvTranspose: [in, out]
+                    nx = dict(keep=False, row0=-1, tiles=[dict(w=wn, bias=self.zero32, out=Hn, add=self.Pskip[di][k - 1],
+                                                                strides=(32 * T * Fo, T * Fo, Fo, 2))])
+                Fin = self._biconvtransglu(step, 5 + 5 * di + n, p, k, in0, in1, Fin, o, fn, bn, pr, out_off=ooff, H=Hc,
+                                           do_conv1=(k == 5 or not chained), nx=nx)
+                if chained:
+                    Hc, Hn = Hn, Hc
                 in0 = self.src(o, 64, *nchw(64, T, Fin))
         return out
 

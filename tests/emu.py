@@ -199,11 +199,32 @@ def run_gconv(d, mem):
                 Wc2 = _unpack_chain(mem.arr(d.wc2, t2 * 16 * 64), t2)[:d.C2]
                 y = np.einsum("oc,bctf->botf", Wc2, G) + mem.arr(d.bc2, d.C2)[None, :, None, None]
             y = post(y.astype(np.float32), d.C2)
-            co = np.arange(d.C2)[None, :, None, None]
-            idx = (out_off + bI * d.out_sb + (co // d.out_cr) * d.out_sc_hi + (co % d.out_cr) * d.out_sc_lo
-                   + tI * d.out_st + jI * d.out_sf + d.out_off + extra)
-            idx = np.broadcast_to(idx, y.shape)
-            out_flat[idx[..., :jmax]] = y[..., :jmax]
+            if d.nx_n == 0 or d.nx_keep:
+                co = np.arange(d.C2)[None, :, None, None]
+                idx = (out_off + bI * d.out_sb + (co // d.out_cr) * d.out_sc_hi + (co % d.out_cr) * d.out_sc_lo
+                       + tI * d.out_st + jI * d.out_sf + d.out_off + extra)
+                idx = np.broadcast_to(idx, y.shape)
+                out_flat[idx[..., :jmax]] = y[..., :jmax]
+            # chained next-stage 1x1 tiles (pdse.h: nx_*)
+            for i in range(d.nx_n):
+                Wn = np.concatenate([_unpack_chain(mem.arr(d.nx_w, 6 * 1024)[(2 * i + m2) * 1024:(2 * i + m2 + 1) * 1024], 1)
+                                     for m2 in (0, 1)], axis=1)                    # [32 out, 64 in]
+                bflat, boff = mem.view(d.nx_bias[i])
+                bz = bflat[boff + np.arange(B)[:, None] * d.nx_bias_sb[i] + np.arange(32)[None, :]][:, :, None, None]
+                z = (np.einsum("oc,bctf->botf", Wn, y) + bz).astype(np.float32)
+                zflat, zoff = mem.view(d.nx_out[i])
+                co = np.arange(32)[None, :, None, None]
+                rel = (bI * d.nx_sb[i] + co * d.nx_sc[i] + tI * d.nx_st[i] + jI * d.nx_sf[i] + d.nx_off[i]
+                       + (d.nx_sf[i] // 2 if extra else 0))
+                rel = np.broadcast_to(rel, z.shape)[..., :jmax]
+                z = z[..., :jmax]
+                if d.nx_add[i]:
+                    aflat, aoff = mem.view(d.nx_add[i])
+                    z = z + aflat[aoff + rel]
+                zflat[zoff + rel] = z
+                if i == d.nx_row0:
+                    r0 = np.broadcast_to(bI * d.nx_sb[i] + co * d.nx_sc[i] + jI * d.nx_sf[i] + 0 * tI, (B, 32) + z.shape[2:])[:, :, :1]
+                    zflat[zoff + r0[..., :jmax]] = np.broadcast_to(bz, r0.shape)[..., :jmax]
 
         tail(acc0, acc1, 0, Fo)
         if ph1 is not None:

@@ -100,7 +100,11 @@ def test_time_embedding_golden(L, weights):
     assert np.array_equal(net.table.cpu().numpy(), g["table"])
 
 
-def test_diffunet1_golden_small(L, weights):
+@pytest.mark.parametrize("chained", [True, False])
+def test_diffunet1_golden_small(L, weights, chained, monkeypatch):
+    """chained (the default): conv1 of every stage rides on the previous stage's tail, encoder/decoder block outputs
+    are never stored; unchained: the per-stage launches, with the stage-1 encoder output checked as well."""
+    monkeypatch.setattr(pkg("nets").EpsNetPlan, "chain_conv1", chained)
     g = golden("diffunet1_small")
     op = pkg("ops").DiffUNet1Op(weights("DiffUNet1"), DEV)
     B, T = int(g["B"]), int(g["T"])
@@ -109,7 +113,8 @@ def test_diffunet1_golden_small(L, weights):
     out = op(x.to(DEV), xi.to(DEV), torch.from_numpy(g["t"]).to(DEV))
     net = op._plans[(B, T)]
     _sync()
-    assert rel_l2(net.en[0].cpu()[:, ::4], g["en1_c4"]) < 2e-5
+    if not chained:
+        assert rel_l2(net.en[0].cpu()[:, ::4], g["en1_c4"]) < 2e-5
     assert rel_l2(net.en[4].cpu().permute(0, 1, 3, 2), g["en5"]) < 2e-5
     assert rel_l2(out.cpu(), g["out"]) < 2e-5
     gi = golden("diffunet1_int_t")

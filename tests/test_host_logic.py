@@ -28,14 +28,20 @@ def test_pack_roundtrip():
     assert sorted(P.RHO.reshape(-1).tolist()) == list(range(32))
 
 
-def test_eps_net_plan_vs_oracle(weights):
+@pytest.mark.parametrize("chained", [True, False])
+def test_eps_net_plan_vs_oracle(weights, chained, monkeypatch):
+    """chained: every stage's conv1 rides on the previous stage's tail and the encoder/decoder block outputs are never
+    stored (only en[4], the TCM input, is); unchained: the per-stage launches with all intermediates in memory."""
     nets = pkg("nets")
+    monkeypatch.setattr(nets.EpsNetPlan, "chain_conv1", chained)
     B, T = 2, 12
     sd = weights("DiffUNet1")
     ctx = nets.Ctx("cpu")
     net = nets.EpsNetPlan(ctx, sd, B, T, time_cond=True, nsteps=1)
     net.build_time()
     net.build_step(0)
+    n_conv1 = sum(1 for _, tag in net.descs if tag == nets.TAG_EPS_CONV1)
+    assert n_conv1 == (4 if chained else 16)          # encoder stage 1 (real frames + pad frame) and decoder stage 5 x 2
     x, xi = seeded((B, 2, T, 161), 3), seeded((B, 2, T, 161), 4) * 0.3
     t = torch.tensor([4.086654, 22.992493])
     net.x.copy_(x)
@@ -46,7 +52,8 @@ def test_eps_net_plan_vs_oracle(weights):
     with torch.no_grad():
         ref = R.diffunet1_forward(sd, x, xi, t, taps=taps)
     assert rel_l2(net.temb[0], taps["temb"]) < TOL
-    assert rel_l2(net.en[0], taps["en_list"][0]) < TOL
+    if not chained:
+        assert rel_l2(net.en[0], taps["en_list"][0]) < TOL
     assert rel_l2(net.en[4].permute(0, 1, 3, 2), taps["en_list"][4]) < TOL
     assert rel_l2(net.out, ref) < TOL
 
@@ -126,7 +133,12 @@ def test_step_descriptors_are_cloned_not_repacked(weights):
             moved += 1
         if a.padrow != b.padrow:
             assert b.padrow - a.padrow == delta
-    assert moved == 16      # 15 stages + the separate pad-frame launch of encoder stage 1
+        assert a.nx_n == b.nx_n and a.nx_w == b.nx_w
+        for i in range(a.nx_n):                            # chained conv1 tiles carry the per-step time bias
+            if a.nx_bias[i] != b.nx_bias[i]:
+                assert b.nx_bias[i] - a.nx_bias[i] == delta
+                moved += 1
+    assert moved == 16      # 15 stage biases + the pad-frame launch of encoder stage 1 (as launches or chained tiles)
 
 
 def test_stft_bases_against_numpy_fft():
