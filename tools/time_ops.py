@@ -68,6 +68,7 @@ if os.environ.get("TABLE"):
             if d.w2:
                 pos1 = d.B * d.Tout * d.Fout1
                 fl += 2.0 * pos1 * 2 * (bin(d.p1mask).count("1") * cin) * 32 + pos1 * tail
+            fl += 2.0 * 64 * 32 * d.nx_n * (pos0 + (d.B * d.Tout * d.Fout1 if d.w2 else 0))
         return fl / 1e9
     print("%4s %-6s %-4s %5s %5s %5s %6s %9s %8s %7s" % ("op", "tag", "epi", "taps", "cin", "cout", "Fout", "GFLOP", "us", "TF/s"))
     for i, (d, tag) in enumerate(net.descs):
