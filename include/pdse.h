@@ -292,15 +292,21 @@ typedef struct pdse_attn_desc {
   int32_t B, T, F, E, heads, axis, pad0_, pad1_;
 } pdse_attn_desc;
 
-/* Bidirectional single-layer GRU (dbaiat.py:45,83) along one axis, hidden 64, persistent per
+/* Bidirectional single-layer GRU (dbaiat.py:45,83) along one axis, hidden H = 64 or 128, persistent per
  * line: gx [B,2*3*H,T,F] = W_ih x + b_ih of both directions ([fw r,z,n | bw r,z,n]);
- * whh [2][3H/32][H/2][64] MFMA A fragments, bhh [2][3H]; y [B,2H,T,F] = [fw | bw]. */
+ * whh [2][3H/32][H/2][64] MFMA A fragments, bhh [2][3H]; y [B,2H,T,F] = [fw | bw].
+ * Fused input projection (H == 64 only): x != NULL replaces gx by the layer input x [B,H/2,T,F] itself;
+ * wih [2][3H/32][H/4][64] A fragments of W_ih, bih [2][3H] - the projection then runs inside the recurrence
+ * kernel and the 12x wider gx tensor never exists. */
 typedef struct pdse_gru_desc {
   const float* gx;
   const float* whh;
   const float* bhh;
   float* y;
   int32_t B, T, F, H, axis, pad_;
+  const float* x;
+  const float* wih;
+  const float* bih;
 } pdse_gru_desc;
 
 /* Swap the two inner axes of [N][R][Cc] -> [N][Cc][R] (fp32) through 32x32 LDS tiles: converts between the

@@ -744,6 +744,7 @@ class AiaPlan(PlanBase):
     on the operators of csrc/aia.hip."""
 
     FH = 80  # bins after the stride-2 encoder conv
+    fused_gru_input = True   # d_model 32: W_ih x inside the GRU kernel (csrc/aia.hip, gru_kernel<64, true>)
 
     def __init__(self, ctx, sd, B, T, plan=None, d=32):
         """d: d_model of the transformer layers (32: AIA_Transformer(64, 64); 64: AIA_Transformer_merge(128, 64))."""
@@ -880,10 +881,15 @@ class AiaPlan(PlanBase):
             gx_in, s2_out = self.t_a, self.t_b
         else:
             gx_in, s2_out = self.n_b, self.s2
-        self._pw(gx_in, dm, Wih.T, bih, self.gx, 12 * dm, FH, in_layout=lay, out_layout=lay)
         whh = np.stack([P.pack_a(self.w(g + "weight_hh_l0" + suf).T) for suf in ("", "_reverse")], 0)   # [2, 3H/32, H/2, 64]
         bhh = np.stack([self.w(g + "bias_hh_l0"), self.w(g + "bias_hh_l0_reverse")], 0)
         gd = L.GruDesc()
+        if self.fused_gru_input and dm == 32:
+            # the input projection runs inside the recurrence kernel: the 12x wider gx tensor never exists
+            wih = np.stack([P.pack_a(self.w(g + "weight_ih_l0" + suf).T) for suf in ("", "_reverse")], 0)   # [2, 6, 16, 64]
+            gd.x, gd.wih, gd.bih = gx_in.data_ptr(), self.ctx.up(wih).data_ptr(), self.ctx.up(bih.reshape(2, -1)).data_ptr()
+        else:
+            self._pw(gx_in, dm, Wih.T, bih, self.gx, 12 * dm, FH, in_layout=lay, out_layout=lay)
         gd.gx, gd.y = self.gx.data_ptr(), self.gy.data_ptr()
         gd.whh, gd.bhh = self.ctx.up(whh).data_ptr(), self.ctx.up(bhh).data_ptr()
         gd.B, gd.H, gd.axis = B, 2 * dm, 1                            # lines on the innermost axis, sequence on the outer
