@@ -134,6 +134,12 @@ typedef struct pdse_gconv_desc {
   int64_t nx_bias_sb[3];
   int64_t nx_sb[3], nx_sc[3], nx_st[3], nx_sf[3], nx_off[3];
   int32_t nx_n, nx_keep, nx_row0, nx_pad_;
+  /* BIGLU, chained form only: biases of the two gather convolutions for OUTPUT FRAME 0 (batch stride bias0_sb /
+     bias1_sb like bias0 / bias1); NULL: frame 0 uses bias0 / bias1 like every other frame.  Needed when conv1 is
+     composed into the gather weights (encoder stage 1): frame 0 sees the zero pad frame, whose conv1 value is the
+     pad bias, through the kt = 0 taps. */
+  const float* bias0_t0;
+  const float* bias1_t0;
 } pdse_gconv_desc;
 
 /* Diffusion-step embedding + every per-stage time bias folded through the following 1x1

@@ -181,6 +181,9 @@ int pdse_gconv_launch(const pdse_gconv_desc* d, hipStream_t s) {
                  "nx: a dual-phase launch chains one tile and does not keep its own output");
     PDSE_REQUIRE(d->nx_keep == 0 || d->out, "nx_keep without an output pointer");
   }
+  PDSE_REQUIRE((d->bias0_t0 == nullptr) == (d->bias1_t0 == nullptr), "bias0_t0 / bias1_t0 must come together");
+  PDSE_REQUIRE(d->bias0_t0 == nullptr || (d->nx_n > 0 && d->w2 == nullptr),
+               "frame-0 biases are a feature of the chained single-phase BIGLU tail");
   if (d->korder == 1) {
     PDSE_REQUIRE(!d->cin1, "korder 1 needs Cin >= 2");
     return pdse_gconv2_launch(d, s);

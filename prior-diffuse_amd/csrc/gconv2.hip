@@ -83,8 +83,11 @@ __global__ __launch_bounds__(256, PDSE_WAVES_PER_EU) void gconv2_kernel(const pd
     }
     for (int i = tid; i < w2n; i += 256) tail_lds[2048 + i] = d.wc2[i];
     if (tid < 32) {
-      tail_lds[4096 + tid] = d.bias0[tid];
-      tail_lds[4128 + tid] = d.bias1[tid];
+      const float bl = d.bias0[(int64_t)b * d.bias0_sb + tid], br = d.bias1[(int64_t)b * d.bias1_sb + tid];
+      tail_lds[4096 + tid] = bl;
+      tail_lds[4128 + tid] = br;
+      tail_lds[PDSE_TAIL_B0 + tid] = d.bias0_t0 ? d.bias0_t0[(int64_t)b * d.bias0_sb + tid] : bl;
+      tail_lds[PDSE_TAIL_B0 + 32 + tid] = d.bias1_t0 ? d.bias1_t0[(int64_t)b * d.bias1_sb + tid] : br;
       tail_lds[4160 + tid] = d.blc[tid];
       tail_lds[4192 + tid] = d.brc[tid];
     }
@@ -269,7 +272,8 @@ __global__ __launch_bounds__(256, PDSE_WAVES_PER_EU) void gconv2_kernel(const pd
                        // instead measured the same: the barrier is not what the tail costs)
     float* const sw = tail_lds;
     const pdse_tail tl{sw, sw + 1024, sw + 2048, sw + 4096, sw + 4128, sw + 4160, sw + 4192, sw + 4224,
-                       d.post_scale ? sw + 4288 : nullptr, sw + 4352, sw + PDSE_TAIL_NXW, sw + PDSE_TAIL_NXB};
+                       d.post_scale ? sw + 4288 : nullptr, sw + 4352, sw + PDSE_TAIL_NXW, sw + PDSE_TAIL_NXB,
+                       sw + PDSE_TAIL_B0, sw + PDSE_TAIL_B0 + 32};
     if constexpr (P1MASK != 0)   // even + odd bins of this lane, paired stores
       biglu_dual_epilogue<NX>(d, tl, acc0[0], acc1[0], acc2[0], acc3[0], b, t, j, pvalid, lane, h);
     else if (d.nx_n > 0)         // block output chained into the next stage's 1x1 convolutions
@@ -371,6 +375,9 @@ int pdse_gconv2_launch(const pdse_gconv_desc* d, hipStream_t s) {
       hipLaunchKernelGGL((gconv2_kernel<PDSE_EPI_BIGLU, 1, 6, 2, false, 0, false, 27>), grid, block, 0, s, *d);
       return pdse_check_launch("gconv2");
     }
+  } else if (d->epi == PDSE_EPI_BIGLU && two && xf == 0 && d->C2 <= 64 && d->w2 == nullptr) {
+    // encoder stage 1 with conv1 composed into the gather weights: (x, x_init) read directly
+    if (nt == 10) GO(PDSE_EPI_BIGLU, 10, 2, true, 0, false, false, false);
   } else if (d->epi == PDSE_EPI_BIGLU && !two && xf == 0 && d->C2 <= 64) {   // tail image in LDS holds C2 <= 64
     if (nt == 2) GO(PDSE_EPI_BIGLU, 2, 4, false, 0, true, true, true);
     if (nt == 4) GO(PDSE_EPI_BIGLU, 4, 2, false, 0, true, true, true);

@@ -51,14 +51,18 @@ struct pdse_tail {
   const float* pt;
   const float* nxw; // chained next-stage 1x1 tiles [nx_n][2][16][64]
   const float* nxb; // their biases of this workgroup's batch item [nx_n][32]
+  const float* bl0; // bl / br for output frame 0 (pdse.h: bias0_t0 / bias1_t0; copies of bl / br when absent)
+  const float* br0;
 };
 // LDS image: [wlc 1024][wrc 1024][wc2 2048][bl 32][br 32][blc 32][brc 32][bc2 64][ps 64][pt 64][nxw 3*2048][nxb 3*32]
 #define PDSE_TAIL_NXW (1024 + 1024 + 2048 + 4 * 32 + 3 * 64)
 #define PDSE_TAIL_NXB (PDSE_TAIL_NXW + 3 * 2048)
-#define PDSE_TAIL_FLOATS (PDSE_TAIL_NXB + 3 * 32)
+#define PDSE_TAIL_B0 (PDSE_TAIL_NXB + 3 * 32)
+#define PDSE_TAIL_FLOATS (PDSE_TAIL_B0 + 2 * 32)
 
 __device__ __forceinline__ pdse_tail tail_from_desc(const pdse_gconv_desc& d) {
-  return pdse_tail{d.wlc, d.wrc, d.wc2, d.bias0, d.bias1, d.blc, d.brc, d.bc2, d.post_scale, d.post_shift, nullptr, nullptr};
+  return pdse_tail{d.wlc, d.wrc, d.wc2, d.bias0, d.bias1, d.blc, d.brc, d.bc2, d.post_scale, d.post_shift, nullptr, nullptr,
+                   d.bias0, d.bias1};
 }
 
 template <int EPI, int MT, bool CR1>
@@ -178,10 +182,11 @@ __device__ __forceinline__ void gconv_epilogue_impl(const pdse_gconv_desc& d, co
 // on their way to HBM: profiles/r01_pmc_traffic_v5.json showed 2x WRITE_SIZE).
 template <typename Sink>   // sink(m2, r, value) is called once per output element, in (m2, r) order
 __device__ __forceinline__ void biglu_tail_values(const pdse_gconv_desc& d, const pdse_tail& tl, const f32x16& accL,
-                                                  const f32x16& accR, const int lane, const int h, Sink&& sink) {
+                                                  const f32x16& accR, const int lane, const int h, Sink&& sink,
+                                                  const bool frame0 = false) {
   f32x16 L = accL, R = accR;
-  const float* pbl = tl.bl + 4 * h;
-  const float* pbr = tl.br + 4 * h;
+  const float* pbl = (frame0 ? tl.bl0 : tl.bl) + 4 * h;
+  const float* pbr = (frame0 ? tl.br0 : tl.br) + 4 * h;
   const float* pblc = tl.blc + 4 * h;
   const float* pbrc = tl.brc + 4 * h;
 #pragma unroll
@@ -269,7 +274,7 @@ __device__ __forceinline__ void biglu_nx_epilogue(const pdse_gconv_desc& d, cons
   biglu_tail_values(d, tl, a0, a1, lane, h, [&](const int m2, const int r, const float v) {
     Y[m2][r] = v;
     if (keep) obase[(int64_t)(32 * m2 + 4 * h) * cstep + (int64_t)PDSE_KR(r) * cstep] = v;
-  });
+  }, t == 0);
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     if (i >= d.nx_n) break;

@@ -71,7 +71,8 @@ class PlanBase:
     def gconv(self, *, in0, in1=None, Tin, Fin, taps, sf_in, wk0, wk1=None, Cout, bias0=None, bias0_sb=0,
               bias1=None, bias1_sb=0, epi=L.EPI_LINEAR, act=L.ACT_NONE, act_slope=0.0, post=None,
               padrow=None, padrow_sb=0, padrow_off=0, xf=None, cin1=False, chain=None, resid=None, out,
-              out_strides, out_off=0, out_cr=1, B, Tout, Fout, tag=TAG_NONE, bias0_off=0, phase1=None, nx=None):
+              out_strides, out_off=0, out_cr=1, B, Tout, Fout, tag=TAG_NONE, bias0_off=0, phase1=None, nx=None,
+              bias1_off=0, bias_t0=None):
         """wk0/wk1: [K, Cout] float64 k-major matrices (packed here); biases/post: numpy or device tensors.
         phase1 (dual-phase transposed conv, BIGLU): dict(wk2, wk3, mask, ntaps1, Fout1).
         nx (BIGLU, C2 == 64): dict(keep, row0, tiles=[dict(w [32,64], bias, bias_off, bias_sb, out, strides (sb, sc, st,
@@ -118,7 +119,9 @@ class PlanBase:
             return x if torch.is_tensor(x) else ctx.up(x)
 
         d.bias0, d.bias0_sb = Ctx.ptr(dev(bias0), bias0_off), bias0_sb
-        d.bias1, d.bias1_sb = Ctx.ptr(dev(bias1)), bias1_sb
+        d.bias1, d.bias1_sb = Ctx.ptr(dev(bias1), bias1_off), bias1_sb
+        if bias_t0 is not None:                               # (tensor, offset of bias0_t0, offset of bias1_t0)
+            d.bias0_t0, d.bias1_t0 = Ctx.ptr(bias_t0[0], bias_t0[1]), Ctx.ptr(bias_t0[0], bias_t0[2])
         d.epi, d.act, d.act_slope = epi, act, float(act_slope)
         if post is not None:
             d.post_scale, d.post_shift = ctx.up(post[0]).data_ptr(), ctx.up(post[1]).data_ptr()
@@ -177,7 +180,8 @@ class EpsNetPlan(PlanBase):
     ENC_F = [161, 79, 39, 19, 9, 4]
     fused_tcm = True        # one launch per TCM residual block (csrc/tcm.hip); False: three gather-GEMM launches
     chain_conv1 = True      # every stage's 1x1 input convolution rides on the previous stage's tail (pdse.h: nx_*)
-    NSLOT = 16  # 15 stages + en1 real-row bias
+    compose_stage1 = True   # (with chain_conv1) encoder stage 1: conv1 composed into the gather weights
+    NSLOT = 20  # 15 stages + en1 real-row bias + 4 composed encoder-stage-1 biases (l/r x frame >= 1 / frame 0)
 
     def __init__(self, ctx, sd, B, T, time_cond=True, nsteps=1, plan=None, table=None, with_pre=None):
         """with_pre False + time_cond True: ``Nocon`` (model/piror_grad.py), DiffUNet1 without Preprocess."""
@@ -238,7 +242,16 @@ class EpsNetPlan(PlanBase):
         W1 = self.w("en.conv1.conv1.weight")[:, :, 0, 0]
         wf.append(wf[0])
         bf.append(bf[0] + (W1 @ self.w("preprocess.conv.bias") if self.with_pre else 0.0))
-        WF, BF = np.concatenate(wf, 0), np.concatenate(bf, 0)      # [512, 512], [512]
+        # slots 16..19: encoder stage 1 with conv1 composed into the two gather convolutions (l, r): their biases become
+        #   frame >= 1:  (S0 + S1) b_real + b        frame 0:  S0 b_pad + S1 b_real + b,    S_kt = sum_kf W[:, :, kt, kf]
+        # (kt = 0 reads frame t-1; for t = 0 that is the zero pad frame, whose conv1 value is the pad bias, slot 0)
+        for br in ("l", "r"):
+            Wg = self.w("en.conv1.%s.weight" % br)                                  # [32, 32, 2, 5]
+            S0, S1 = Wg[:, :, 0].sum(-1), Wg[:, :, 1].sum(-1)
+            bg = self.w("en.conv1.%s.bias" % br)
+            wf += [(S0 + S1) @ wf[0], (S0 + S1) @ wf[0]]
+            bf += [(S0 + S1) @ bf[15] + bg, S0 @ bf[0] + S1 @ bf[15] + bg]
+        WF, BF = np.concatenate(wf, 0), np.concatenate(bf, 0)      # [NSLOT*32, 512], [NSLOT*32]
         self.t_p1T = ctx.up(self.w("time_embedding.projection1.weight").T)
         self.t_b1 = ctx.up(self.w("time_embedding.projection1.bias"))
         self.t_p2T = ctx.up(self.w("time_embedding.projection2.weight").T)
@@ -260,6 +273,43 @@ class EpsNetPlan(PlanBase):
     def _bias_for(self, step, slot):
         """(tensor-or-array, element offset, batch stride) of a stage's conv1 bias."""
         return self.tbias, (step * self.B) * self.NSLOT * 32 + slot * 32, self.NSLOT * 32
+
+    def _biconvglu_composed(self, step, src_x, src_init, out_t, out_strides, nx):
+        """Encoder stage 1 with its 1x1 conv1 (and the folded Preprocess) composed into the two (2,5) gather
+        convolutions: conv1 -> l / r is linear (model/diff3.py:316-319), so l(conv1(u)) is ONE (2,5) convolution over
+        the 4 input channels (x, x_init) with W'[o,i] = sum_c Wl[o,c] W1[c,i] - 40 instead of 320 k-rows, no conv1
+        launch, no 32-channel H tensor.  conv1's bias (time-conditioned, different for the zero pad frame) moves into
+        per-batch-item biases of l / r with a separate value for output frame 0 (slots 16..19 of the folded table)."""
+        B, T = self.B, self.T
+        p = "en.conv1"
+        Fin, Fout = F0, (F0 - 5) // 2 + 1
+        W1 = self.w(p + ".conv1.weight")[:, :, 0, 0]                       # [32, Cin]
+        if self.with_pre:
+            W1 = W1 @ self.w("preprocess.conv.weight")[:, :, 0, 0]          # [32, 4] over (x, x_init)
+        kk, taps = P.conv_taps(2, 5, 1)                                     # weight row kt reads frame t + kt - 1
+        comp = {br: np.einsum("ockf,ci->oikf", self.w("%s.%s.weight" % (p, br)).astype(np.float64), W1.astype(np.float64))
+                for br in ("l", "r")}
+        if self.time_cond:
+            tb, o_l, sbb = self._bias_for(step, 16)
+            _, o_l0, _ = self._bias_for(step, 17)
+            _, o_r, _ = self._bias_for(step, 18)
+            _, o_r0, _ = self._bias_for(step, 19)
+            bias = dict(bias0=tb, bias0_off=o_l, bias0_sb=sbb, bias1=tb, bias1_off=o_r, bias1_sb=sbb, bias_t0=(tb, o_l0, o_r0))
+        else:
+            b1 = self.w(p + ".conv1.bias")                                  # pad frame = conv1(0) = b1 as well
+            bias = {}
+            for key, br in (("bias0", "l"), ("bias1", "r")):
+                Wg = self.w("%s.%s.weight" % (p, br))
+                bias[key] = Wg.sum((2, 3)) @ b1 + self.w("%s.%s.bias" % (p, br))
+        post = P.bn_fold(self.sd, "en.en1.0")
+        chain = dict(C2=64, wlc=self.w(p + ".l_conv.weight")[:, :, 0, 0], blc=self.w(p + ".l_conv.bias"),
+                     wrc=self.w(p + ".r_conv.weight")[:, :, 0, 0], brc=self.w(p + ".r_conv.bias"),
+                     wc2=self.w(p + ".conv2.weight")[:, :, 0, 0], bc2=self.w(p + ".conv2.bias"))
+        self.gconv(in0=src_x, in1=src_init, Tin=T, Fin=Fin, taps=taps, sf_in=2, wk0=P.conv_kmat(comp["l"], kk),
+                   wk1=P.conv_kmat(comp["r"], kk), Cout=32, epi=L.EPI_BIGLU, act=L.ACT_PRELU,
+                   act_slope=float(self.w("en.en1.1.weight")[0]), post=post, chain=chain, out=out_t, out_strides=out_strides,
+                   B=B, Tout=T, Fout=Fout, tag=TAG_EPS_BLOCK, nx=nx, **bias)
+        return Fout
 
     def _biconvglu(self, step, k, src_x, src_init, Fin, out_t, out_strides, H=None, do_conv1=True, nx=None):
         """Encoder stage k (model/diff3.py:144-166 + :307-326 + BN + PReLU).  do_conv1 False: H already holds this
@@ -442,7 +492,7 @@ class EpsNetPlan(PlanBase):
             for d, tag in items:
                 d2 = type(d).from_buffer_copy(d)
                 if isinstance(d2, L.GconvDesc):
-                    for f in ("bias0", "padrow"):
+                    for f in ("bias0", "bias1", "bias0_t0", "bias1_t0", "padrow"):
                         v = getattr(d2, f)
                         if v and lo <= v < hi:
                             setattr(d2, f, v + delta)
@@ -490,7 +540,10 @@ class EpsNetPlan(PlanBase):
                     tl.update(bias_of(5 + 5 * di + (5 - k)) if self.time_cond else dict(bias=self.w(pd + ".conv1.bias")))
                     tiles.append(tl)
                 nx = dict(keep=False, row0=0, tiles=tiles)
-            Fin = self._biconvglu(step, k, src_x, src_i, Fin, o, ostr, H=Hc, do_conv1=(k == 1 or not chained), nx=nx)
+            if chained and k == 1 and self.compose_stage1:
+                Fin = self._biconvglu_composed(step, src_x, src_i, o, ostr, nx)
+            else:
+                Fin = self._biconvglu(step, k, src_x, src_i, Fin, o, ostr, H=Hc, do_conv1=(k == 1 or not chained), nx=nx)
             if chained:
                 Hc, Hn = Hn, Hc
             src_x, src_i = self.src(o, 64, *nchw(64, T, Fin)), None

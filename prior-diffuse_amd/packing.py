@@ -42,7 +42,7 @@ V2_CP = {
     (0, 1, False, 0): 8, (0, 1, False, 1): 8, (0, 1, True, 0): 8, (0, 4, False, 0): 2,
     (0, 3, False, 0): 4, (0, 6, False, 0): 2,
     (1, 1, True, 0): 4, (1, 2, True, 0): 2, (1, 3, False, 0): 4, (1, 5, False, 2): 4,
-    (2, 2, False, 0): 4, (2, 4, False, 0): 2, (2, 6, False, 0): 2, (2, 10, False, 0): 2,
+    (2, 2, False, 0): 4, (2, 4, False, 0): 2, (2, 6, False, 0): 2, (2, 10, False, 0): 2, (2, 10, True, 0): 2,
 }
 
 

@@ -185,8 +185,11 @@ def run_gconv(d, mem):
         store(post(y, d.Cout), d.Cout)
     else:
         def tail(aL, aR, extra, jmax):
-            Lh = aL[:, :32] + mem.arr(d.bias0, 32)[None, :, None, None]
-            Rh = aR[:, :32] + mem.arr(d.bias1, 32)[None, :, None, None]
+            bl, br = bias(d.bias0, d.bias0_sb, 32), bias(d.bias1, d.bias1_sb, 32)          # [B or 1, 32, 1, 1]
+            Lh, Rh = aL[:, :32] + bl, aR[:, :32] + br
+            if d.bias0_t0:                                                                   # output frame 0 has its own biases
+                Lh[:, :, 0] = (aL[:, :32] + bias(d.bias0_t0, d.bias0_sb, 32))[:, :, 0]
+                Rh[:, :, 0] = (aR[:, :32] + bias(d.bias1_t0, d.bias1_sb, 32))[:, :, 0]
             Wlc = _unpack_chain(mem.arr(d.wlc, 16 * 64), 1)
             Wrc = _unpack_chain(mem.arr(d.wrc, 16 * 64), 1)
             mL = _sig(np.einsum("oc,bctf->botf", Wlc, Lh) + mem.arr(d.blc, 32)[None, :, None, None])

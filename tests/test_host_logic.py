@@ -41,7 +41,7 @@ def test_eps_net_plan_vs_oracle(weights, chained, monkeypatch):
     net.build_time()
     net.build_step(0)
     n_conv1 = sum(1 for _, tag in net.descs if tag == nets.TAG_EPS_CONV1)
-    assert n_conv1 == (4 if chained else 16)          # encoder stage 1 (real frames + pad frame) and decoder stage 5 x 2
+    assert n_conv1 == (2 if chained else 16)          # chained: only decoder stage 5 x 2 (encoder stage 1 is composed)
     x, xi = seeded((B, 2, T, 161), 3), seeded((B, 2, T, 161), 4) * 0.3
     t = torch.tensor([4.086654, 22.992493])
     net.x.copy_(x)
@@ -128,9 +128,10 @@ def test_step_descriptors_are_cloned_not_repacked(weights):
             assert bytes(a) == bytes(b)
             continue
         assert a.w0 == b.w0 and a.out == b.out
-        if a.bias0 != b.bias0:
-            assert b.bias0 - a.bias0 == delta
-            moved += 1
+        for f in ("bias0", "bias1", "bias0_t0", "bias1_t0"):
+            if getattr(a, f) != getattr(b, f):
+                assert getattr(b, f) - getattr(a, f) == delta
+                moved += 1
         if a.padrow != b.padrow:
             assert b.padrow - a.padrow == delta
         assert a.nx_n == b.nx_n and a.nx_w == b.nx_w
@@ -138,7 +139,7 @@ def test_step_descriptors_are_cloned_not_repacked(weights):
             if a.nx_bias[i] != b.nx_bias[i]:
                 assert b.nx_bias[i] - a.nx_bias[i] == delta
                 moved += 1
-    assert moved == 16      # 15 stage biases + the pad-frame launch of encoder stage 1 (as launches or chained tiles)
+    assert moved == 18      # 14 stage biases (launches or chained tiles) + l, r biases of the composed stage 1 x (frame >= 1, frame 0)
 
 
 def test_stft_bases_against_numpy_fft():
