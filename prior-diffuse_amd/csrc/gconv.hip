@@ -171,6 +171,7 @@ int pdse_gconv_launch(const pdse_gconv_desc* d, hipStream_t s) {
     PDSE_REQUIRE(d->xf_mode != 2 || (d->xf_scale1 && d->xf_shift1), "xf_mode 2 without second set");
   }
   PDSE_REQUIRE((d->post_scale == nullptr) == (d->post_shift == nullptr), "post_scale/post_shift must come together");
+  PDSE_REQUIRE(d->resid == nullptr || d->act == PDSE_ACT_NONE, "a residual input excludes an activation (x + f(..) is the last op)");
   if (d->nx_n != 0) {
     PDSE_REQUIRE(d->nx_n > 0 && d->nx_n <= 3 && d->nx_w, "nx: 1..3 chained tiles and their weights");
     PDSE_REQUIRE(d->epi == PDSE_EPI_BIGLU && d->korder == 1 && d->C2 == 64 && d->out_cr == 1,
@@ -224,6 +225,7 @@ int pdse_gconv_launch(const pdse_gconv_desc* d, hipStream_t s) {
                    "BIGLU chain pointers missing");
       PDSE_REQUIRE(d->C2 == 1 || (d->C2 > 0 && d->C2 % 32 == 0), "BIGLU C2 must be 1 or a multiple of 32");
       PDSE_REQUIRE(d->resid == nullptr, "BIGLU has no residual input");
+      PDSE_REQUIRE(d->act == PDSE_ACT_NONE || d->act == PDSE_ACT_PRELU, "BIGLU stages end in PReLU or no activation");
       LAUNCH(PDSE_EPI_BIGLU, 1, false);
       break;
     }

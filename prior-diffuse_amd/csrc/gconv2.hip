@@ -93,10 +93,8 @@ __global__ __launch_bounds__(256, PDSE_WAVES_PER_EU) void gconv2_kernel(const pd
     }
     if (tid < d.C2) {
       tail_lds[4224 + tid] = d.bc2[tid];
-      if (d.post_scale) {
-        tail_lds[4288 + tid] = d.post_scale[tid];
-        tail_lds[4352 + tid] = d.post_shift[tid];
-      }
+      tail_lds[4288 + tid] = d.post_scale ? d.post_scale[tid] : 1.0f;   // no BatchNorm: identity pair (branch-free tail)
+      tail_lds[4352 + tid] = d.post_scale ? d.post_shift[tid] : 0.0f;
     }
     if (d.nx_n > 0) {   // chained next-stage 1x1 tiles + their biases for this batch item
       for (int i = tid; i < d.nx_n * 2048; i += 256) tail_lds[PDSE_TAIL_NXW + i] = d.nx_w[i];
@@ -272,7 +270,7 @@ __global__ __launch_bounds__(256, PDSE_WAVES_PER_EU) void gconv2_kernel(const pd
                        // instead measured the same: the barrier is not what the tail costs)
     float* const sw = tail_lds;
     const pdse_tail tl{sw, sw + 1024, sw + 2048, sw + 4096, sw + 4128, sw + 4160, sw + 4192, sw + 4224,
-                       d.post_scale ? sw + 4288 : nullptr, sw + 4352, sw + PDSE_TAIL_NXW, sw + PDSE_TAIL_NXB,
+                       sw + 4288, sw + 4352, sw + PDSE_TAIL_NXW, sw + PDSE_TAIL_NXB,
                        sw + PDSE_TAIL_B0, sw + PDSE_TAIL_B0 + 32};
     if constexpr (P1MASK != 0)   // even + odd bins of this lane, paired stores
       biglu_dual_epilogue<NX>(d, tl, acc0[0], acc1[0], acc2[0], acc3[0], b, t, j, pvalid, lane, h);
@@ -309,9 +307,13 @@ static void launch_mt(const pdse_gconv_desc* d, hipStream_t s, int mt, int gx, i
   if constexpr (EPI == PDSE_EPI_BIGLU) {
     hipLaunchKernelGGL((gconv2_kernel<EPI, 1, NT, CP, SRC2, XF, PP1>), dim3(gx, d->B, 1), block, 0, s, *d);
   } else {
-    if (mt >= 4)
-      hipLaunchKernelGGL((gconv2_kernel<EPI, 4, NT, CP, SRC2, XF, PP4>), dim3(gx, d->B, (mtiles + 3) / 4), block, 0, s, *d);
-    else if (mt == 2)
+    if constexpr (EPI != PDSE_EPI_GLU) {   // GLU keeps two accumulator sets: pick_mt() never widens it beyond 2 tiles
+      if (mt >= 4) {
+        hipLaunchKernelGGL((gconv2_kernel<EPI, 4, NT, CP, SRC2, XF, PP4>), dim3(gx, d->B, (mtiles + 3) / 4), block, 0, s, *d);
+        return;
+      }
+    }
+    if (mt >= 2)
       hipLaunchKernelGGL((gconv2_kernel<EPI, 2, NT, CP, SRC2, XF, PP2>), dim3(gx, d->B, (mtiles + 1) / 2), block, 0, s, *d);
     else
       hipLaunchKernelGGL((gconv2_kernel<EPI, 1, NT, CP, SRC2, XF, PP1>), dim3(gx, d->B, mtiles), block, 0, s, *d);

@@ -3,6 +3,7 @@
 #ifndef PDSE_GCONV_COMMON_H
 #define PDSE_GCONV_COMMON_H
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 #include "pdse.h"
@@ -17,6 +18,20 @@ __device__ __forceinline__ int rho(int r, int h) { return (r & 3) + 8 * (r >> 2)
 // the block kernels — accurate expf + IEEE division cost ~35 VALU instructions per sigmoid.
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 __device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + fast_exp(-x)); }
+
+template <int ACT>
+__device__ __forceinline__ float act_c(float y, float slope) {
+  if constexpr (ACT == PDSE_ACT_PRELU) return y > 0.f ? y : slope * y;
+  else if constexpr (ACT == PDSE_ACT_ELU) return y > 0.f ? y : fast_exp(y) - 1.0f;
+  else if constexpr (ACT == PDSE_ACT_SIGMOID) return sigmoid_f(y);
+  else return y;
+}
+
+// stand-ins for absent per-channel operands (bias, folded BatchNorm): keeps the epilogue free of pointer tests
+__device__ const float pdse_zeros[32] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f,
+                                         0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+__device__ const float pdse_ones[32] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f,
+                                        1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
 
 __device__ __forceinline__ float act_f(float y, int act, float slope) {
   switch (act) {
@@ -79,37 +94,69 @@ __device__ __forceinline__ void gconv_epilogue_impl(const pdse_gconv_desc& d, co
   };
 
   if constexpr (EPI == PDSE_EPI_LINEAR || EPI == PDSE_EPI_GLU) {
+    // Everything that is uniform over the launch is resolved OUTSIDE the element loops: the activation and the
+    // residual are dispatched once (epilogue_tiles<ACT, RES>), a missing bias / BatchNorm reads zeros / ones from a
+    // constant block, and a full channel tile stores without per-element guards.  The straightforward form
+    // (`switch (d.act)`, `if (bias)`, `if (co < Cout)` per element) compiled to ~20 branches per output element.
     const float* rbase = d.resid ? d.resid + (obase - d.out) : nullptr;
+    auto tiles = [&](auto act_tag, auto res_tag) {
+      constexpr int ACT = decltype(act_tag)::value;
+      constexpr bool RES = decltype(res_tag)::value;
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      if (mt0 + m >= mtiles) continue;
-      const int c0 = 32 * (mt0 + m) + 4 * h;
-      const float* pb0 = d.bias0 ? d.bias0 + (int64_t)b * d.bias0_sb + c0 : nullptr;
-      const float* pb1 = (EPI == PDSE_EPI_GLU && d.bias1) ? d.bias1 + (int64_t)b * d.bias1_sb + c0 : nullptr;
-      const float* ps = d.post_scale ? d.post_scale + c0 : nullptr;
-      const float* pt = d.post_scale ? d.post_shift + c0 : nullptr;
+      for (int m = 0; m < MT; ++m) {
+        if (mt0 + m >= mtiles) continue;
+        const int c0 = 32 * (mt0 + m) + 4 * h;
+        const float* pb0 = d.bias0 ? d.bias0 + (int64_t)b * d.bias0_sb + c0 : pdse_zeros + 4 * h;
+        const float* pb1 = (EPI == PDSE_EPI_GLU && d.bias1) ? d.bias1 + (int64_t)b * d.bias1_sb + c0 : pdse_zeros + 4 * h;
+        const float* ps = d.post_scale ? d.post_scale + c0 : pdse_ones + 4 * h;
+        const float* pt = d.post_scale ? d.post_shift + c0 : pdse_zeros + 4 * h;
+        auto value = [&](const int r) {
+          float y = acc0[m][r] + pb0[PDSE_KR(r)];
+          if constexpr (EPI == PDSE_EPI_GLU) y = y * sigmoid_f(acc1[m][r] + pb1[PDSE_KR(r)]);
+          y = y * ps[PDSE_KR(r)] + pt[PDSE_KR(r)];
+          return act_c<ACT>(y, d.act_slope);
+        };
+        if (32 * (mt0 + m) + 32 <= d.Cout && CR1) {   // full tile, plain channel stride: one predicated region
+          if (pvalid) {
+            float* po = obase + (int64_t)c0 * cstep;
+            const float* pr = RES ? rbase + (int64_t)c0 * cstep : nullptr;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int co = c0 + PDSE_KR(r);
-        if (pvalid && co < d.Cout) {
-          float y = acc0[m][r];
-          if (pb0) y += pb0[PDSE_KR(r)];
-          if constexpr (EPI == PDSE_EPI_GLU) {
-            float g = acc1[m][r];
-            if (pb1) g += pb1[PDSE_KR(r)];
-            y = y * sigmoid_f(g);
+            for (int r = 0; r < 16; ++r) {
+              float y = value(r);
+              if constexpr (RES) y += pr[(int64_t)PDSE_KR(r) * cstep];
+              po[(int64_t)PDSE_KR(r) * cstep] = y;
+            }
           }
-          if (ps) y = y * ps[PDSE_KR(r)] + pt[PDSE_KR(r)];
-          y = act_f(y, d.act, d.act_slope);
-          const int64_t o = CR1 ? (int64_t)c0 * cstep + (int64_t)PDSE_KR(r) * cstep : chan_off(co);
-          if (rbase) y += rbase[o];
-          obase[o] = y;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int co = c0 + PDSE_KR(r);
+            if (pvalid && co < d.Cout) {
+              float y = value(r);
+              const int64_t o = CR1 ? (int64_t)c0 * cstep + (int64_t)PDSE_KR(r) * cstep : chan_off(co);
+              if constexpr (RES) y += rbase[o];
+              obase[o] = y;
+            }
+          }
         }
+      }
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    if (rbase) {   // a residual input never comes with an activation (validated at launch)
+      tiles(std::integral_constant<int, PDSE_ACT_NONE>{}, T{});
+    } else {
+      switch (d.act) {
+        case PDSE_ACT_PRELU: tiles(std::integral_constant<int, PDSE_ACT_PRELU>{}, F{}); break;
+        case PDSE_ACT_ELU: tiles(std::integral_constant<int, PDSE_ACT_ELU>{}, F{}); break;
+        case PDSE_ACT_SIGMOID: tiles(std::integral_constant<int, PDSE_ACT_SIGMOID>{}, F{}); break;
+        default: tiles(std::integral_constant<int, PDSE_ACT_NONE>{}, F{}); break;
       }
     }
   } else {
     // BiConvGLU / BiConvTransGLU tail, register to register (model/diff3.py:316-326, :345-351)
     f32x16 L = acc0[0], R = acc1[0];
+    const float slope = d.act == PDSE_ACT_PRELU ? d.act_slope : 1.0f;   // PReLU or nothing (validated at launch)
     const float* pbl = tl.bl + 4 * h;
     const float* pbr = tl.br + 4 * h;
     const float* pblc = tl.blc + 4 * h;
@@ -141,7 +188,7 @@ __device__ __forceinline__ void gconv_epilogue_impl(const pdse_gconv_desc& d, co
       for (int r = 0; r < 16; ++r) part += pw[PDSE_KR(r)] * G[r];
       float y = part + __shfl_xor(part, 32) + tl.bc2[0];
       if (tl.ps) y = y * tl.ps[0] + tl.pt[0];
-      y = act_f(y, d.act, d.act_slope);
+      y = y > 0.f ? y : slope * y;
       if (pvalid && h == 0) obase[0] = y;
     } else {
       const int tiles2 = (d.C2 + 31) >> 5;
@@ -162,7 +209,7 @@ __device__ __forceinline__ void gconv_epilogue_impl(const pdse_gconv_desc& d, co
           if (pvalid && co < d.C2) {
             float y = O[r] + pb[PDSE_KR(r)];
             if (ps) y = y * ps[PDSE_KR(r)] + pt[PDSE_KR(r)];
-            y = act_f(y, d.act, d.act_slope);
+            y = y > 0.f ? y : slope * y;
             const int64_t o = CR1 ? (int64_t)c0 * cstep + (int64_t)PDSE_KR(r) * cstep : chan_off(co);
 #if defined(PDSE_ABLATE) && (PDSE_ABLATE & 8)
             if (y == 1234.5f) obase[o] = y;   // diagnostic: tail without its stores
@@ -180,11 +227,16 @@ __device__ __forceinline__ void gconv_epilogue_impl(const pdse_gconv_desc& d, co
 // (C2 == 1: y[0][0] on every lane).  Used by the dual-phase transposed conv, which stores the even
 // and the odd output bin of a lane with ONE 8-byte store (two strided 4-byte stores are not merged
 // on their way to HBM: profiles/r01_pmc_traffic_v5.json showed 2x WRITE_SIZE).
+// Per-element control flow is kept out of the tail on purpose: the activation of a BIGLU stage is PReLU or nothing
+// (PReLU with slope 1), and the LDS tail image always carries a BatchNorm pair (identity when the stage has none).
+// With `switch (d.act)` / `if (ps)` per element the tail ran ~1000 scalar branches per 32-position tile and took
+// 2.4x as long per MFMA as the gather loop (profiles/r01_ablation_v8.txt).
 template <typename Sink>   // sink(m2, r, value) is called once per output element, in (m2, r) order
 __device__ __forceinline__ void biglu_tail_values(const pdse_gconv_desc& d, const pdse_tail& tl, const f32x16& accL,
                                                   const f32x16& accR, const int lane, const int h, Sink&& sink,
                                                   const bool frame0 = false) {
   f32x16 L = accL, R = accR;
+  const float slope = d.act == PDSE_ACT_PRELU ? d.act_slope : 1.0f;   // validated: BIGLU stages use PReLU or nothing
   const float* pbl = (frame0 ? tl.bl0 : tl.bl) + 4 * h;
   const float* pbr = (frame0 ? tl.br0 : tl.br) + 4 * h;
   const float* pblc = tl.blc + 4 * h;
@@ -215,8 +267,8 @@ __device__ __forceinline__ void biglu_tail_values(const pdse_gconv_desc& d, cons
 #pragma unroll
     for (int r = 0; r < 16; ++r) part += pw[PDSE_KR(r)] * G[r];
     float v = part + __shfl_xor(part, 32) + tl.bc2[0];
-    if (tl.ps) v = v * tl.ps[0] + tl.pt[0];
-    sink(0, 0, act_f(v, d.act, d.act_slope));
+    v = v * tl.ps[0] + tl.pt[0];
+    sink(0, 0, v > 0.f ? v : slope * v);
   } else {
 #pragma unroll
     for (int m2 = 0; m2 < 2; ++m2) {
@@ -228,13 +280,13 @@ __device__ __forceinline__ void biglu_tail_values(const pdse_gconv_desc& d, cons
         O = __builtin_amdgcn_mfma_f32_32x32x2f32(tl.wc2[(m2 * 16 + r) * 64 + lane], G[r], O, 0, 0, 0);
       const int c0 = 32 * m2 + 4 * h;
       const float* pb = tl.bc2 + c0;
-      const float* ps = tl.ps ? tl.ps + c0 : nullptr;
-      const float* pt = tl.ps ? tl.pt + c0 : nullptr;
+      const float* ps = tl.ps + c0;
+      const float* pt = tl.pt + c0;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float v = O[r] + pb[PDSE_KR(r)];
-        if (ps) v = v * ps[PDSE_KR(r)] + pt[PDSE_KR(r)];
-        sink(m2, r, act_f(v, d.act, d.act_slope));
+        v = v * ps[PDSE_KR(r)] + pt[PDSE_KR(r)];
+        sink(m2, r, v > 0.f ? v : slope * v);
       }
     }
   }
@@ -286,11 +338,12 @@ __device__ __forceinline__ void biglu_nx_epilogue(const pdse_gconv_desc& d, cons
     const float* const ab = d.nx_add[i] ? d.nx_add[i] + off : nullptr;
     const float* const pb = tl.nxb + 32 * i + 4 * h;
     if (pvalid) {
+      if (ab) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float v = Z[r] + pb[PDSE_KR(r)];
-        if (ab) v += ab[(int64_t)PDSE_KR(r) * sc];
-        zb[(int64_t)PDSE_KR(r) * sc] = v;
+        for (int r = 0; r < 16; ++r) zb[(int64_t)PDSE_KR(r) * sc] = Z[r] + pb[PDSE_KR(r)] + ab[(int64_t)PDSE_KR(r) * sc];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zb[(int64_t)PDSE_KR(r) * sc] = Z[r] + pb[PDSE_KR(r)];
       }
       if (i == d.nx_row0 && t == 0) {   // explicit pad frame of the next encoder stage: conv1(0 + tp) = the folded bias
         float* const z0 = d.nx_out[i] + rowbase;
@@ -338,14 +391,15 @@ __device__ __forceinline__ void biglu_dual_epilogue(const pdse_gconv_desc& d, co
     __builtin_amdgcn_sched_barrier(0);
     biglu_tail_values(d, tl, a2, a3, lane, h, [&](const int m2, const int r, const float v) { Y[m2][r] = v; });
     Z1 = nx_tile_acc(tl, 0, Y, lane, Z1);
+    if (nbin == 1 && two) {             // the common case: neighbouring bins, one 8-byte store per channel row
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float* p = zb + (int64_t)PDSE_KR(r) * sc;
-      const float ve = Z0[r] + pb[PDSE_KR(r)], vo = Z1[r] + pb[PDSE_KR(r)];
-      if (two && nbin == 1) store_pair(p, ve, vo);
-      else if (pvalid) {
-        p[0] = ve;
-        if (two) p[nbin] = vo;
+      for (int r = 0; r < 16; ++r) store_pair(zb + (int64_t)PDSE_KR(r) * sc, Z0[r] + pb[PDSE_KR(r)], Z1[r] + pb[PDSE_KR(r)]);
+    } else if (pvalid) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) zb[(int64_t)PDSE_KR(r) * sc] = Z0[r] + pb[PDSE_KR(r)];
+      if (two) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zb[(int64_t)PDSE_KR(r) * sc + nbin] = Z1[r] + pb[PDSE_KR(r)];
       }
     }
     return;
