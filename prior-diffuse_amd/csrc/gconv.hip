@@ -171,6 +171,13 @@ int pdse_gconv_launch(const pdse_gconv_desc* d, hipStream_t s) {
     PDSE_REQUIRE(d->xf_mode != 2 || (d->xf_scale1 && d->xf_shift1), "xf_mode 2 without second set");
   }
   PDSE_REQUIRE((d->post_scale == nullptr) == (d->post_shift == nullptr), "post_scale/post_shift must come together");
+  {  // the epilogues read per-channel operands four floats at a time
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    PDSE_REQUIRE(al16(d->bias0) && al16(d->bias1) && al16(d->post_scale) && al16(d->post_shift) && al16(d->blc) &&
+                     al16(d->brc) && al16(d->bc2) && al16(d->bias0_t0) && al16(d->bias1_t0),
+                 "per-channel operands (biases, folded BatchNorm) must be 16-byte aligned");
+    PDSE_REQUIRE((d->bias0_sb & 3) == 0 && (d->bias1_sb & 3) == 0, "bias batch strides must be multiples of 4 floats");
+  }
   PDSE_REQUIRE(d->resid == nullptr || d->act == PDSE_ACT_NONE, "a residual input excludes an activation (x + f(..) is the last op)");
   if (d->nx_n != 0) {
     PDSE_REQUIRE(d->nx_n > 0 && d->nx_n <= 3 && d->nx_w, "nx: 1..3 chained tiles and their weights");

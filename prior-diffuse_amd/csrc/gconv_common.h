@@ -28,9 +28,9 @@ __device__ __forceinline__ float act_c(float y, float slope) {
 }
 
 // stand-ins for absent per-channel operands (bias, folded BatchNorm): keeps the epilogue free of pointer tests
-__device__ const float pdse_zeros[32] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f,
+__device__ const float pdse_zeros[32] __attribute__((aligned(16))) = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f,
                                          0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-__device__ const float pdse_ones[32] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f,
+__device__ const float pdse_ones[32] __attribute__((aligned(16))) = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f,
                                         1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
 
 __device__ __forceinline__ float act_f(float y, int act, float slope) {
@@ -44,6 +44,23 @@ __device__ __forceinline__ float act_f(float y, int act, float slope) {
 
 // register r of a 32x32 accumulator holds row KR(r) + 4*h
 #define PDSE_KR(r) (((r) & 3) + 8 * ((r) >> 2))
+
+// The 16 per-channel operands of a lane's accumulator rows, KR(r) + 4*h for r = 0..15, are four runs of four
+// consecutive floats (KR(4q + i) = 8q + i): p must already include the 4*h (and tile) offset and be 16-byte aligned.
+// One ds_read_b128 / global_load_dwordx4 per run instead of sixteen dependent 4-byte reads - with the scalar form
+// the BIGLU tail issued ~100 LDS reads per phase, each waited for individually (~12k cycles per tile).
+__device__ __forceinline__ f32x16 ld16(const float* p) {
+  f32x16 v;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 x = *reinterpret_cast<const float4*>(p + 8 * q);
+    v[4 * q] = x.x;
+    v[4 * q + 1] = x.y;
+    v[4 * q + 2] = x.z;
+    v[4 * q + 3] = x.w;
+  }
+  return v;
+}
 
 // Channel-indexed vectors (bias, folded BN) and the output are addressed as
 //   base(lane half, tile) + KR(r) * stride
@@ -110,19 +127,19 @@ __device__ __forceinline__ void gconv_epilogue_impl(const pdse_gconv_desc& d, co
         const float* pb1 = (EPI == PDSE_EPI_GLU && d.bias1) ? d.bias1 + (int64_t)b * d.bias1_sb + c0 : pdse_zeros + 4 * h;
         const float* ps = d.post_scale ? d.post_scale + c0 : pdse_ones + 4 * h;
         const float* pt = d.post_scale ? d.post_shift + c0 : pdse_zeros + 4 * h;
-        auto value = [&](const int r) {
-          float y = acc0[m][r] + pb0[PDSE_KR(r)];
-          if constexpr (EPI == PDSE_EPI_GLU) y = y * sigmoid_f(acc1[m][r] + pb1[PDSE_KR(r)]);
-          y = y * ps[PDSE_KR(r)] + pt[PDSE_KR(r)];
-          return act_c<ACT>(y, d.act_slope);
+        auto value = [&](const int r, const float b0, const float b1, const float sc, const float sh) {
+          float y = acc0[m][r] + b0;
+          if constexpr (EPI == PDSE_EPI_GLU) y = y * sigmoid_f(acc1[m][r] + b1);
+          return act_c<ACT>(y * sc + sh, d.act_slope);
         };
         if (32 * (mt0 + m) + 32 <= d.Cout && CR1) {   // full tile, plain channel stride: one predicated region
+          const f32x16 vb0 = ld16(pb0), vb1 = ld16(pb1), vs = ld16(ps), vt = ld16(pt);   // 16-byte aligned (host contract)
           if (pvalid) {
             float* po = obase + (int64_t)c0 * cstep;
             const float* pr = RES ? rbase + (int64_t)c0 * cstep : nullptr;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              float y = value(r);
+              float y = value(r, vb0[r], vb1[r], vs[r], vt[r]);
               if constexpr (RES) y += pr[(int64_t)PDSE_KR(r) * cstep];
               po[(int64_t)PDSE_KR(r) * cstep] = y;
             }
@@ -132,7 +149,9 @@ __device__ __forceinline__ void gconv_epilogue_impl(const pdse_gconv_desc& d, co
           for (int r = 0; r < 16; ++r) {
             const int co = c0 + PDSE_KR(r);
             if (pvalid && co < d.Cout) {
-              float y = value(r);
+              const bool hb0 = d.bias0 != nullptr, hb1 = EPI == PDSE_EPI_GLU && d.bias1 != nullptr, hs = d.post_scale != nullptr;
+              float y = value(r, hb0 ? pb0[PDSE_KR(r)] : 0.f, hb1 ? pb1[PDSE_KR(r)] : 0.f, hs ? ps[PDSE_KR(r)] : 1.f,
+                              hs ? pt[PDSE_KR(r)] : 0.f);
               const int64_t o = CR1 ? (int64_t)c0 * cstep + (int64_t)PDSE_KR(r) * cstep : chan_off(co);
               if constexpr (RES) y += rbase[o];
               obase[o] = y;
@@ -157,15 +176,9 @@ __device__ __forceinline__ void gconv_epilogue_impl(const pdse_gconv_desc& d, co
     // BiConvGLU / BiConvTransGLU tail, register to register (model/diff3.py:316-326, :345-351)
     f32x16 L = acc0[0], R = acc1[0];
     const float slope = d.act == PDSE_ACT_PRELU ? d.act_slope : 1.0f;   // PReLU or nothing (validated at launch)
-    const float* pbl = tl.bl + 4 * h;
-    const float* pbr = tl.br + 4 * h;
-    const float* pblc = tl.blc + 4 * h;
-    const float* pbrc = tl.brc + 4 * h;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      L[r] += pbl[PDSE_KR(r)];
-      R[r] += pbr[PDSE_KR(r)];
-    }
+    L += ld16(tl.bl + 4 * h);
+    R += ld16(tl.br + 4 * h);
+    const f32x16 vblc = ld16(tl.blc + 4 * h), vbrc = ld16(tl.brc + 4 * h);
     f32x16 mL, mR;
 #pragma unroll
     for (int r = 0; r < 16; ++r) mL[r] = mR[r] = 0.f;
@@ -177,15 +190,15 @@ __device__ __forceinline__ void gconv_epilogue_impl(const pdse_gconv_desc& d, co
     f32x16 G;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float ml = sigmoid_f(mL[r] + pblc[PDSE_KR(r)]);
-      const float mr = sigmoid_f(mR[r] + pbrc[PDSE_KR(r)]);
+      const float ml = sigmoid_f(mL[r] + vblc[r]);
+      const float mr = sigmoid_f(mR[r] + vbrc[r]);
       G[r] = L[r] * mr + R[r] * ml;
     }
     if (d.C2 == 1) {
-      const float* pw = tl.wc2 + 4 * h;
+      const f32x16 vw = ld16(tl.wc2 + 4 * h);
       float part = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) part += pw[PDSE_KR(r)] * G[r];
+      for (int r = 0; r < 16; ++r) part += vw[r] * G[r];
       float y = part + __shfl_xor(part, 32) + tl.bc2[0];
       if (tl.ps) y = y * tl.ps[0] + tl.pt[0];
       y = y > 0.f ? y : slope * y;
@@ -237,15 +250,9 @@ __device__ __forceinline__ void biglu_tail_values(const pdse_gconv_desc& d, cons
                                                   const bool frame0 = false) {
   f32x16 L = accL, R = accR;
   const float slope = d.act == PDSE_ACT_PRELU ? d.act_slope : 1.0f;   // validated: BIGLU stages use PReLU or nothing
-  const float* pbl = (frame0 ? tl.bl0 : tl.bl) + 4 * h;
-  const float* pbr = (frame0 ? tl.br0 : tl.br) + 4 * h;
-  const float* pblc = tl.blc + 4 * h;
-  const float* pbrc = tl.brc + 4 * h;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    L[r] += pbl[PDSE_KR(r)];
-    R[r] += pbr[PDSE_KR(r)];
-  }
+  L += ld16((frame0 ? tl.bl0 : tl.bl) + 4 * h);
+  R += ld16((frame0 ? tl.br0 : tl.br) + 4 * h);
+  const f32x16 vblc = ld16(tl.blc + 4 * h), vbrc = ld16(tl.brc + 4 * h);
   f32x16 mL, mR;
 #pragma unroll
   for (int r = 0; r < 16; ++r) mL[r] = mR[r] = 0.f;
@@ -257,15 +264,15 @@ __device__ __forceinline__ void biglu_tail_values(const pdse_gconv_desc& d, cons
   f32x16 G;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const float ml = sigmoid_f(mL[r] + pblc[PDSE_KR(r)]);
-    const float mr = sigmoid_f(mR[r] + pbrc[PDSE_KR(r)]);
+    const float ml = sigmoid_f(mL[r] + vblc[r]);
+    const float mr = sigmoid_f(mR[r] + vbrc[r]);
     G[r] = L[r] * mr + R[r] * ml;
   }
   if (d.C2 == 1) {
-    const float* pw = tl.wc2 + 4 * h;
+    const f32x16 vw = ld16(tl.wc2 + 4 * h);
     float part = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) part += pw[PDSE_KR(r)] * G[r];
+    for (int r = 0; r < 16; ++r) part += vw[r] * G[r];
     float v = part + __shfl_xor(part, 32) + tl.bc2[0];
     v = v * tl.ps[0] + tl.pt[0];
     sink(0, 0, v > 0.f ? v : slope * v);
@@ -279,13 +286,10 @@ __device__ __forceinline__ void biglu_tail_values(const pdse_gconv_desc& d, cons
       for (int r = 0; r < 16; ++r)
         O = __builtin_amdgcn_mfma_f32_32x32x2f32(tl.wc2[(m2 * 16 + r) * 64 + lane], G[r], O, 0, 0, 0);
       const int c0 = 32 * m2 + 4 * h;
-      const float* pb = tl.bc2 + c0;
-      const float* ps = tl.ps + c0;
-      const float* pt = tl.pt + c0;
+      const f32x16 vb = ld16(tl.bc2 + c0), vs = ld16(tl.ps + c0), vt = ld16(tl.pt + c0);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float v = O[r] + pb[PDSE_KR(r)];
-        v = v * ps[PDSE_KR(r)] + pt[PDSE_KR(r)];
+        const float v = (O[r] + vb[r]) * vs[r] + vt[r];
         sink(m2, r, v > 0.f ? v : slope * v);
       }
     }
@@ -336,19 +340,19 @@ __device__ __forceinline__ void biglu_nx_epilogue(const pdse_gconv_desc& d, cons
     const int64_t off = rowbase + (int64_t)t * d.nx_st[i] + d.nx_off[i];
     float* const zb = d.nx_out[i] + off;
     const float* const ab = d.nx_add[i] ? d.nx_add[i] + off : nullptr;
-    const float* const pb = tl.nxb + 32 * i + 4 * h;
+    const f32x16 pb = ld16(tl.nxb + 32 * i + 4 * h);
     if (pvalid) {
       if (ab) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) zb[(int64_t)PDSE_KR(r) * sc] = Z[r] + pb[PDSE_KR(r)] + ab[(int64_t)PDSE_KR(r) * sc];
+        for (int r = 0; r < 16; ++r) zb[(int64_t)PDSE_KR(r) * sc] = Z[r] + pb[r] + ab[(int64_t)PDSE_KR(r) * sc];
       } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) zb[(int64_t)PDSE_KR(r) * sc] = Z[r] + pb[PDSE_KR(r)];
+        for (int r = 0; r < 16; ++r) zb[(int64_t)PDSE_KR(r) * sc] = Z[r] + pb[r];
       }
       if (i == d.nx_row0 && t == 0) {   // explicit pad frame of the next encoder stage: conv1(0 + tp) = the folded bias
         float* const z0 = d.nx_out[i] + rowbase;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) z0[(int64_t)PDSE_KR(r) * sc] = pb[PDSE_KR(r)];
+        for (int r = 0; r < 16; ++r) z0[(int64_t)PDSE_KR(r) * sc] = pb[r];
       }
     }
   }
@@ -377,7 +381,7 @@ __device__ __forceinline__ void biglu_dual_epilogue(const pdse_gconv_desc& d, co
     const int64_t off = (int64_t)b * d.nx_sb[0] + (int64_t)t * d.nx_st[0] + (int64_t)j * d.nx_sf[0] + d.nx_off[0] + (int64_t)(4 * h) * sc;
     float* const zb = d.nx_out[0] + off;
     const float* const ab = d.nx_add[0] ? d.nx_add[0] + off : nullptr;
-    const float* const pb = tl.nxb + 4 * h;
+    const f32x16 pb = ld16(tl.nxb + 4 * h);
     const bool two = pvalid && j < d.Fout1;
     float Y[2][16];
     f32x16 Z0, Z1;
@@ -393,13 +397,13 @@ __device__ __forceinline__ void biglu_dual_epilogue(const pdse_gconv_desc& d, co
     Z1 = nx_tile_acc(tl, 0, Y, lane, Z1);
     if (nbin == 1 && two) {             // the common case: neighbouring bins, one 8-byte store per channel row
 #pragma unroll
-      for (int r = 0; r < 16; ++r) store_pair(zb + (int64_t)PDSE_KR(r) * sc, Z0[r] + pb[PDSE_KR(r)], Z1[r] + pb[PDSE_KR(r)]);
+      for (int r = 0; r < 16; ++r) store_pair(zb + (int64_t)PDSE_KR(r) * sc, Z0[r] + pb[r], Z1[r] + pb[r]);
     } else if (pvalid) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) zb[(int64_t)PDSE_KR(r) * sc] = Z0[r] + pb[PDSE_KR(r)];
+      for (int r = 0; r < 16; ++r) zb[(int64_t)PDSE_KR(r) * sc] = Z0[r] + pb[r];
       if (two) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) zb[(int64_t)PDSE_KR(r) * sc + nbin] = Z1[r] + pb[PDSE_KR(r)];
+        for (int r = 0; r < 16; ++r) zb[(int64_t)PDSE_KR(r) * sc + nbin] = Z1[r] + pb[r];
       }
     }
     return;
