@@ -82,6 +82,24 @@ def test_error_reporting(L):
     g = L.GconvDesc()
     with pytest.raises(L.PdseError, match="gconv"):
         L.launch(g)
+    # a valid 1x1 launch, then the same with a bias pointer that is not 16-byte aligned (the epilogues read
+    # per-channel operands four floats at a time) and with an activation next to a residual input
+    nets = pkg("nets")
+    pb = nets.PlanBase(nets.Ctx(DEV), plan=None)
+    x, y = torch.randn(1, 4, 2, 40, device=DEV), torch.empty(1, 32, 2, 40, device=DEV)
+    bias = torch.zeros(40, device=DEV)
+    d = pb.gconv(in0=pb.src(x, 4, *nets.nchw(4, 2, 40)), Tin=2, Fin=40, taps=[(0, 0)], sf_in=1, wk0=np.ones((4, 32)), Cout=32,
+                 bias0=bias, out=y, out_strides=nets.nchw_out(32, 2, 40), B=1, Tout=2, Fout=40)
+    L.launch(d)
+    _sync()
+    assert torch.allclose(y, x.sum(1, keepdim=True).expand_as(y), atol=1e-5)
+    d.bias0 = bias.data_ptr() + 4
+    with pytest.raises(L.PdseError, match="16-byte aligned"):
+        L.launch(d)
+    d.bias0 = bias.data_ptr()
+    d.resid, d.act = y.data_ptr(), L.ACT_PRELU
+    with pytest.raises(L.PdseError, match="residual"):
+        L.launch(d)
 
 
 # ---------------------------------------------------------------- networks vs golden + oracle
