@@ -546,6 +546,23 @@ def test_q_sample_bit_exact_and_int_t_forward(L, weights):
     assert eps.shape == label.shape and torch.isfinite(eps).all()
 
 
+@pytest.mark.parametrize("L_", [161, 400])
+def test_shortest_utterances(L, weights, R, L_):
+    """T = 2 and T = 3 frames: every tile is partial, the TCM halo exceeds the sequence, the chained tails write the
+    encoder pad frame next to the only real frames."""
+    params = pkg("params").params
+    wav, x_T = pkg("synth").synthetic_waveforms(2, L_, seed=5)
+    x_T = x_T[:, :, : 1 + L_ // 160]
+    pipe = pkg("pipeline").SamplerPipeline(DEV, "GCRN", weights("GCRN"), weights("DiffUNet1"), 2, L_=L_)
+    out, spec = pipe.enhance(wav.to(DEV), x_T.to(DEV))
+    _sync()
+    with torch.no_grad():
+        ref_w, ref_s = R.enhance("GCRN", weights("GCRN"), weights("DiffUNet1"), wav, x_T, params.noise_schedule,
+                                 params.inference_noise_schedule, True, False)
+    assert rel_l2(spec.cpu(), ref_s) < 1e-4
+    assert rel_l2(out.cpu(), ref_w) < 1e-4
+
+
 def test_wrong_geometry_is_rejected(L, weights):
     """A plan is recorded for one geometry: other shapes/dtypes raise instead of silently broadcasting."""
     P = pkg("pipeline")
