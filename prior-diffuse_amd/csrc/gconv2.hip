@@ -70,6 +70,12 @@ __global__ __launch_bounds__(256, PDSE_WAVES_PER_EU) void gconv2_kernel(const pd
   const int j = pvalid ? p - t * d.Fout : 0;
   const int mtiles = (d.Cout + 31) >> 5;
   const int mt0 = blockIdx.z * MT;
+  // A workgroup covers four 32-position tiles; launches with few positions per batch item (P = 401: 13 tiles in
+  // 4 workgroups) would run up to three fully masked waves through the whole K loop.  They leave here - except in
+  // the BIGLU kernels, whose waves meet at a barrier before the tail.
+  if constexpr (EPI != PDSE_EPI_BIGLU) {
+    if ((blockIdx.x * 4 + wave) * 32 >= P) return;
+  }
 
   // BIGLU: copy the tail's operands (chain fragments, biases, folded BN) to LDS, once per
   // workgroup; the copy is in flight during the tap set-up and is fenced just before the tail
