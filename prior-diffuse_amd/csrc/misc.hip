@@ -17,12 +17,15 @@
 
 // ---------------------------------------------------------------------------------------
 // Diffusion-step embedding (model/diff3.py:62-95) and the 15 folded per-stage time biases.
-// One 512-thread workgroup per batch item; the three matrices are stored transposed so that
-// thread j streams column j with coalesced reads.  Tiny (1.3 MFLOP per item): latency only.
+// One workgroup per batch item; the three matrices are stored transposed so that thread j streams
+// column j with coalesced reads.  Tiny (1.3 MFLOP per item): latency only.
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ float silu_f(float x) { return x * (1.0f / (1.0f + expf(-x))); }
 
-__global__ __launch_bounds__(512) void time_embed_kernel(const pdse_time_desc d) {
+// blockDim = max(512, NF rounded up to a wavefront) so that every folded output has its own thread; the first 512
+// threads run the two MLP layers.  The dot products keep one running sum (the summation order the golden vectors of
+// the time embedding were checked with).
+__global__ __launch_bounds__(1024) void time_embed_kernel(const pdse_time_desc d) {
   __shared__ float x0[128];
   __shared__ float y1[512];
   __shared__ float y2[512];
@@ -38,17 +41,21 @@ __global__ __launch_bounds__(512) void time_embed_kernel(const pdse_time_desc d)
     x0[j] = low + (high - low) * (t - fl);
   }
   __syncthreads();
-  float s = d.b1[j];
-  for (int i = 0; i < 128; ++i) s += d.p1T[i * 512 + j] * x0[i];
-  y1[j] = silu_f(s);
+  if (j < 512) {
+    float s = d.b1[j];
+    for (int i = 0; i < 128; ++i) s += d.p1T[i * 512 + j] * x0[i];
+    y1[j] = silu_f(s);
+  }
   __syncthreads();
-  s = d.b2[j];
-  for (int i = 0; i < 512; ++i) s += d.p2T[i * 512 + j] * y1[i];
-  s = silu_f(s);
-  y2[j] = s;
-  if (d.temb) d.temb[(size_t)b * 512 + j] = s;
+  if (j < 512) {
+    float s = d.b2[j];
+    for (int i = 0; i < 512; ++i) s += d.p2T[i * 512 + j] * y1[i];
+    s = silu_f(s);
+    y2[j] = s;
+    if (d.temb) d.temb[(size_t)b * 512 + j] = s;
+  }
   __syncthreads();
-  for (int o = j; o < d.NF; o += 512) {
+  for (int o = j; o < d.NF; o += blockDim.x) {
     float a = d.bf[o];
     for (int i = 0; i < 512; ++i) a += d.wfT[(size_t)i * d.NF + o] * y2[i];
     d.out[(size_t)b * d.NF + o] = a;
@@ -59,7 +66,8 @@ int pdse_time_launch(const pdse_time_desc* d, hipStream_t s) {
   REQ(d && d->t && d->table && d->p1T && d->b1 && d->p2T && d->b2 && d->out, "time_embed: null pointer");
   REQ(d->B > 0 && d->max_steps > 0 && d->NF >= 0, "time_embed: bad sizes");
   REQ(d->NF == 0 || (d->wfT && d->bf), "time_embed: folded weights missing");
-  hipLaunchKernelGGL(time_embed_kernel, dim3(d->B), dim3(512), 0, s, *d);
+  const int threads = d->NF <= 512 ? 512 : (d->NF >= 1024 ? 1024 : (d->NF + 63) / 64 * 64);
+  hipLaunchKernelGGL(time_embed_kernel, dim3(d->B), dim3(threads), 0, s, *d);
   return pdse_check_launch("time_embed");
 }
 
