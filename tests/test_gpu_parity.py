@@ -31,6 +31,9 @@ def R():
 
 @pytest.fixture(scope="module")
 def L():
+    import __graft_entry__ as ge
+
+    ge.build()               # no-op when libpdse.so matches the sources; builds in-tree on a box that lacks it
     lib = pkg("_lib")
     lib.load()
     assert torch.cuda.is_available(), "GPU tests need an MI355X"
