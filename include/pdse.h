@@ -337,6 +337,25 @@ typedef struct pdse_crm_desc {
   int32_t plane, B, mode, pad_;
 } pdse_crm_desc;
 
+/* Last decoder stage of the GCRN prior + its Linear over the bins (model/gcrn.py:158-163), one decoder per launch:
+ *   u = cat(in0, ELU(in1))  [32 ch, 80 bins]          (in0 = previous stage, already BN + ELU; in1 = encoder-1 skip)
+ *   g[f] = (convT1(u)[f] + b1) * sigmoid(convT2(u)[f] + b2),  ConvTranspose2d(32 -> 1, (1,3), stride (1,2)): 161 bins
+ *   y = ELU(bn_scale * g + bn_shift);   out[b, t, :] = fcT^T y + fcb        (Linear(161, 161))
+ * A persistent workgroup keeps fcT [161 in][161 out] in LDS and walks (b, t) rows: the single output channel wastes
+ * 31/32 of an MFMA tile and the Linear is a 161-tap gather on the generic kernel otherwise (3 launches, 0.34 ms). */
+typedef struct pdse_gcrnlast_desc {
+  const float* in0;   /* [B][16][T][80] */
+  const float* in1;   /* [B][16][T][80] */
+  const float* w1;    /* [32][3] main branch, ConvTranspose weight[c][0][0][k] */
+  const float* w2;    /* [32][3] gate branch */
+  const float* fcT;   /* [161][161] = fc.weight^T */
+  const float* fcb;   /* [161] */
+  float* out;         /* element (b, t, o) at out + b*out_sb + t*161 + o */
+  int64_t out_sb;
+  float b1, b2, bn_scale, bn_shift;
+  int32_t B, T;
+} pdse_gcrnlast_desc;
+
 /* One dilated residual block of the eps-net's TCMs (model/diff3.py:215-257) over [B][256][T], fused with the
  * NEXT block's 1x1 input convolution (csrc/tcm.hip):
  *   g = main(BN(PReLU(h))) * sigmoid(mask(BN(PReLU(h))));  x_out = conv2(BN(PReLU(g))) + x;  h_out = conv1_next(x_out)
@@ -414,7 +433,8 @@ enum pdse_op_kind {
   PDSE_OP_QSAMPLE = 15,
   PDSE_OP_TRANSPOSE = 16,
   PDSE_OP_TCM = 17,
-  PDSE_OP_CRM = 18
+  PDSE_OP_CRM = 18,
+  PDSE_OP_GCRNLAST = 19
 };
 
 int pdse_abi_version(void);
@@ -442,6 +462,7 @@ int pdse_qsample_f32(const pdse_qsample_desc* d, pdse_stream_t s);
 int pdse_transpose_f32(const pdse_transpose_desc* d, pdse_stream_t s);
 int pdse_tcm_f32(const pdse_tcm_desc* d, pdse_stream_t s);
 int pdse_crm_f32(const pdse_crm_desc* d, pdse_stream_t s);
+int pdse_gcrnlast_f32(const pdse_gcrnlast_desc* d, pdse_stream_t s);
 
 /* plans: a recorded operator sequence replayed by one call (and capturable in a hipGraph) */
 typedef struct pdse_plan pdse_plan;

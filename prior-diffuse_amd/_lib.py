@@ -15,7 +15,7 @@ ACT_NONE, ACT_PRELU, ACT_ELU, ACT_SIGMOID = 0, 1, 2, 3
 EPI_LINEAR, EPI_GLU, EPI_BIGLU = 0, 1, 2
 EW_DIV, EW_UPDATE, EW_UPDATE_FINAL, EW_COPY, EW_ADD_MUL = 0, 1, 2, 3, 4
 (OP_GCONV, OP_TIME, OP_EW, OP_COMPAND, OP_WAVPREP, OP_OLA, OP_SIGMA, OP_LN, OP_LSTM,
- OP_ROWLN, OP_CHLN, OP_ATTN, OP_GRU, OP_GNCOMB, OP_AHAM, OP_QSAMPLE, OP_TRANSPOSE, OP_TCM, OP_CRM) = range(19)
+ OP_ROWLN, OP_CHLN, OP_ATTN, OP_GRU, OP_GNCOMB, OP_AHAM, OP_QSAMPLE, OP_TRANSPOSE, OP_TCM, OP_CRM, OP_GCRNLAST) = range(20)
 
 _fp = C.c_void_p  # device pointers travel as integers
 _i32, _i64, _f32 = C.c_int32, C.c_int64, C.c_float
@@ -145,7 +145,12 @@ class CrmDesc(C.Structure):
                 ("a3", _f32), ("b3", _f32), ("plane", _i32), ("B", _i32), ("mode", _i32), ("pad_", _i32)]
 
 
-DESC_TYPES = {OP_CRM: CrmDesc, OP_TCM: TcmDesc, OP_TRANSPOSE: TransposeDesc, OP_QSAMPLE: QsampleDesc, OP_ROWLN: RowlnDesc, OP_CHLN: ChlnDesc, OP_ATTN: AttnDesc, OP_GRU: GruDesc, OP_GNCOMB: GncombDesc,
+class GcrnLastDesc(C.Structure):
+    _fields_ = [("in0", _fp), ("in1", _fp), ("w1", _fp), ("w2", _fp), ("fcT", _fp), ("fcb", _fp), ("out", _fp),
+                ("out_sb", _i64), ("b1", _f32), ("b2", _f32), ("bn_scale", _f32), ("bn_shift", _f32), ("B", _i32), ("T", _i32)]
+
+
+DESC_TYPES = {OP_GCRNLAST: GcrnLastDesc, OP_CRM: CrmDesc, OP_TCM: TcmDesc, OP_TRANSPOSE: TransposeDesc, OP_QSAMPLE: QsampleDesc, OP_ROWLN: RowlnDesc, OP_CHLN: ChlnDesc, OP_ATTN: AttnDesc, OP_GRU: GruDesc, OP_GNCOMB: GncombDesc,
               OP_AHAM: AhamDesc, OP_GCONV: GconvDesc, OP_TIME: TimeDesc, OP_EW: EwDesc, OP_COMPAND: CompandDesc,
               OP_WAVPREP: WavprepDesc, OP_OLA: OlaDesc, OP_SIGMA: SigmaDesc, OP_LN: LnDesc,
               OP_LSTM: LstmDesc}
@@ -156,7 +161,7 @@ EXPORTS = [
     "pdse_gconv_f32", "pdse_time_embed_f32", "pdse_ew_f32", "pdse_compand_f32", "pdse_wavprep_f32",
     "pdse_ola_f32", "pdse_sigma_mask_f32", "pdse_layernorm_f32", "pdse_lstm_f32",
     "pdse_rowln_prelu_f32", "pdse_chln_f32", "pdse_attention_f32", "pdse_bigru_f32", "pdse_gn_combine_f32",
-    "pdse_aham_f32", "pdse_qsample_f32", "pdse_transpose_f32", "pdse_tcm_f32", "pdse_crm_f32",
+    "pdse_aham_f32", "pdse_qsample_f32", "pdse_transpose_f32", "pdse_tcm_f32", "pdse_crm_f32", "pdse_gcrnlast_f32",
     "pdse_plan_create", "pdse_plan_add", "pdse_plan_size", "pdse_plan_run", "pdse_plan_run_range",
     "pdse_plan_build_graph", "pdse_plan_launch_graph", "pdse_plan_time_ops", "pdse_plan_time_tag",
     "pdse_plan_destroy",
@@ -167,7 +172,7 @@ _DIRECT = {OP_GCONV: "pdse_gconv_f32", OP_TIME: "pdse_time_embed_f32", OP_EW: "p
            OP_SIGMA: "pdse_sigma_mask_f32", OP_LN: "pdse_layernorm_f32", OP_LSTM: "pdse_lstm_f32",
            OP_ROWLN: "pdse_rowln_prelu_f32", OP_CHLN: "pdse_chln_f32", OP_ATTN: "pdse_attention_f32",
            OP_GRU: "pdse_bigru_f32", OP_GNCOMB: "pdse_gn_combine_f32", OP_AHAM: "pdse_aham_f32",
-           OP_QSAMPLE: "pdse_qsample_f32", OP_TRANSPOSE: "pdse_transpose_f32", OP_TCM: "pdse_tcm_f32", OP_CRM: "pdse_crm_f32"}
+           OP_QSAMPLE: "pdse_qsample_f32", OP_TRANSPOSE: "pdse_transpose_f32", OP_TCM: "pdse_tcm_f32", OP_CRM: "pdse_crm_f32", OP_GCRNLAST: "pdse_gcrnlast_f32"}
 
 
 class PdseError(RuntimeError):

@@ -43,6 +43,7 @@ union pdse_any_desc {
   pdse_transpose_desc transpose;
   pdse_tcm_desc tcm;
   pdse_crm_desc crm;
+  pdse_gcrnlast_desc gcrnlast;
 };
 
 struct pdse_op {
@@ -78,6 +79,7 @@ static int op_size(int kind) {
     case PDSE_OP_TRANSPOSE: return (int)sizeof(pdse_transpose_desc);
     case PDSE_OP_TCM: return (int)sizeof(pdse_tcm_desc);
     case PDSE_OP_CRM: return (int)sizeof(pdse_crm_desc);
+    case PDSE_OP_GCRNLAST: return (int)sizeof(pdse_gcrnlast_desc);
     default: return -1;
   }
 }
@@ -103,6 +105,7 @@ static int launch_op(const pdse_op& op, hipStream_t s) {
     case PDSE_OP_TRANSPOSE: return pdse_transpose_launch(&op.d.transpose, s);
     case PDSE_OP_TCM: return pdse_tcm_launch(&op.d.tcm, s);
     case PDSE_OP_CRM: return pdse_crm_launch(&op.d.crm, s);
+    case PDSE_OP_GCRNLAST: return pdse_gcrnlast_launch(&op.d.gcrnlast, s);
     default: pdse_set_error("plan: unknown op kind"); return 1;
   }
 }
@@ -132,6 +135,7 @@ int pdse_qsample_f32(const pdse_qsample_desc* d, pdse_stream_t s) { return pdse_
 int pdse_transpose_f32(const pdse_transpose_desc* d, pdse_stream_t s) { return pdse_transpose_launch(d, (hipStream_t)s); }
 int pdse_tcm_f32(const pdse_tcm_desc* d, pdse_stream_t s) { return pdse_tcm_launch(d, (hipStream_t)s); }
 int pdse_crm_f32(const pdse_crm_desc* d, pdse_stream_t s) { return pdse_crm_launch(d, (hipStream_t)s); }
+int pdse_gcrnlast_f32(const pdse_gcrnlast_desc* d, pdse_stream_t s) { return pdse_gcrnlast_launch(d, (hipStream_t)s); }
 
 int pdse_plan_create(pdse_plan** out) {
   if (!out) {

@@ -373,3 +373,126 @@ int pdse_qsample_launch(const pdse_qsample_desc* d, hipStream_t s) {
   hipLaunchKernelGGL(qsample_kernel, dim3(bx, d->B), dim3(256), 0, s, *d);
   return pdse_check_launch("qsample");
 }
+
+// ---------------------------------------------------------------------------------------
+// GCRN: last decoder stage (gated ConvTranspose 32 -> 1, BN, ELU) + Linear(161,161) over the bins
+// (model/gcrn.py:158-163).  Persistent workgroups: the Linear's weight matrix is read once per workgroup (one
+// column per thread, in registers) and re-used for ~B*T/512 rows; per row 10 KB of activations come in, 644 bytes go out.
+// ---------------------------------------------------------------------------------------
+#define GL_F 161
+#define GL_FI 80
+__device__ __forceinline__ float gl_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+
+__global__ __launch_bounds__(512, 2) void gcrnlast_kernel(const pdse_gcrnlast_desc d) {
+  __shared__ float xs[32 * GL_FI];          // inputs of the current row (ELU already applied to the skip)
+  __shared__ __attribute__((aligned(16))) float ys[164];   // gated, normalised, activated bins (padded to a multiple of 4)
+  __shared__ float wl[192];                 // [32][3] main, then [32][3] gate
+  __shared__ float pm[2][GL_F], pg[2][GL_F], pf[GL_F];   // partial sums of the second thread half
+  const int tid = threadIdx.x;
+  const int o = tid & 255, half = tid >> 8;  // output bin, K half (conv: channels 16*half.., Linear: inputs 84*half..)
+  const bool act = o < GL_F;
+  // thread (o, half) keeps its half of column o of the Linear (84 / 77 weights) in registers for all its rows: the
+  // matrix is read once per workgroup and the per-row product needs only broadcast reads of y.  (A 104 KB LDS image
+  // of the matrix allowed one workgroup per CU and cost 161 more LDS reads per output: 320 us per launch; whole
+  // columns in registers: 205 us at one wave per SIMD.)
+  constexpr int KH = 84;                    // multiple of 4: half 0 covers inputs 0..83, half 1 covers 84..160 (+ zero padding)
+  float col[KH];
+#pragma unroll
+  for (int i = 0; i < KH; ++i) {
+    const int k = KH * half + i;
+    col[i] = (act && k < GL_F) ? d.fcT[k * GL_F + o] : 0.f;
+  }
+  if (tid < 3) ys[GL_F + tid] = 0.f;
+  if (tid < 4) ys[160 + tid] = 0.f;
+  if (tid < 96) {
+    wl[tid] = d.w1[tid];
+    wl[96 + tid] = d.w2[tid];
+  }
+  const float fcb = (act && half == 0) ? d.fcb[o] : 0.f;
+  const int64_t plane = (int64_t)d.T * GL_FI;
+  const int rows = d.B * d.T;
+  // this thread's five (channel, bin) items of a row: element e = tid + 512*i, channel e / 80
+  auto fetch = [&](const int row, float (&v)[5]) {
+    const int b = row / d.T, t = row - b * d.T;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int e = tid + 512 * i;
+      const int c = e / GL_FI, f = e - c * GL_FI;
+      v[i] = c < 16 ? d.in0[((int64_t)b * 16 + c) * plane + (int64_t)t * GL_FI + f]
+                    : d.in1[((int64_t)b * 16 + (c - 16)) * plane + (int64_t)t * GL_FI + f];
+    }
+  };
+  float nxt[5];
+  if ((int)blockIdx.x < rows) fetch(blockIdx.x, nxt);
+  for (int row = blockIdx.x; row < rows; row += gridDim.x) {   // uniform trip count per workgroup
+    const int b = row / d.T, t = row - b * d.T;
+    __syncthreads();                        // previous row's buffers are free (and the staging above is complete)
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int e = tid + 512 * i;
+      const float v = nxt[i];
+      xs[e] = e < 16 * GL_FI ? v : (v > 0.f ? v : gl_exp(v) - 1.0f);   // ELU on the skip half
+    }
+    if (row + (int)gridDim.x < rows) fetch(row + gridDim.x, nxt);   // next row: in flight during this row's arithmetic
+    __syncthreads();
+    float m = 0.f, g = 0.f;
+    if (act) {
+      // ConvTranspose (1,3) stride 2: even bin 2j <- tap 0 at j, tap 2 at j-1; odd bin 2j+1 <- tap 1 at j
+      const int j = o >> 1, c0 = 16 * half;
+      if (o & 1) {
+#pragma unroll
+        for (int c = c0; c < c0 + 16; ++c) {
+          const float x = xs[c * GL_FI + j];
+          m += x * wl[3 * c + 1];
+          g += x * wl[96 + 3 * c + 1];
+        }
+      } else {
+        const bool a = j < GL_FI, p = j >= 1;
+#pragma unroll
+        for (int c = c0; c < c0 + 16; ++c) {
+          const float x0 = a ? xs[c * GL_FI + j] : 0.f, x2 = p ? xs[c * GL_FI + j - 1] : 0.f;
+          m += x0 * wl[3 * c] + x2 * wl[3 * c + 2];
+          g += x0 * wl[96 + 3 * c] + x2 * wl[96 + 3 * c + 2];
+        }
+      }
+      if (half) {
+        pm[1][o] = m;
+        pg[1][o] = g;
+      }
+    }
+    __syncthreads();
+    if (act && half == 0) {
+      m += pm[1][o];
+      g += pg[1][o];
+      float y = (m + d.b1) * __builtin_amdgcn_rcpf(1.0f + gl_exp(-(g + d.b2)));
+      y = y * d.bn_scale + d.bn_shift;
+      ys[o] = y > 0.f ? y : gl_exp(y) - 1.0f;
+    }
+    __syncthreads();
+    float a0 = fcb, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (act) {
+      const float* yh = ys + KH * half;     // half 1 reads 84..167: ys[161..163] are zero, col[] is zero there too
+#pragma unroll
+      for (int i = 0; i < KH; i += 4) {
+        float4 y;
+        if (KH * half + i + 4 <= 164) y = *reinterpret_cast<const float4*>(yh + i);
+        else y = make_float4(0.f, 0.f, 0.f, 0.f);
+        a0 += col[i] * y.x;
+        a1 += col[i + 1] * y.y;
+        a2 += col[i + 2] * y.z;
+        a3 += col[i + 3] * y.w;
+      }
+      if (half) pf[o] = (a0 + a1) + (a2 + a3);
+    }
+    __syncthreads();
+    if (act && half == 0) d.out[(int64_t)b * d.out_sb + (int64_t)t * GL_F + o] = ((a0 + a1) + (a2 + a3)) + pf[o];
+  }
+}
+
+int pdse_gcrnlast_launch(const pdse_gcrnlast_desc* d, hipStream_t s) {
+  REQ(d && d->in0 && d->in1 && d->w1 && d->w2 && d->fcT && d->fcb && d->out, "gcrn_last: null pointer");
+  REQ(d->B > 0 && d->T > 0 && (int64_t)d->B * d->T < (1ll << 31), "gcrn_last: bad sizes");
+  const int rows = d->B * d->T;
+  hipLaunchKernelGGL(gcrnlast_kernel, dim3(rows < 512 ? rows : 512), dim3(512), 0, s, *d);   // two workgroups per CU
+  return pdse_check_launch("gcrn_last");
+}

@@ -30,4 +30,5 @@ int pdse_qsample_launch(const pdse_qsample_desc* d, hipStream_t s);
 int pdse_transpose_launch(const pdse_transpose_desc* d, hipStream_t s);
 int pdse_tcm_launch(const pdse_tcm_desc* d, hipStream_t s);
 int pdse_crm_launch(const pdse_crm_desc* d, hipStream_t s);
+int pdse_gcrnlast_launch(const pdse_gcrnlast_desc* d, hipStream_t s);
 #endif

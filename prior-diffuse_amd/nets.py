@@ -603,6 +603,7 @@ class EpsNetPlan(PlanBase):
 # GCRN prior
 # ==========================================================================
 class GcrnPlan(PlanBase):
+    fused_last = True       # last decoder stage + Linear(161,161) as one persistent launch (pdse_gcrnlast_desc)
     ENC_C = [2, 16, 32, 64, 128, 256]
     ENC_F = [161, 80, 39, 19, 9, 4]
 
@@ -697,6 +698,20 @@ class GcrnPlan(PlanBase):
             for n, (k, ci, co) in enumerate(dec):
                 p = "conv%d_t_%d" % (k, br)
                 Fout = 2 * (Fin - 1) + 3 + (1 if k == 2 else 0)
+                if k == 1 and self.fused_last and not self.force_generic:
+                    # last stage (one output channel) + Linear(161,161) in one persistent launch (csrc/misc.hip)
+                    sc, sh = P.bn_fold(self.sd, "bn1_t_%d" % br)
+                    g = L.GcrnLastDesc()
+                    g.in0, g.in1 = self.d[3].data_ptr(), self.e[0].data_ptr()
+                    up = self.ctx.up
+                    g.w1 = up(self.w(p + ".conv1.weight")[:, 0, 0, :]).data_ptr()          # [32, 3]
+                    g.w2 = up(self.w(p + ".conv2.weight")[:, 0, 0, :]).data_ptr()
+                    g.fcT, g.fcb = up(self.w("fc%d.weight" % br).T).data_ptr(), up(self.w("fc%d.bias" % br)).data_ptr()
+                    g.out, g.out_sb = Ctx.ptr(out, (br - 1) * T * F0), 2 * T * F0
+                    g.b1, g.b2 = float(self.w(p + ".conv1.bias")[0]), float(self.w(p + ".conv2.bias")[0])
+                    g.bn_scale, g.bn_shift, g.B, g.T = float(sc[0]), float(sh[0]), B, T
+                    self.add(g, TAG_PRIOR)
+                    break
                 osb, osc, _, ost, osf = nchw_out(co, T, Fout)
                 for phase in (0, 1):
                     kk, taps = P.convT_phase_taps(1, 3, phase)
@@ -712,11 +727,11 @@ class GcrnPlan(PlanBase):
                     in0 = self.src(self.d[n], co, *nchw(co, T, Fout))
                     skip = self.e[k - 2]
                     in1 = self.src(skip, co, *nchw(co, T, Fout), act=L.ACT_ELU)   # elu(cat(.., skip)) re-applies ELU
-            # Linear(161,161) over the bins (gcrn.py:162-163): taps enumerate the input bin
-            self.gconv(in0=self.src(self.d[4], 1, *nchw(1, T, F0)), Tin=T, Fin=F0, taps=[(0, f) for f in range(F0)],
-                       sf_in=1, wk0=self.w("fc%d.weight" % br).T, Cout=F0, bias0=self.w("fc%d.bias" % br), cin1=True,
-                       out=out, out_strides=(2 * T * F0, 1, 0, F0, 0), out_off=(br - 1) * T * F0, B=B, Tout=T, Fout=1,
-                       tag=TAG_PRIOR)
+            else:   # (no break: the unfused form) Linear(161,161) over the bins (gcrn.py:162-163): taps enumerate the input bin
+                self.gconv(in0=self.src(self.d[4], 1, *nchw(1, T, F0)), Tin=T, Fin=F0, taps=[(0, f) for f in range(F0)],
+                           sf_in=1, wk0=self.w("fc%d.weight" % br).T, Cout=F0, bias0=self.w("fc%d.bias" % br), cin1=True,
+                           out=out, out_strides=(2 * T * F0, 1, 0, F0, 0), out_off=(br - 1) * T * F0, B=B, Tout=T, Fout=1,
+                           tag=TAG_PRIOR)
         return out
 
 

@@ -390,7 +390,30 @@ def run_tcm(d, mem):
     mem.arr(d.x_out, B * 256 * T)[:] = xo.astype(np.float32).reshape(-1)
 
 
-RUNNERS = {L.TcmDesc: run_tcm, L.GconvDesc: run_gconv, L.TimeDesc: run_time, L.EwDesc: run_ew, L.CompandDesc: run_compand,
+def run_gcrnlast(d, mem):
+    """pdse_gcrnlast_desc: gated ConvTranspose 32 -> 1 (1,3)/stride 2 + BN + ELU + Linear(161,161)."""
+    B, T = d.B, d.T
+    x0 = mem.arr(d.in0, B * 16 * T * 80).reshape(B, 16, T, 80).astype(np.float64)
+    x1 = mem.arr(d.in1, B * 16 * T * 80).reshape(B, 16, T, 80).astype(np.float64)
+    u = np.concatenate([x0, np.where(x1 > 0, x1, np.expm1(np.minimum(x1, 0)))], axis=1)       # [B,32,T,80]
+    w = [mem.arr(d.w1, 96).reshape(32, 3).astype(np.float64), mem.arr(d.w2, 96).reshape(32, 3).astype(np.float64)]
+    pre = []
+    for wk in w:
+        o = np.zeros((B, T, 161))
+        for k in range(3):                                    # output bin 2*j + k <- input bin j
+            o[:, :, k:k + 160:2] += np.einsum("bctf,c->btf", u, wk[:, k])
+        pre.append(o)
+    y = (pre[0] + d.b1) * _sig(pre[1] + d.b2)
+    y = y * d.bn_scale + d.bn_shift
+    y = np.where(y > 0, y, np.expm1(np.minimum(y, 0)))
+    fcT = mem.arr(d.fcT, 161 * 161).reshape(161, 161).astype(np.float64)
+    res = (y @ fcT + mem.arr(d.fcb, 161)).astype(np.float32)                                     # [B,T,161]
+    flat, off = mem.view(d.out)
+    idx = off + np.arange(B)[:, None, None] * d.out_sb + np.arange(T)[None, :, None] * 161 + np.arange(161)[None, None, :]
+    flat[idx] = res
+
+
+RUNNERS = {L.GcrnLastDesc: run_gcrnlast, L.TcmDesc: run_tcm, L.GconvDesc: run_gconv, L.TimeDesc: run_time, L.EwDesc: run_ew, L.CompandDesc: run_compand,
            L.WavprepDesc: run_wavprep, L.OlaDesc: run_ola, L.SigmaDesc: run_sigma, L.LnDesc: run_ln,
            L.LstmDesc: run_lstm}
 
