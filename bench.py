@@ -165,9 +165,9 @@ def main():
     eps_flop = EPS_GFLOP_PER_UTT_STEP * 1e9 * (T / 401.0) * B * pipe.nsteps
     achieved = eps_flop / (eps_ms * 1e-3) / 1e12
     # HBM traffic of the same launches from the committed rocprofv3 PMC passes (FETCH_SIZE | WRITE_SIZE collected
-    # separately, profiles/r01_pmc_traffic_v9.json); read-side doubled as MI355X_MICROARCH.md prescribes for gfx950
+    # separately, profiles/r01_pmc_traffic_final.json); read-side doubled as MI355X_MICROARCH.md prescribes for gfx950
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic_v9.json")
+    tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic_final.json")
     n_eps_launch = max(1, sum(per_tag[k]["launches"] for k in ("eps_block", "eps_conv1", "tcm")))
     if os.path.exists(tpath) and B == 32 and T == 401:
         pj = json.load(open(tpath))["eps_net_one_pass"]
@@ -175,7 +175,7 @@ def main():
     roofline = {"bound": "mfma", "kernel": "gconv2_kernel + tcm_block_kernel (eps-net: BiConvGLU/BiConvTransGLU/TCM launches)",
                 "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r01_pmc_traffic_v9.json)",
+                "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r01_pmc_traffic_final.json)",
                 "algorithmic_flop_per_launch": round(eps_flop / n_eps_launch),
                 "avg_launch_ms": round(eps_ms / max(1, sum(per_tag[k]["launches"] for k in ("eps_block", "eps_conv1", "tcm"))), 5),
                 "per_stage_ms": per_tag}
