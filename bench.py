@@ -12,6 +12,10 @@ hipGraph.  Multi-GPU: utterances are sharded over ranks (weak scaling, B=32 per 
 data-path collective; the only collectives are the timing barrier and a max-reduce.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu-baseline]
+
+``--gpus N`` with N > 1 and no launcher environment (WORLD_SIZE unset): this process only spawns N fresh rank
+processes (it never touches a GPU itself) and waits for them; under ``torch.distributed.run`` the ranks already exist
+and ``--gpus`` must equal WORLD_SIZE.  Either way: one process per GPU, RCCL (backend "nccl"), rendezvous on 127.0.0.1.
 """
 import argparse
 import importlib
@@ -28,6 +32,35 @@ sys.path.insert(0, ROOT)
 # algorithmic work per utterance: flops of one eps-net forward at T=401
 EPS_GFLOP_PER_UTT_STEP = 10.29
 FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md, fp32 matrix = fp32 vector peak
+
+
+def _free_port():
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n, argv, dry_run):
+    """Parent of a self-launched multi-GPU run: start n children (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in their
+    environment), wait, return the worst exit code.  The parent makes no HIP call (device_count() does not initialise
+    the runtime on this image), and the children are fresh interpreters, never an exec of a process that touched the GPU."""
+    import subprocess
+
+    if not dry_run:
+        have = torch.cuda.device_count()
+        if have < n:
+            print("bench.py: --gpus %d but this node exposes %d GPU(s)" % (n, have), file=sys.stderr)
+            return 2
+    env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=e))
+    codes = [p.wait() for p in procs]
+    return max(abs(c) for c in codes)
 
 
 def main():
@@ -48,7 +81,19 @@ def main():
     ap.add_argument("--stage-streams", action="store_true",
                     help="with --inflight 2: prior stream | loop stream instead of one stream per batch")
     ap.add_argument("--streams", type=int, default=1, help="concurrent sub-batch pipelines per GPU")
+    ap.add_argument("--full-schedule", action="store_true",
+                    help="BASELINE config 3: the full 50-step reverse schedule instead of 6-step fast sampling")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="rehearse the launch / rendezvous / timing-reduction / reporting path on CPU (gloo, no GPU, no "
+                         "kernels): the JSON line carries \"dry_run\": true and value null")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:], args.dry_run))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        sys.exit("bench.py: --gpus %d does not match WORLD_SIZE=%s of the launcher" % (args.gpus, os.environ["WORLD_SIZE"]))
+    fast = not args.full_schedule
     args.overlap = args.inflight > 1
     args.depth, args.by_batch = max(2, args.inflight), not args.stage_streams
 
@@ -62,13 +107,17 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # PDSE_BENCH_BACKEND=gloo + PDSE_BENCH_DEVICE=0: rehearse the N>1 code path with several ranks on ONE GPU
         # (RCCL refuses two ranks per device); the driver's real runs use nccl, one rank per GPU
-        backend = os.environ.get("PDSE_BENCH_BACKEND", "nccl")
+        backend = "gloo" if args.dry_run else os.environ.get("PDSE_BENCH_BACKEND", "nccl")
         if "PDSE_BENCH_DEVICE" in os.environ:
             local = int(os.environ["PDSE_BENCH_DEVICE"])
         if backend == "nccl":
+            if local >= torch.cuda.device_count():
+                sys.exit("bench.py: rank %d needs GPU %d, node exposes %d" % (rank, local, torch.cuda.device_count()))
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
+    if args.dry_run:
+        return dry_run(args, dist, world, rank)
     torch.cuda.set_device(local)
     dev = "cuda:%d" % local
 
@@ -96,13 +145,13 @@ def main():
     use_graph = not args.no_graph
     if args.overlap:
         runner = pipeline.PipelinedSampler(dev, args.prior, gs, ds, B, L_, depth=args.depth, by_batch=args.by_batch,
-                                           graph=use_graph, fast_sampling=True)
+                                           graph=use_graph, fast_sampling=fast)
         pipe = runner.pipes[0]
     elif args.streams > 1:
-        runner = pipeline.ConcurrentSampler(dev, args.prior, gs, ds, B, L_=L_, nsplit=args.streams, fast_sampling=True)
+        runner = pipeline.ConcurrentSampler(dev, args.prior, gs, ds, B, L_=L_, nsplit=args.streams, fast_sampling=fast)
         pipe = runner.pipes[0]
     else:
-        runner = pipe = pipeline.SamplerPipeline(dev, args.prior, gs, ds, B, L_=L_, fast_sampling=True)
+        runner = pipe = pipeline.SamplerPipeline(dev, args.prior, gs, ds, B, L_=L_, fast_sampling=fast)
 
     def step():
         if args.overlap:
@@ -149,12 +198,22 @@ def main():
     # (in the timed region above the sub-batch pipelines overlap each other, so wall time < sum of durations)
     stream = torch.cuda.current_stream().cuda_stream
     if args.streams > 1 or args.overlap:
+        bank = pipe.bank
         del runner
         torch.cuda.empty_cache()
-        pipe = pipeline.SamplerPipeline(dev, args.prior, gs, ds, B, L_=L_, fast_sampling=True)
+        pipe = pipeline.SamplerPipeline(dev, args.prior, gs, ds, B, L_=L_, fast_sampling=fast, bank=bank)
     pipe.stft.wav.copy_(wav)
     pipe.xT_in.copy_(x_T)
     torch.cuda.synchronize()
+    # the strictly sequential pass (one batch at a time, one stream, hipGraph replay) beside the in-flight number
+    seq_steps = max(3, min(args.steps, 10))
+    pipe.enhance(wav, x_T, graph=use_graph)
+    torch.cuda.synchronize()
+    ts = time.perf_counter()
+    for _ in range(seq_steps):
+        pipe.run(graph=use_graph)
+    torch.cuda.synchronize()
+    ms_sequential = (time.perf_counter() - ts) / seq_steps * 1e3
     per_tag = {}
     for name, tag in (("eps_block", nets.TAG_EPS_BLOCK), ("eps_conv1", nets.TAG_EPS_CONV1), ("tcm", nets.TAG_TCM),
                       ("prior_conv", nets.TAG_PRIOR), ("lstm", nets.TAG_LSTM), ("signal", nets.TAG_SIGNAL),
@@ -167,15 +226,17 @@ def main():
     # HBM traffic of the same launches from the committed rocprofv3 PMC passes (FETCH_SIZE | WRITE_SIZE collected
     # separately, profiles/r01_pmc_traffic_final.json); read-side doubled as MI355X_MICROARCH.md prescribes for gfx950
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic_final.json")
+    tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    if not os.path.exists(tpath):
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic_final.json")
     n_eps_launch = max(1, sum(per_tag[k]["launches"] for k in ("eps_block", "eps_conv1", "tcm")))
-    if os.path.exists(tpath) and B == 32 and T == 401:
+    if os.path.exists(tpath) and B == 32 and T == 401 and fast and args.prior == "GCRN":
         pj = json.load(open(tpath))["eps_net_one_pass"]
         traffic = round((pj["fetch_size_bytes_x2"] + pj["write_size_bytes"]) / pj["launches"])
     roofline = {"bound": "mfma", "kernel": "gconv2_kernel + tcm_block_kernel (eps-net: BiConvGLU/BiConvTransGLU/TCM launches)",
                 "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r01_pmc_traffic_final.json)",
+                "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/%s)" % os.path.basename(tpath),
                 "algorithmic_flop_per_launch": round(eps_flop / n_eps_launch),
                 "avg_launch_ms": round(eps_ms / max(1, sum(per_tag[k]["launches"] for k in ("eps_block", "eps_conv1", "tcm"))), 5),
                 "per_stage_ms": per_tag}
@@ -218,26 +279,31 @@ def main():
         nthreads = max(1, min(16, len(os.sched_getaffinity(0))))
         torch.set_num_threads(nthreads)
         cb = 16 if "aia" not in args.prior else 4   # about 10-15 s of host work
+        if not fast:
+            cb = 2                                   # 50 steps: ~8x the work per utterance
+        cb = max(1, min(cb, int(cb * 4.0 / args.seconds)))
         note("cpu baseline: oracle on %d host threads, %d utterances" % (nthreads, cb))
         w_cpu, x_cpu = synth.synthetic_waveforms(B * world, L_, seed=1234)
         w_cpu, x_cpu = w_cpu[:cb], x_cpu[:cb]
         with torch.no_grad():
             R.enhance(args.prior, gs, ds, w_cpu[:1], x_cpu[:1], params.noise_schedule, params.inference_noise_schedule, True)
             tc = time.perf_counter()
-            R.enhance(args.prior, gs, ds, w_cpu, x_cpu, params.noise_schedule, params.inference_noise_schedule, True)
+            R.enhance(args.prior, gs, ds, w_cpu, x_cpu, params.noise_schedule, params.inference_noise_schedule, fast)
             tc = time.perf_counter() - tc
         cpu = {"value": round(cb * args.seconds / tc, 3), "unit": "audio_s/s", "cores": nthreads, "kind": "port",
                "sample": "oracle (torch-CPU fp32 restatement), %d of the %d utterances in one batch, full path incl. "
                          "STFT/ISTFT, 1-utterance warm-up + 1 timed run (%.1f s)" % (cb, B, tc)}
 
     out = {
-        "metric": "enhanced-audio sec/sec (RTF), 6-step fast sampling, B=32",
+        "metric": "enhanced-audio sec/sec (RTF), %s, B=%d" % ("6-step fast sampling" if fast else "50-step full schedule", B),
         "value": round(rtf, 2), "unit": "audio_s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(ms_per_step, 3), "ms_per_step_sequential": round(ms_sequential, 3),
+        "value_sequential": round(B * args.seconds / (ms_sequential * 1e-3), 2),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "frames_per_s_per_gpu": round(args.steps * B * T / elapsed, 1),
         "config": {"workload": "B=%d x %.0f s 16 kHz utterances per GPU, [B,2,%d,161] spectrograms, %s prior + "
-                               "DiffUNet1 6-step fast sampling, STFT..ISTFT, seeded random weights" % (B, args.seconds, T, args.prior),
+                               "DiffUNet1 %d-step sampling, STFT..ISTFT, seeded random weights" % (B, args.seconds, T, args.prior, pipe.nsteps),
                    "global_batch": B * world, "frames": T, "parallelism": "batch-shard x%d" % world,
                    "graph": use_graph and (not args.overlap or args.by_batch), "streams_per_gpu": args.streams,
                    "batches_in_flight": args.inflight},
@@ -246,6 +312,43 @@ def main():
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def dry_run(args, dist, world, rank):
+    """CPU rehearsal of everything around the kernels: rank set-up, sharding of the global batch, barrier, max-reduce of
+    the elapsed time and the single JSON line from rank 0.  No GPU, no kernels, no throughput claim."""
+    shard = importlib.import_module("prior-diffuse_amd.shard")
+    B = args.batch
+    lo, hi = shard.shard_range(B * world, world, rank)
+    assert hi - lo == B
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        time.sleep(0.001)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001 * (1 + rank))          # uneven ranks: the reduction must return the slowest
+    barrier()
+    elapsed = time.perf_counter() - t0
+    mine = elapsed
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "enhanced-audio sec/sec (RTF), 6-step fast sampling, B=%d" % B, "value": None,
+                          "unit": "audio_s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dry_run": True,
+                          "rank0_elapsed_s": round(mine, 4), "max_elapsed_s": round(elapsed, 4),
+                          "config": {"workload": "dry run (no kernels)", "global_batch": B * world,
+                                     "parallelism": "batch-shard x%d" % world}}))
+    return 0
 
 
 if __name__ == "__main__":

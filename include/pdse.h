@@ -15,7 +15,8 @@
  *
  * Ownership: the caller owns every buffer named in a descriptor (inputs, outputs,
  * packed weights, workspaces).  The library owns only plan objects.  No global mutable
- * state, no device selection: kernels run on the device current on the calling thread.
+ * state; direct launches run on the device current on the calling thread, plans on the device
+ * they were bound to with pdse_plan_set_device (restoring the caller's current device).
  * Threading: one host thread per plan; different plans are independent.
  *
  * Data layout: activations are "channel-major" [B, C, T, F] fp32 with F innermost (the
@@ -30,7 +31,7 @@
 extern "C" {
 #endif
 
-#define PDSE_ABI_VERSION 2
+#define PDSE_ABI_VERSION 3
 
 typedef void* pdse_stream_t; /* hipStream_t */
 
@@ -208,9 +209,12 @@ typedef struct pdse_ola_desc {
   int32_t B, T, L, n_fft, hop, pad_;
 } pdse_ola_desc;
 
-/* forward noising of the training step, prior-grad parameterisation (trainer/complex_ddpm_trainer.py:707-727):
- *   out[b] = a[b] * (label[b] - init[b]) + s[b] * noise[b],  a = sqrt(alpha_bar_t), s = sqrt(1 - alpha_bar_t)
- * per batch item; every product/sum rounded separately like the reference's tensor ops. */
+/* forward noising of the training step (trainer/complex_ddpm_trainer.py:707-729), a = sqrt(alpha_bar_t),
+ * s = sqrt(1 - alpha_bar_t) per batch item; every product/sum rounded separately like the reference's tensor ops:
+ *   mode 0 (pirorgrad, :718):  out[b] = a[b] * (label[b] - init[b]) + s[b] * noise[b]
+ *   mode 1 (deltamu,   :721):  out[b] = a[b] * label[b] + s[b] * (noise[b] + init[b])
+ *   mode 2 (neither,   :724):  out[b] = a[b] * label[b] + s[b] * noise[b]            (init unused, may be NULL)
+ * (--sigma, :709-715: the caller passes noise already multiplied by sqrt(mask), pdse_sigma_mask_f32). */
 typedef struct pdse_qsample_desc {
   const float* label;
   const float* init;
@@ -219,8 +223,23 @@ typedef struct pdse_qsample_desc {
   const float* s; /* [B] */
   float* out;
   int64_t plane; /* elements per batch item */
-  int32_t B, pad_;
+  int32_t B, mode;
 } pdse_qsample_desc;
+
+/* Masked complex MSE of the validation loop (utils/loss.py:34-44, used at trainer/complex_ddpm_trainer.py:490):
+ *   loss = sum_{b, c, t < frames[b], f} (esti - label)^2 / (C * F * sum_b frames[b])
+ * over [B][C][T][F] tensors; frames beyond an utterance's own (the zero padding of the batch) do not count.
+ * Two launches with a fixed summation order (per-workgroup partial sums in double, then one workgroup): the value
+ * does not depend on scheduling.  partial: scratch of B * PDSE_MASKLOSS_BLOCKS doubles. */
+#define PDSE_MASKLOSS_BLOCKS 32
+typedef struct pdse_maskloss_desc {
+  const float* esti;
+  const float* label;
+  const int32_t* frames; /* device, [B] */
+  double* partial;
+  float* out; /* [1] */
+  int32_t B, C, T, F;
+} pdse_maskloss_desc;
 
 /* per-(b,ch) abs-max mask of --sigma (:951-956): out = a * sqrt(|init|/max|init| / 2 + 0.5) */
 typedef struct pdse_sigma_desc {
@@ -434,7 +453,8 @@ enum pdse_op_kind {
   PDSE_OP_TRANSPOSE = 16,
   PDSE_OP_TCM = 17,
   PDSE_OP_CRM = 18,
-  PDSE_OP_GCRNLAST = 19
+  PDSE_OP_GCRNLAST = 19,
+  PDSE_OP_MASKLOSS = 20
 };
 
 int pdse_abi_version(void);
@@ -463,12 +483,20 @@ int pdse_transpose_f32(const pdse_transpose_desc* d, pdse_stream_t s);
 int pdse_tcm_f32(const pdse_tcm_desc* d, pdse_stream_t s);
 int pdse_crm_f32(const pdse_crm_desc* d, pdse_stream_t s);
 int pdse_gcrnlast_f32(const pdse_gcrnlast_desc* d, pdse_stream_t s);
+int pdse_masked_mse_f32(const pdse_maskloss_desc* d, pdse_stream_t s);
 
 /* plans: a recorded operator sequence replayed by one call (and capturable in a hipGraph) */
 typedef struct pdse_plan pdse_plan;
 int pdse_plan_create(pdse_plan** out);
 int pdse_plan_add(pdse_plan* p, int op_kind, const void* desc, int tag);
 int pdse_plan_size(const pdse_plan* p);
+/* Bind the plan to a device ordinal: every run / capture / replay / timing call makes that device current for its
+ * duration and restores the caller's current device (one process per GPU: LOCAL_RANK != 0 while torch still has
+ * device 0 current).  -1 (default): launch on whatever device is current.  Direct pdse_*_f32 launches always use the
+ * current device. */
+int pdse_plan_set_device(pdse_plan* p, int device);
+/* drop every recorded operator (and a captured graph): the plan object can be re-recorded for another geometry */
+int pdse_plan_clear(pdse_plan* p);
 int pdse_plan_run(pdse_plan* p, pdse_stream_t s);
 int pdse_plan_run_range(pdse_plan* p, int begin, int end, pdse_stream_t s);
 /* capture the whole plan into a hipGraph on stream s, then replay it with launch_graph */

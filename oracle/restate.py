@@ -354,8 +354,10 @@ def sigma_mask(init):
 
 
 def reverse_loop(ddpm_sd, init_scaled, x_T, alpha, beta, alpha_cum, sigmas, T, table=None,
-                 use_sigma=False, trace=None, deltamu=False):
+                 use_sigma=False, trace=None, deltamu=False, feat_scaled=None):
     """Runs n = S-1 … 0 on ``audio = x_T`` with ``init_scaled = X_init / 11``.
+    feat_scaled (noisy feature / 11): the branch with neither ``pirorgrad`` nor ``deltamu`` set — DiffUNet1 is
+    conditioned on it instead of X_init (reference :972-974).
 
     The n>0 noise term is kept for fidelity: ``newsigma = max(0, σ - c1σ)`` is
     identically 0 (reference :986-992), so no RNG draw changes the result.
@@ -373,7 +375,10 @@ def reverse_loop(ddpm_sd, init_scaled, x_T, alpha, beta, alpha_cum, sigmas, T, t
         c1 = 1 / alpha[n] ** 0.5
         c2 = beta[n] / (1 - alpha_cum[n]) ** 0.5
         tn = torch.tensor([T[n]]).repeat(N)
-        eps = nocon_forward(ddpm_sd, audio, tn, table) if deltamu else diffunet1_forward(ddpm_sd, audio, init_scaled, tn, table)
+        if deltamu:
+            eps = nocon_forward(ddpm_sd, audio, tn, table)
+        else:
+            eps = diffunet1_forward(ddpm_sd, audio, init_scaled if feat_scaled is None else feat_scaled, tn, table)
         audio = float(c1) * (audio - float(c2) * eps)
         if n > 0:
             newsigma = max(0, gamma[n] - c1 * gamma[n])
@@ -384,18 +389,20 @@ def reverse_loop(ddpm_sd, init_scaled, x_T, alpha, beta, alpha_cum, sigmas, T, t
 
 
 def sample(prior_name, prior_sd, ddpm_sd, feat, x_T, noise_schedule, inference_noise_schedule,
-           fast_sampling=True, use_sigma=False, trace=None, deltamu=False):
+           fast_sampling=True, use_sigma=False, trace=None, deltamu=False, cond="init"):
     """feat [B,2,T,F] (compressed spectrogram) -> enhanced compressed spectrogram.
 
-    reference: trainer/complex_ddpm_trainer.py:941-998.
+    reference: trainer/complex_ddpm_trainer.py:941-998.  cond "feat": neither pirorgrad nor deltamu (:972-974),
+    DiffUNet1 conditioned on feat / 11 and no final ``+ X_init`` (:994-995).
     """
     alpha, beta, alpha_cum, sigmas, T = inference_schedule(noise_schedule, inference_noise_schedule,
                                                            fast_sampling)
     init = PRIORS[prior_name](prior_sd, feat)
     init = init / C_SCALE
+    feat_cond = cond == "feat" and not deltamu
     audio = reverse_loop(ddpm_sd, init, x_T, alpha, beta, alpha_cum, sigmas, T, use_sigma=use_sigma,
-                         trace=trace, deltamu=deltamu)
-    if not deltamu:                  # ``if self.pirorgrad: audio += init_audio`` (reference :995-996)
+                         trace=trace, deltamu=deltamu, feat_scaled=feat / C_SCALE if feat_cond else None)
+    if not (deltamu or feat_cond):   # ``if self.pirorgrad: audio += init_audio`` (reference :995-996)
         audio = audio + init
     audio = audio * C_SCALE
     return audio, init * C_SCALE
@@ -642,3 +649,25 @@ def enhance_ragged(prior_name, prior_sd, ddpm_sd, wavs, x_T, noise_schedule, inf
         y = torch.istft(z, n_fft=320, hop_length=160, win_length=320, window=torch.hann_window(320))[0]
         outs.append(y[: (n // 160) * 160] / cs[i])
     return outs
+
+
+def com_mse_loss(esti, label, frame_list):
+    """reference: utils/loss.py:34-44 — complex MSE over the frames each utterance really has (the zero padding
+    of a ragged batch does not count)."""
+    mask = torch.zeros_like(esti)
+    for i, n in enumerate(frame_list):
+        mask[i, :, :n] = 1.0
+    return (((esti - label) * mask) ** 2).sum() / mask.sum()
+
+
+def q_sample(label, init, t, noise, noise_schedule, mode="pirorgrad", sigma=False):
+    """reference: trainer/complex_ddpm_trainer.py:42-44, :704-729 (label / init already divided by 11)."""
+    noise_level = torch.tensor(np.cumprod(1 - np.array(noise_schedule)).astype(np.float32))
+    ns = noise_level[t].unsqueeze(1).unsqueeze(2).unsqueeze(3)
+    if sigma:
+        noise = noise * sigma_mask(init) ** 0.5
+    if mode == "pirorgrad":
+        return ns ** 0.5 * (label - init) + (1.0 - ns) ** 0.5 * noise
+    if mode == "deltamu":
+        return ns ** 0.5 * label + (1.0 - ns) ** 0.5 * (noise + init)
+    return ns ** 0.5 * label + (1.0 - ns) ** 0.5 * noise

@@ -9,13 +9,15 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PDSE_LIB") or os.path.join(_HERE, "libpdse.so")   # PDSE_LIB: diagnostic builds only
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 ACT_NONE, ACT_PRELU, ACT_ELU, ACT_SIGMOID = 0, 1, 2, 3
 EPI_LINEAR, EPI_GLU, EPI_BIGLU = 0, 1, 2
 EW_DIV, EW_UPDATE, EW_UPDATE_FINAL, EW_COPY, EW_ADD_MUL = 0, 1, 2, 3, 4
 (OP_GCONV, OP_TIME, OP_EW, OP_COMPAND, OP_WAVPREP, OP_OLA, OP_SIGMA, OP_LN, OP_LSTM,
- OP_ROWLN, OP_CHLN, OP_ATTN, OP_GRU, OP_GNCOMB, OP_AHAM, OP_QSAMPLE, OP_TRANSPOSE, OP_TCM, OP_CRM, OP_GCRNLAST) = range(20)
+ OP_ROWLN, OP_CHLN, OP_ATTN, OP_GRU, OP_GNCOMB, OP_AHAM, OP_QSAMPLE, OP_TRANSPOSE, OP_TCM, OP_CRM, OP_GCRNLAST,
+ OP_MASKLOSS) = range(21)
+MASKLOSS_BLOCKS = 32
 
 _fp = C.c_void_p  # device pointers travel as integers
 _i32, _i64, _f32 = C.c_int32, C.c_int64, C.c_float
@@ -127,7 +129,12 @@ class AhamDesc(C.Structure):
 
 class QsampleDesc(C.Structure):
     _fields_ = [("label", _fp), ("init", _fp), ("noise", _fp), ("a", _fp), ("s", _fp), ("out", _fp),
-                ("plane", _i64), ("B", _i32), ("pad_", _i32)]
+                ("plane", _i64), ("B", _i32), ("mode", _i32)]
+
+
+class MasklossDesc(C.Structure):
+    _fields_ = [("esti", _fp), ("label", _fp), ("frames", _fp), ("partial", _fp), ("out", _fp),
+                ("B", _i32), ("C", _i32), ("T", _i32), ("F", _i32)]
 
 
 class TransposeDesc(C.Structure):
@@ -150,7 +157,7 @@ class GcrnLastDesc(C.Structure):
                 ("out_sb", _i64), ("b1", _f32), ("b2", _f32), ("bn_scale", _f32), ("bn_shift", _f32), ("B", _i32), ("T", _i32)]
 
 
-DESC_TYPES = {OP_GCRNLAST: GcrnLastDesc, OP_CRM: CrmDesc, OP_TCM: TcmDesc, OP_TRANSPOSE: TransposeDesc, OP_QSAMPLE: QsampleDesc, OP_ROWLN: RowlnDesc, OP_CHLN: ChlnDesc, OP_ATTN: AttnDesc, OP_GRU: GruDesc, OP_GNCOMB: GncombDesc,
+DESC_TYPES = {OP_MASKLOSS: MasklossDesc, OP_GCRNLAST: GcrnLastDesc, OP_CRM: CrmDesc, OP_TCM: TcmDesc, OP_TRANSPOSE: TransposeDesc, OP_QSAMPLE: QsampleDesc, OP_ROWLN: RowlnDesc, OP_CHLN: ChlnDesc, OP_ATTN: AttnDesc, OP_GRU: GruDesc, OP_GNCOMB: GncombDesc,
               OP_AHAM: AhamDesc, OP_GCONV: GconvDesc, OP_TIME: TimeDesc, OP_EW: EwDesc, OP_COMPAND: CompandDesc,
               OP_WAVPREP: WavprepDesc, OP_OLA: OlaDesc, OP_SIGMA: SigmaDesc, OP_LN: LnDesc,
               OP_LSTM: LstmDesc}
@@ -162,7 +169,9 @@ EXPORTS = [
     "pdse_ola_f32", "pdse_sigma_mask_f32", "pdse_layernorm_f32", "pdse_lstm_f32",
     "pdse_rowln_prelu_f32", "pdse_chln_f32", "pdse_attention_f32", "pdse_bigru_f32", "pdse_gn_combine_f32",
     "pdse_aham_f32", "pdse_qsample_f32", "pdse_transpose_f32", "pdse_tcm_f32", "pdse_crm_f32", "pdse_gcrnlast_f32",
-    "pdse_plan_create", "pdse_plan_add", "pdse_plan_size", "pdse_plan_run", "pdse_plan_run_range",
+    "pdse_masked_mse_f32",
+    "pdse_plan_create", "pdse_plan_add", "pdse_plan_size", "pdse_plan_set_device", "pdse_plan_clear", "pdse_plan_run",
+    "pdse_plan_run_range",
     "pdse_plan_build_graph", "pdse_plan_launch_graph", "pdse_plan_time_ops", "pdse_plan_time_tag",
     "pdse_plan_destroy",
 ]
@@ -172,7 +181,8 @@ _DIRECT = {OP_GCONV: "pdse_gconv_f32", OP_TIME: "pdse_time_embed_f32", OP_EW: "p
            OP_SIGMA: "pdse_sigma_mask_f32", OP_LN: "pdse_layernorm_f32", OP_LSTM: "pdse_lstm_f32",
            OP_ROWLN: "pdse_rowln_prelu_f32", OP_CHLN: "pdse_chln_f32", OP_ATTN: "pdse_attention_f32",
            OP_GRU: "pdse_bigru_f32", OP_GNCOMB: "pdse_gn_combine_f32", OP_AHAM: "pdse_aham_f32",
-           OP_QSAMPLE: "pdse_qsample_f32", OP_TRANSPOSE: "pdse_transpose_f32", OP_TCM: "pdse_tcm_f32", OP_CRM: "pdse_crm_f32", OP_GCRNLAST: "pdse_gcrnlast_f32"}
+           OP_QSAMPLE: "pdse_qsample_f32", OP_TRANSPOSE: "pdse_transpose_f32", OP_TCM: "pdse_tcm_f32", OP_CRM: "pdse_crm_f32", OP_GCRNLAST: "pdse_gcrnlast_f32",
+           OP_MASKLOSS: "pdse_masked_mse_f32"}
 
 
 class PdseError(RuntimeError):
@@ -209,6 +219,8 @@ def load():
     lib.pdse_plan_create.argtypes = [C.POINTER(C.c_void_p)]
     lib.pdse_plan_add.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
     lib.pdse_plan_size.argtypes = [C.c_void_p]
+    lib.pdse_plan_set_device.argtypes = [C.c_void_p, C.c_int]
+    lib.pdse_plan_clear.argtypes = [C.c_void_p]
     lib.pdse_plan_run.argtypes = [C.c_void_p, C.c_void_p]
     lib.pdse_plan_run_range.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     lib.pdse_plan_build_graph.argtypes = [C.c_void_p, C.c_void_p]
@@ -233,21 +245,34 @@ def check(rc, what=""):
         raise PdseError("%s failed: %s" % (what or "libpdse call", load().pdse_last_error().decode()))
 
 
-def launch(desc, stream=0):
-    """Launch one operator directly."""
+def launch(desc, stream=0, device=None):
+    """Launch one operator directly (on ``device`` when given, else on the current device)."""
     lib = load()
     kind = KIND_OF[type(desc)]
+    if device is not None:
+        import torch
+
+        with torch.cuda.device(device):
+            check(getattr(lib, _DIRECT[kind])(C.byref(desc), C.c_void_p(stream)), _DIRECT[kind])
+        return
     check(getattr(lib, _DIRECT[kind])(C.byref(desc), C.c_void_p(stream)), _DIRECT[kind])
 
 
 class Plan:
     """Recorded operator sequence replayed by one C call (include/pdse.h, plans)."""
 
-    def __init__(self):
+    def __init__(self, device=None):
+        """device: torch device (or ordinal) the plan's buffers live on; every run makes it current for the call."""
         self._lib = load()
         h = C.c_void_p()
         check(self._lib.pdse_plan_create(C.byref(h)), "pdse_plan_create")
         self._h = h
+        if device is not None:
+            import torch
+
+            dev = torch.device(device) if not isinstance(device, int) else torch.device("cuda", device)
+            idx = dev.index if dev.index is not None else torch.cuda.current_device()
+            check(self._lib.pdse_plan_set_device(self._h, int(idx)), "pdse_plan_set_device")
         self._keep = []  # python-side owners of every buffer named by a descriptor
         self.has_graph = False
 

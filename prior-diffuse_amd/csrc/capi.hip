@@ -44,6 +44,7 @@ union pdse_any_desc {
   pdse_tcm_desc tcm;
   pdse_crm_desc crm;
   pdse_gcrnlast_desc gcrnlast;
+  pdse_maskloss_desc maskloss;
 };
 
 struct pdse_op {
@@ -56,6 +57,24 @@ struct pdse_plan {
   std::vector<pdse_op> ops;
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
+  int device = -1;   // -1: whatever device is current on the calling thread
+};
+
+// Makes the plan's device current for the duration of a call and restores the caller's afterwards: every buffer of a
+// plan lives on one device, and a stream handle of device N used while device 0 is current fails (or worse, launches on
+// the wrong device).  One process per GPU with LOCAL_RANK != 0 is the case that needs it.
+struct device_guard {
+  int prev = -1;
+  bool ok = true;
+  explicit device_guard(const pdse_plan* p) {
+    if (!p || p->device < 0) return;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != p->device) ok = !pdse_check_hip(hipSetDevice(p->device), "set device");
+    else prev = -1;
+  }
+  ~device_guard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
 };
 
 static int op_size(int kind) {
@@ -80,6 +99,7 @@ static int op_size(int kind) {
     case PDSE_OP_TCM: return (int)sizeof(pdse_tcm_desc);
     case PDSE_OP_CRM: return (int)sizeof(pdse_crm_desc);
     case PDSE_OP_GCRNLAST: return (int)sizeof(pdse_gcrnlast_desc);
+    case PDSE_OP_MASKLOSS: return (int)sizeof(pdse_maskloss_desc);
     default: return -1;
   }
 }
@@ -106,6 +126,7 @@ static int launch_op(const pdse_op& op, hipStream_t s) {
     case PDSE_OP_TCM: return pdse_tcm_launch(&op.d.tcm, s);
     case PDSE_OP_CRM: return pdse_crm_launch(&op.d.crm, s);
     case PDSE_OP_GCRNLAST: return pdse_gcrnlast_launch(&op.d.gcrnlast, s);
+    case PDSE_OP_MASKLOSS: return pdse_maskloss_launch(&op.d.maskloss, s);
     default: pdse_set_error("plan: unknown op kind"); return 1;
   }
 }
@@ -136,6 +157,7 @@ int pdse_transpose_f32(const pdse_transpose_desc* d, pdse_stream_t s) { return p
 int pdse_tcm_f32(const pdse_tcm_desc* d, pdse_stream_t s) { return pdse_tcm_launch(d, (hipStream_t)s); }
 int pdse_crm_f32(const pdse_crm_desc* d, pdse_stream_t s) { return pdse_crm_launch(d, (hipStream_t)s); }
 int pdse_gcrnlast_f32(const pdse_gcrnlast_desc* d, pdse_stream_t s) { return pdse_gcrnlast_launch(d, (hipStream_t)s); }
+int pdse_masked_mse_f32(const pdse_maskloss_desc* d, pdse_stream_t s) { return pdse_maskloss_launch(d, (hipStream_t)s); }
 
 int pdse_plan_create(pdse_plan** out) {
   if (!out) {
@@ -170,11 +192,40 @@ int pdse_plan_add(pdse_plan* p, int op_kind, const void* desc, int tag) {
 
 int pdse_plan_size(const pdse_plan* p) { return p ? (int)p->ops.size() : -1; }
 
+int pdse_plan_set_device(pdse_plan* p, int device) {
+  int n = 0;
+  if (!p || device < -1 || (device >= 0 && (hipGetDeviceCount(&n) != hipSuccess || device >= n))) {
+    pdse_set_error("plan_set_device: no such device");
+    return 1;
+  }
+  if (p->exec) {
+    pdse_set_error("plan_set_device: plan already captured into a graph");
+    return 1;
+  }
+  p->device = device;
+  return 0;
+}
+
+int pdse_plan_clear(pdse_plan* p) {
+  if (!p) {
+    pdse_set_error("plan_clear: null plan");
+    return 1;
+  }
+  if (p->exec) (void)hipGraphExecDestroy(p->exec);
+  if (p->graph) (void)hipGraphDestroy(p->graph);
+  p->exec = nullptr;
+  p->graph = nullptr;
+  p->ops.clear();
+  return 0;
+}
+
 int pdse_plan_run_range(pdse_plan* p, int begin, int end, pdse_stream_t s) {
   if (!p || begin < 0 || end > (int)p->ops.size() || begin > end) {
     pdse_set_error("plan_run_range: bad range");
     return 1;
   }
+  device_guard dg(p);
+  if (!dg.ok) return 1;
   for (int i = begin; i < end; ++i)
     if (int rc = launch_op(p->ops[i], (hipStream_t)s)) return rc;
   return 0;
@@ -188,6 +239,8 @@ int pdse_plan_build_graph(pdse_plan* p, pdse_stream_t s) {
     return 1;
   }
   if (p->exec) return 0;
+  device_guard dg(p);
+  if (!dg.ok) return 1;
   hipStream_t st = (hipStream_t)s;
   if (pdse_check_hip(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal), "begin capture")) return 1;
   int rc = pdse_plan_run(p, s);
@@ -213,6 +266,8 @@ int pdse_plan_launch_graph(pdse_plan* p, pdse_stream_t s) {
     pdse_set_error("plan_launch_graph: no captured graph");
     return 1;
   }
+  device_guard dg(p);
+  if (!dg.ok) return 1;
   return pdse_check_hip(hipGraphLaunch(p->exec, (hipStream_t)s), "graph launch");
 }
 
@@ -221,6 +276,8 @@ int pdse_plan_time_ops(pdse_plan* p, int begin, int end, pdse_stream_t s, float*
     pdse_set_error("plan_time_ops: bad argument");
     return 1;
   }
+  device_guard dg(p);
+  if (!dg.ok) return 1;
   hipStream_t st = (hipStream_t)s;
   const int n = end - begin;
   std::vector<hipEvent_t> ev((size_t)n + 1);
@@ -243,6 +300,8 @@ int pdse_plan_time_tag(pdse_plan* p, int tag, pdse_stream_t s, float* ms_out, in
     pdse_set_error("plan_time_tag: bad argument");
     return 1;
   }
+  device_guard dg(p);
+  if (!dg.ok) return 1;
   hipStream_t st = (hipStream_t)s;
   std::vector<hipEvent_t> ev;
   int rc = 0, cnt = 0;

@@ -358,15 +358,26 @@ __global__ __launch_bounds__(256) void qsample_kernel(const pdse_qsample_desc d)
   const int64_t off = (int64_t)b * d.plane;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < d.plane; i += (int64_t)gridDim.x * 256) {
 #pragma clang fp contract(off)
-    const float diff = d.label[off + i] - d.init[off + i];
-    const float t1 = a * diff;
-    const float t2 = s * d.noise[off + i];
+    float t1, t2;
+    if (d.mode == 0) {          // a * (label - init) + s * noise
+      const float diff = d.label[off + i] - d.init[off + i];
+      t1 = a * diff;
+      t2 = s * d.noise[off + i];
+    } else if (d.mode == 1) {   // a * label + s * (noise + init)
+      t1 = a * d.label[off + i];
+      const float ni = d.noise[off + i] + d.init[off + i];
+      t2 = s * ni;
+    } else {                    // a * label + s * noise
+      t1 = a * d.label[off + i];
+      t2 = s * d.noise[off + i];
+    }
     d.out[off + i] = t1 + t2;
   }
 }
 
 int pdse_qsample_launch(const pdse_qsample_desc* d, hipStream_t s) {
-  REQ(d && d->label && d->init && d->noise && d->a && d->s && d->out, "qsample: null pointer");
+  REQ(d && d->label && d->noise && d->a && d->s && d->out, "qsample: null pointer");
+  REQ(d->mode >= 0 && d->mode <= 2 && (d->mode == 2 || d->init), "qsample: mode 0 / 1 need init");
   REQ(d->B > 0 && d->B <= 65535 && d->plane > 0, "qsample: bad sizes");
   int bx = (int)((d->plane + 255) / 256);
   if (bx > 128) bx = 128;
@@ -495,4 +506,56 @@ int pdse_gcrnlast_launch(const pdse_gcrnlast_desc* d, hipStream_t s) {
   const int rows = d->B * d->T;
   hipLaunchKernelGGL(gcrnlast_kernel, dim3(rows < 512 ? rows : 512), dim3(512), 0, s, *d);   // two workgroups per CU
   return pdse_check_launch("gcrn_last");
+}
+
+// ---------------------------------------------------------------------------------------
+// Masked complex MSE of the validation loop (utils/loss.py:34-44).  HBM-bound: two streamed reads, fixed-order
+// double-precision partial sums (32 workgroups per utterance, then one workgroup over all partials).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ double block_sum_256(double v, double* lds) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) lds[wave] = v;
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x == 0) r = ((lds[0] + lds[1]) + lds[2]) + lds[3];
+  return r;   // valid on thread 0
+}
+
+__global__ __launch_bounds__(256) void maskloss_partial_kernel(const pdse_maskloss_desc d) {
+  __shared__ double lds[4];
+  const int b = blockIdx.y;
+  const int fr = min(max(d.frames[b], 0), d.T);
+  const int64_t plane = (int64_t)d.T * d.F, live = (int64_t)fr * d.F;   // the first `fr` frames of every channel plane
+  double acc = 0.0;
+  for (int c = 0; c < d.C; ++c) {
+    const int64_t base = ((int64_t)b * d.C + c) * plane;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < live; i += (int64_t)gridDim.x * 256) {
+      const float e = d.esti[base + i] - d.label[base + i];   // fp32 difference like the reference, squared in double
+      acc += (double)e * (double)e;
+    }
+  }
+  const double tot = block_sum_256(acc, lds);
+  if (threadIdx.x == 0) d.partial[(int64_t)b * gridDim.x + blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256) void maskloss_final_kernel(const pdse_maskloss_desc d) {
+  __shared__ double lds[4];
+  const int n = d.B * PDSE_MASKLOSS_BLOCKS;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) acc += d.partial[i];
+  const double tot = block_sum_256(acc, lds);
+  if (threadIdx.x == 0) {
+    double frames = 0.0;
+    for (int b = 0; b < d.B; ++b) frames += (double)min(max(d.frames[b], 0), d.T);
+    d.out[0] = (float)(tot / (frames * (double)d.C * (double)d.F));
+  }
+}
+
+int pdse_maskloss_launch(const pdse_maskloss_desc* d, hipStream_t s) {
+  REQ(d && d->esti && d->label && d->frames && d->partial && d->out, "masked_mse: null pointer");
+  REQ(d->B > 0 && d->B <= 65535 && d->C > 0 && d->T > 0 && d->F > 0, "masked_mse: bad sizes");
+  hipLaunchKernelGGL(maskloss_partial_kernel, dim3(PDSE_MASKLOSS_BLOCKS, d->B), dim3(256), 0, s, *d);
+  hipLaunchKernelGGL(maskloss_final_kernel, dim3(1), dim3(256), 0, s, *d);
+  return pdse_check_launch("masked_mse");
 }

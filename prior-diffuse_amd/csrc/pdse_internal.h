@@ -31,4 +31,5 @@ int pdse_transpose_launch(const pdse_transpose_desc* d, hipStream_t s);
 int pdse_tcm_launch(const pdse_tcm_desc* d, hipStream_t s);
 int pdse_crm_launch(const pdse_crm_desc* d, hipStream_t s);
 int pdse_gcrnlast_launch(const pdse_gcrnlast_desc* d, hipStream_t s);
+int pdse_maskloss_launch(const pdse_maskloss_desc* d, hipStream_t s);
 #endif

@@ -7,6 +7,8 @@ signatures for the two networks on the path,
 on contiguous fp32 ``[B,2,T,161]`` tensors living on an MI355X.  Each (B, T) builds its
 plan once (weights packed into HBM once per operator) and replays it afterwards.
 """
+from collections import OrderedDict
+
 import torch
 
 from . import _lib as L
@@ -14,13 +16,28 @@ from . import nets
 
 
 class _PlannedOp:
-    def __init__(self, state_dict, device="cuda:0"):
+    MAX_PLANS = 3   # recorded (B, T) geometries kept (least recently used first out); packed weights are shared
+
+    def __init__(self, state_dict, device="cuda:0", bank=None):
         self.sd = state_dict
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise L.PdseError("operators run on the GPU only (no CPU fallback); got device %s" % device)
         L.load()
-        self._plans = {}
+        self.bank = bank if bank is not None else nets.WeightBank()
+        self._plans = OrderedDict()
+
+    def _plan(self, key, build):
+        """LRU of recorded plans; ``build(ctx)`` records a new one against the shared weight bank."""
+        net = self._plans.get(key)
+        if net is None:
+            while len(self._plans) >= self.MAX_PLANS:
+                self._plans.popitem(last=False)
+            net = self._plans[key] = build(nets.Ctx(self.device, self.bank))
+            net.finish()
+        else:
+            self._plans.move_to_end(key)
+        return net
 
     def _check(self, x):
         if x.dim() != 4 or x.shape[1] != 2 or x.shape[3] != nets.F0:
@@ -34,6 +51,22 @@ class _PlannedOp:
     def eval(self):  # parity contract: eval-mode statistics always
         return self
 
+    @staticmethod
+    def _steps(t):
+        """Diffusion steps as float32 without a device->host round trip: a tensor that already lives on the GPU is
+        range-checked by the kernel's clamp-free table walk only when ``PDSE_CHECK_STEPS`` asks for it (the check
+        costs two synchronisations per call, i.e. per reverse step when the operator is driven from a Python loop);
+        host tensors and python numbers are checked for free."""
+        import os
+
+        if not torch.is_tensor(t):
+            t = torch.as_tensor(t)
+        tf = t.to(torch.float32)
+        if (not tf.is_cuda) or os.environ.get("PDSE_CHECK_STEPS", "0") == "1":
+            if tf.numel() and (float(tf.min()) < 0 or float(tf.max()) > 49):
+                raise IndexError("diffusion step outside the 50-entry embedding table")  # reference: IndexError
+        return tf
+
 
 class DiffUNet1Op(_PlannedOp):
     """ε-network ``DiffUNet1.forward(x, x_init, t)`` (model/diff3.py:37-57).
@@ -45,17 +78,15 @@ class DiffUNet1Op(_PlannedOp):
         B, _, T, _ = x.shape
         if t.shape != (B,):
             raise ValueError("t must have shape [B]")
-        tf = t.to(torch.float32)
-        if float(tf.min()) < 0 or float(tf.max()) > 49:
-            raise IndexError("diffusion step outside the 50-entry embedding table")  # reference: IndexError
-        key = (B, T)
-        if key not in self._plans:
-            net = nets.EpsNetPlan(nets.Ctx(self.device), self.sd, B, T, time_cond=True, nsteps=1)
+        tf = self._steps(t)
+
+        def build(ctx):
+            net = nets.EpsNetPlan(ctx, self.sd, B, T, time_cond=True, nsteps=1)
             net.build_time()
             net.build_step(0)
-            net.finish()
-            self._plans[key] = net
-        net = self._plans[key]
+            return net
+
+        net = self._plan((B, T), build)
         net.x.copy_(x)
         net.x_init.copy_(x_init)
         net.tsteps.copy_(tf.view(1, B))
@@ -69,17 +100,17 @@ class NoconOp(_PlannedOp):
     def __call__(self, x, t):
         self._check(x)
         B, _, T, _ = x.shape
-        tf = t.to(torch.float32)
-        if t.shape != (B,) or float(tf.min()) < 0 or float(tf.max()) > 49:
-            raise IndexError("t must be [B] diffusion steps inside the 50-entry embedding table")
-        key = (B, T)
-        if key not in self._plans:
-            net = nets.EpsNetPlan(nets.Ctx(self.device), self.sd, B, T, time_cond=True, nsteps=1, with_pre=False)
+        if t.shape != (B,):
+            raise ValueError("t must have shape [B]")
+        tf = self._steps(t)
+
+        def build(ctx):
+            net = nets.EpsNetPlan(ctx, self.sd, B, T, time_cond=True, nsteps=1, with_pre=False)
             net.build_time()
             net.build_step(0)
-            net.finish()
-            self._plans[key] = net
-        net = self._plans[key]
+            return net
+
+        net = self._plan((B, T), build)
         net.x.copy_(x)
         net.tsteps.copy_(tf.view(1, B))
         net.plan.run(self._stream())
@@ -92,13 +123,13 @@ class DiffUNetOp(_PlannedOp):
     def __call__(self, x):
         self._check(x)
         B, _, T, _ = x.shape
-        key = (B, T)
-        if key not in self._plans:
-            net = nets.EpsNetPlan(nets.Ctx(self.device), self.sd, B, T, time_cond=False)
+
+        def build(ctx):
+            net = nets.EpsNetPlan(ctx, self.sd, B, T, time_cond=False)
             net.build_step(0)
-            net.finish()
-            self._plans[key] = net
-        net = self._plans[key]
+            return net
+
+        net = self._plan((B, T), build)
         net.x.copy_(x)
         net.plan.run(self._stream())
         return net.out.clone()
@@ -110,13 +141,13 @@ class GCRNOp(_PlannedOp):
     def __call__(self, x):
         self._check(x)
         B, _, T, _ = x.shape
-        key = (B, T)
-        if key not in self._plans:
-            net = nets.GcrnPlan(nets.Ctx(self.device), self.sd, B, T)
+
+        def build(ctx):
+            net = nets.GcrnPlan(ctx, self.sd, B, T)
             net.build()
-            net.finish()
-            self._plans[key] = net
-        net = self._plans[key]
+            return net
+
+        net = self._plan((B, T), build)
         net.x.copy_(x)
         net.plan.run(self._stream())
         return net.out.clone()
@@ -130,13 +161,13 @@ class AiaOp(_PlannedOp):
     def __call__(self, x):
         self._check(x)
         B, _, T, _ = x.shape
-        key = (B, T)
-        if key not in self._plans:
-            net = getattr(nets, self.PLAN)(nets.Ctx(self.device), self.sd, B, T)
+
+        def build(ctx):
+            net = getattr(nets, self.PLAN)(ctx, self.sd, B, T)
             net.build()
-            net.finish()
-            self._plans[key] = net
-        net = self._plans[key]
+            return net
+
+        net = self._plan((B, T), build)
         net.x.copy_(x)
         net.plan.run(self._stream())
         return net.out.clone()
@@ -151,20 +182,40 @@ class DualAiaOp(AiaOp):
 PRIOR_OPS = {"GCRN": GCRNOp, "DiffUNet": DiffUNetOp, "aia_complex_trans_ri": AiaOp, "dual_aia_trans_merge_crm": DualAiaOp}
 
 
-def q_sample(label, init, t, noise, noise_schedule=None):
-    """Forward noising of the training step, prior-grad parameterisation (SURVEY §8f rank 4;
-    trainer/complex_ddpm_trainer.py:42-44, :704-727):
+def q_sample(label, init, t, noise, noise_schedule=None, mode="pirorgrad", sigma=False):
+    """Forward noising of the training step (trainer/complex_ddpm_trainer.py:42-44, :704-729),
+    t int64 [B], alpha_bar the float32 cumprod the trainer keeps in ``noise_level``:
 
-        noisy = sqrt(alpha_bar_t) * (label - init) + sqrt(1 - alpha_bar_t) * noise,   t int64 [B]
+        mode "pirorgrad": noisy = sqrt(ab_t) * (label - init) + sqrt(1 - ab_t) * noise          (:718)
+        mode "deltamu":   noisy = sqrt(ab_t) * label + sqrt(1 - ab_t) * (noise + init)          (:721)
+        mode "plain":     noisy = sqrt(ab_t) * label + sqrt(1 - ab_t) * noise                   (:724)
+        sigma: noise is first multiplied by sqrt(|init| / max|init| / 2 + 0.5) per (b, channel) (:709-715)
 
     ``label`` / ``init`` are already divided by 11 by the caller, like the reference.  Bit-exact with the
-    reference's fp32 tensor arithmetic (alpha_bar is the float32 cumprod the trainer keeps in ``noise_level``)."""
+    reference's fp32 tensor arithmetic."""
     import numpy as np
 
     from .params import params as _p
 
     if label.device.type != "cuda":
         raise L.PdseError("q_sample runs on the GPU only (no CPU fallback)")
+    modes = {"pirorgrad": 0, "deltamu": 1, "plain": 2}
+    if mode not in modes:
+        raise ValueError("mode must be one of %s" % sorted(modes))
+    for x in (label, init, noise):
+        if not x.is_contiguous() or x.dtype != torch.float32 or x.shape != label.shape:
+            raise ValueError("label, init, noise must be contiguous fp32 tensors of one shape")
+    stream = torch.cuda.current_stream(label.device).cuda_stream
+    if sigma:
+        if label.dim() != 4:
+            raise ValueError("sigma mask needs [B,C,T,F] tensors")
+        masked = torch.empty_like(noise)
+        sd_ = L.SigmaDesc()
+        sd_.init, sd_.a, sd_.out = init.data_ptr(), noise.data_ptr(), masked.data_ptr()
+        maxbuf = torch.empty(label.shape[0] * label.shape[1], device=label.device, dtype=torch.float32)
+        sd_.maxbuf, sd_.plane, sd_.nplanes = maxbuf.data_ptr(), label.shape[2] * label.shape[3], label.shape[0] * label.shape[1]
+        L.launch(sd_, stream, device=label.device)
+        noise = masked
     beta = np.array(_p.noise_schedule if noise_schedule is None else noise_schedule)
     noise_level = torch.tensor(np.cumprod(1 - beta).astype(np.float32), device=label.device)     # :42-44
     ns = noise_level[t.to(label.device).long()]
@@ -172,9 +223,31 @@ def q_sample(label, init, t, noise, noise_schedule=None):
     out = torch.empty_like(label)
     d = L.QsampleDesc()
     d.label, d.init, d.noise, d.out = label.data_ptr(), init.data_ptr(), noise.data_ptr(), out.data_ptr()
-    d.a, d.s, d.plane, d.B = a.data_ptr(), s.data_ptr(), label[0].numel(), label.shape[0]
-    for x in (label, init, noise):
-        if not x.is_contiguous() or x.dtype != torch.float32 or x.shape != label.shape:
-            raise ValueError("label, init, noise must be contiguous fp32 tensors of one shape")
-    L.launch(d, torch.cuda.current_stream(label.device).cuda_stream)
+    d.a, d.s, d.plane, d.B, d.mode = a.data_ptr(), s.data_ptr(), label[0].numel(), label.shape[0], modes[mode]
+    L.launch(d, stream, device=label.device)
     return out
+
+
+def com_mse_loss(esti, label, frame_list):
+    """Masked complex MSE of the validation loop (utils/loss.py:34-44; trainer/complex_ddpm_trainer.py:490):
+    ``((esti - label) * mask) ** 2).sum() / mask.sum()`` over [B,2,T,F] with mask = 1 on the first ``frame_list[b]``
+    frames of utterance b.  Returns a 0-dim fp32 tensor on the device (no host synchronisation)."""
+    if esti.device.type != "cuda":
+        raise L.PdseError("com_mse_loss runs on the GPU only (no CPU fallback)")
+    if esti.dim() != 4 or esti.shape != label.shape or esti.dtype != torch.float32 or label.dtype != torch.float32:
+        raise ValueError("esti, label: fp32 tensors of one [B,C,T,F] shape")
+    if not (esti.is_contiguous() and label.is_contiguous()):
+        raise ValueError("esti, label must be contiguous")
+    B, C_, T, F_ = esti.shape
+    frames = torch.as_tensor(list(frame_list), dtype=torch.int32)
+    if frames.numel() != B or int(frames.min()) < 0 or int(frames.max()) > T:
+        raise ValueError("frame_list: one frame count in [0, T] per utterance")
+    frames = frames.to(esti.device)
+    partial = torch.empty(B * L.MASKLOSS_BLOCKS, dtype=torch.float64, device=esti.device)
+    out = torch.empty(1, dtype=torch.float32, device=esti.device)
+    d = L.MasklossDesc()
+    d.esti, d.label, d.frames, d.partial, d.out = (esti.data_ptr(), label.data_ptr(), frames.data_ptr(), partial.data_ptr(),
+                                                    out.data_ptr())
+    d.B, d.C, d.T, d.F = B, C_, T, F_
+    L.launch(d, torch.cuda.current_stream(esti.device).cuda_stream, device=esti.device)
+    return out[0]

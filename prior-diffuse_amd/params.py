@@ -8,21 +8,26 @@ import numpy as np
 
 
 class AttrDict(dict):
-    """dict whose keys are also attributes (reference: utils/params.py:19-32)."""
+    """Mapping whose keys read and write as attributes (``params.fast_sampling``), which is how the reference's
+    trainer consumes its module-level ``params`` (utils/params.py:35-41)."""
 
-    def __init__(self, *args, **kwargs):
-        super().__init__(*args, **kwargs)
-        self.__dict__ = self
+    def __getattr__(self, name):
+        try:
+            return self[name]
+        except KeyError:
+            raise AttributeError(name) from None
 
-    def override(self, attrs):
-        if isinstance(attrs, dict):
-            self.__dict__.update(**attrs)
-        elif isinstance(attrs, (list, tuple, set)):
-            for attr in attrs:
-                self.override(attr)
-        elif attrs is not None:
-            raise NotImplementedError
-        return self
+    def __setattr__(self, name, value):
+        self[name] = value
+
+    def __delattr__(self, name):
+        try:
+            del self[name]
+        except KeyError:
+            raise AttributeError(name) from None
+
+    def copy(self):
+        return AttrDict(self)
 
 
 # reference: utils/params.py:35-41 (the active, un-commented "diffwave" schedule)

@@ -31,17 +31,24 @@ def _expect(t, like, name):
 
 class SamplerPipeline:
     def __init__(self, device, prior_name, prior_sd, ddpm_sd, B, T=None, L_=None, fast_sampling=True,
-                 use_sigma=False, params=default_params, with_signal=None, deltamu=False):
+                 use_sigma=False, params=default_params, with_signal=None, deltamu=False, cond="init", bank=None):
         """deltamu: the alternative parameterisation of utils/params.py:36 — ddpm_sd is a ``Nocon`` state_dict,
-        x_T = noise + X_init/11 (:947-948), eps = Nocon(x, t) (:970-971), no final ``+ X_init`` (:995)."""
+        x_T = noise + X_init/11 (:947-948), eps = Nocon(x, t) (:970-971), no final ``+ X_init`` (:995).
+        cond (deltamu False): what conditions DiffUNet1 — "init": X_init/11 (pirorgrad, :967-969, + X_init at the end,
+        :994-995); "feat": the noisy feature / 11 (the branch with neither flag set, :74-75, :972-974; no final add).
+        bank: a ``nets.WeightBank`` shared with other pipelines built from the same state_dicts (packed weights are
+        uploaded once, every further (B, T) only records descriptors)."""
         if L_ is not None:
             T = 1 + L_ // 160
         if with_signal is None:
             with_signal = L_ is not None
+        if cond not in ("init", "feat"):
+            raise ValueError("cond must be 'init' or 'feat'")
         self.B, self.T, self.L = B, T, L_
         self.device = torch.device(device)
-        self.ctx = ctx = nets.Ctx(device)
-        self.plan = L.Plan() if self.device.type == "cuda" else None
+        self.ctx = ctx = nets.Ctx(device, bank)
+        self.bank = ctx.bank
+        self.plan = L.Plan(self.device) if self.device.type == "cuda" else None
         alpha, beta, alpha_cum, sigmas, Tarr = inference_schedule(params, fast_sampling)
         self.schedule = (alpha, beta, alpha_cum, sigmas, Tarr)
         c1, c2 = step_coefficients(alpha, beta, alpha_cum)
@@ -69,11 +76,13 @@ class SamplerPipeline:
         self.eps = adopt(nets.EpsNetPlan(ctx, ddpm_sd, B, T, time_cond=True, nsteps=S, plan=self.plan,
                                          with_pre=not deltamu))
         self.deltamu = deltamu
+        self.cond_feat = cond_feat = (cond == "feat") and not deltamu
         self.istft = adopt(nets.IstftPlan(ctx, B, T, L_, plan=self.plan)) if with_signal else None
 
         self.feat = self.prior.x                     # prior input = compressed spectrogram
-        self.init = self.eps.x_init if not deltamu else ctx.alloc(B, 2, T, F0)   # X_init / 11
-        self.zero = ctx.alloc(B, 2, T, F0, zero=True) if deltamu else None
+        # X_init / 11: the eps-net's conditioning input only in the pirorgrad parameterisation
+        self.init = self.eps.x_init if not (deltamu or cond_feat) else ctx.alloc(B, 2, T, F0)
+        self.zero = ctx.alloc(B, 2, T, F0, zero=True) if (deltamu or cond_feat) else None
         self.audio = self.eps.x                      # x_t, updated in place
         self.spec = self.istft.spec if with_signal else ctx.alloc(B, 2, T, F0)
         self.xT_in = ctx.alloc(B, 2, T, F0)          # injected x_T (kept so a replay starts from it)
@@ -99,18 +108,20 @@ class SamplerPipeline:
 
         def prologue():
             ew(L.EW_DIV, self.prior.out, out=self.init, s0=PRIOR_SCALE_C)
-            if use_sigma:
+            if cond_feat:
+                ew(L.EW_DIV, self.feat, out=self.eps.x_init, s0=PRIOR_SCALE_C)        # batch_feat /= c  (:943)
+            src = self.xT_in
+            if deltamu:
+                ew(L.EW_ADD_MUL, self.xT_in, b=self.init, out=self.audio, s0=1.0)     # randn_like(init) + init  (:947-948)
+                src = self.audio
+            if use_sigma:                                                             # audio * sqrt(mask(init))  (:951-956)
                 d = L.SigmaDesc()
-                d.init, d.a, d.out = self.init.data_ptr(), self.xT_in.data_ptr(), self.audio.data_ptr()
+                d.init, d.a, d.out = self.init.data_ptr(), src.data_ptr(), self.audio.data_ptr()
                 d.maxbuf = ctx.alloc(B * 2).data_ptr()
                 d.plane, d.nplanes = T * F0, B * 2
                 self.eps.add(d, nets.TAG_EW)
-            elif deltamu:
-                ew(L.EW_ADD_MUL, self.xT_in, b=self.init, out=self.audio, s0=1.0)     # randn_like(init) + init
-            else:
+            elif not deltamu:
                 ew(L.EW_COPY, self.xT_in, out=self.audio)
-            if deltamu and use_sigma:
-                raise NotImplementedError("--sigma with deltamu is not built")
             self.eps.build_time()
 
         mark("prologue", prologue)
@@ -120,18 +131,20 @@ class SamplerPipeline:
             nstep = S - 1 - i
 
             def one(i=i, nstep=nstep):
-                self.eps.build_step(i, x=self.audio, x_init=None if deltamu else self.init, out=self.eps.out)
+                self.eps.build_step(i, x=self.audio, x_init=None if deltamu else (self.eps.x_init if cond_feat else self.init),
+                                    out=self.eps.out)
                 if nstep > 0:
                     ew(L.EW_UPDATE, self.audio, b=self.eps.out, out=self.audio, s0=float(c1[nstep]), s1=float(c2[nstep]))
                 else:
-                    ew(L.EW_UPDATE_FINAL, self.audio, b=self.eps.out, c=self.zero if deltamu else self.init, out=self.spec,
+                    ew(L.EW_UPDATE_FINAL, self.audio, b=self.eps.out, c=self.zero if self.zero is not None else self.init,
+                       out=self.spec,
                        s0=float(c1[0]), s1=float(c2[0]), s2=PRIOR_SCALE_C)
 
             mark("step%d" % nstep, one)
         if with_signal:
             mark("istft", lambda: self.istft.build(spec=self.spec, c=self.stft.c))
         if self.plan is not None:
-            self.plan.keep(ctx.keep)
+            self.plan.keep(ctx.keep, ctx.bank)
         self._graph_stream = None
 
     # ------------------------------------------------------------------
@@ -203,6 +216,7 @@ class ConcurrentSampler:
         self.device = torch.device(device)
         self.B, self.nsplit = B, max(1, min(nsplit, B))
         self.spans = [shard_range(B, self.nsplit, r) for r in range(self.nsplit)]
+        kw.setdefault("bank", nets.WeightBank())    # one packed copy of the weights for all sub-batch pipelines
         self.pipes = [SamplerPipeline(device, prior_name, prior_sd, ddpm_sd, hi - lo, T=T, L_=L_, **kw)
                       for lo, hi in self.spans]
         self.T, self.L = self.pipes[0].T, self.pipes[0].L
@@ -260,6 +274,7 @@ class PipelinedSampler:
         True: every batch runs start to end on its own stream, ``depth`` streams round-robin."""
         self.device = torch.device(device)
         self.depth, self.by_batch, self.graph = depth, by_batch, graph
+        kw.setdefault("bank", nets.WeightBank())    # the in-flight buffer sets share one packed copy of the weights
         self.pipes = [SamplerPipeline(device, prior_name, prior_sd, ddpm_sd, B, L_=L_, **kw) for _ in range(depth)]
         self.s_prior = torch.cuda.Stream(self.device, priority=-1)   # tiny dependent launches: schedule them first
         self.s_loop = torch.cuda.Stream(self.device)

@@ -35,10 +35,15 @@ def enhance_sharded(enhance_fn, wav, x_T, group=None, gather=True):
     m = (B + world - 1) // world
     pad = out.new_zeros((m, wav.shape[1]))
     pad[: hi - lo] = out
-    parts = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(parts, pad, group=group)
+    # RCCL ("nccl") moves device buffers peer to peer over xGMI; gloo (CPU rehearsals, several ranks sharing one GPU)
+    # gathers host copies
+    via_host = pad.is_cuda and dist.get_backend(group) != "nccl"
+    send = pad.cpu() if via_host else pad
+    parts = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(parts, send, group=group)
     res = []
     for r in range(world):
         a, b = shard_range(B, world, r)
         res.append(parts[r][: b - a])
-    return torch.cat(res, dim=0)
+    full = torch.cat(res, dim=0)
+    return full.to(out.device) if via_host else full

@@ -15,19 +15,22 @@ Deliberate differences from the reference, all recorded in SURVEY.md §0/§2:
 import glob
 import logging
 import os
+from collections import OrderedDict
 from copy import deepcopy
 
 import numpy as np
 import torch
 
 from . import _lib as L
-from . import ops, wavio
+from . import nets, ops, wavio
 from .params import PRIOR_SCALE_C, params as default_params
 from .pipeline import SamplerPipeline
 from .schedule import inference_schedule as _inference_schedule
 
 
 class ComplexDDPMTrainer(object):
+    MAX_PLANS = 3   # recorded (B, T) geometries kept alive (least recently used first out); weights are shared by all
+
     def __init__(self, args, config, device=None, prior_state_dict=None, ddpm_state_dict=None, params=None):
         """args: .retrain .joint .draw .sigma .checkpoint .generated_wav
         config: .model.name, .train.{fft_num, win_size, win_shift, feat_type}
@@ -37,11 +40,10 @@ class ComplexDDPMTrainer(object):
         self.args = deepcopy(args)
         self.config = deepcopy(config)
         self.params = default_params if params is None else params    # :34 (override: synthetic runs / deltamu)
-        self.pirorgrad = self.params.pirorgrad
-        self.deltamu = self.params.deltamu
-        if self.pirorgrad == self.deltamu:
-            # :70-75 also has a third branch (neither flag: DiffUNet1 conditioned on the noisy feature); not built
-            raise NotImplementedError("exactly one of pirorgrad (DiffUNet1) / deltamu (Nocon) must be set")
+        self.pirorgrad = bool(self.params.pirorgrad)
+        # :70-75 / :967-974: pirorgrad wins over deltamu; neither flag = DiffUNet1 conditioned on the noisy feature
+        self.deltamu = bool(self.params.deltamu) and not self.pirorgrad
+        self.cond = "init" if (self.pirorgrad or self.deltamu) else "feat"
         tr = self.config.train
         if (tr.fft_num, tr.win_size, tr.win_shift) != (320, 320, 160) or tr.feat_type != "sqrt":
             raise NotImplementedError("STFT 320/320/160 with feat_type 'sqrt' is baked into every model of the path")
@@ -60,9 +62,10 @@ class ComplexDDPMTrainer(object):
             self._load_checkpoint()
         if self.prior_sd is None or self.ddpm_sd is None:
             raise ValueError("no weights: pass state_dicts or use --retrain with a best_checkpoint.pth")
-        self.model = ops.PRIOR_OPS[self.prior_name](self.prior_sd, self.device)       # :69
-        self.model_ddpm = (ops.NoconOp if self.deltamu else ops.DiffUNet1Op)(self.ddpm_sd, self.device)   # :70-73
-        self._pipes = {}
+        self.bank = nets.WeightBank()     # packed weights in HBM: uploaded once, shared by every plan of this trainer
+        self.model = ops.PRIOR_OPS[self.prior_name](self.prior_sd, self.device, bank=self.bank)       # :69
+        self.model_ddpm = (ops.NoconOp if self.deltamu else ops.DiffUNet1Op)(self.ddpm_sd, self.device, bank=self.bank)   # :70-73
+        self._pipes = OrderedDict()
 
     # ---- A8 checkpoint rules (:91-97, :906-913) ---------------------------
     def _load_checkpoint(self):
@@ -74,6 +77,11 @@ class ComplexDDPMTrainer(object):
                 self.ddpm_sd = data[2]
         else:
             self.prior_sd = data
+        if getattr(self, "_pipes", None):      # new weights: every recorded plan and the packed copies are stale
+            self._pipes.clear()
+            self.bank = nets.WeightBank()
+            self.model = ops.PRIOR_OPS[self.prior_name](self.prior_sd, self.device, bank=self.bank)
+            self.model_ddpm = (ops.NoconOp if self.deltamu else ops.DiffUNet1Op)(self.ddpm_sd, self.device, bank=self.bank)
         logging.info("loaded %s", path)
 
     # ---- A1 ---------------------------------------------------------------
@@ -82,12 +90,21 @@ class ComplexDDPMTrainer(object):
 
     # ---- batched entry points ----------------------------------------------
     def _pipe(self, B, T=None, L_=None):
+        """The recorded plan of one geometry.  ``generate_wav`` meets a new utterance length with almost every file:
+        a new plan re-records its descriptors (milliseconds) against the weights already packed in ``self.bank``;
+        only ``MAX_PLANS`` geometries keep their activation buffers, the least recently used one is dropped."""
         key = (B, T, L_, bool(getattr(self.args, "sigma", False)), bool(self.params.fast_sampling))
-        if key not in self._pipes:
-            self._pipes[key] = SamplerPipeline(self.device, self.prior_name, self.prior_sd, self.ddpm_sd, B, T=T,
-                                               L_=L_, fast_sampling=self.params.fast_sampling,
-                                               use_sigma=key[3], params=self.params, deltamu=self.deltamu)
-        return self._pipes[key]
+        pipe = self._pipes.get(key)
+        if pipe is None:
+            while len(self._pipes) >= self.MAX_PLANS:
+                self._pipes.popitem(last=False)
+            pipe = self._pipes[key] = SamplerPipeline(
+                self.device, self.prior_name, self.prior_sd, self.ddpm_sd, B, T=T, L_=L_,
+                fast_sampling=self.params.fast_sampling, use_sigma=key[3], params=self.params, deltamu=self.deltamu,
+                cond=self.cond, bank=self.bank)
+        else:
+            self._pipes.move_to_end(key)
+        return pipe
 
     def _x_T(self, shape, x_T):
         if x_T is None:                                               # :947-950 randn_like(init)
@@ -126,17 +143,31 @@ class ComplexDDPMTrainer(object):
         return [out[i, :cut[i]].clone() for i in range(B)]
 
     # ---- A2..A7: the reference's entry point --------------------------------
-    def generate_wav(self, load_pre_train=True, data_path="data/noisy_testset_wav"):
+    def generate_wav(self, load_pre_train=True, data_path="data/noisy_testset_wav", rng_fidelity=True):
         """Per-file B=1 enhancement of ``data_path/*.wav`` into ``args.generated_wav``
-        (:903-1018).  Returns the list of written paths instead of calling exit()."""
+        (:903-1018).  Returns the list of written paths instead of calling exit().
+
+        rng_fidelity: the reference draws ``randn_like(audio)`` after every reverse step n > 0 (:986-987) and multiplies
+        it by ``newsigma == 0``; the draws change nothing in a file's output but advance the generator, so file k's
+        x_T depends on them.  With the flag set the same number of same-shaped draws is made (and discarded) after each
+        file, which keeps a seeded ``--generate`` run on the reference's generator stream file for file.
+        Files that cannot be read (unsupported encoding) are logged and skipped instead of aborting the run."""
         if load_pre_train and getattr(self.args, "retrain", False):
             self._load_checkpoint()
         os.makedirs(self.args.generated_wav, exist_ok=True)
         written = []
         with torch.no_grad():
             for path in sorted(glob.glob(data_path + "/*.wav")):
-                wav = torch.from_numpy(wavio.read_wav(path, 16000))[None]
+                try:
+                    wav = torch.from_numpy(wavio.read_wav(path, 16000))[None]
+                except (ValueError, EOFError, wavio.wave.Error) as e:
+                    logging.warning("skipping %s: %s", path, e)
+                    continue
                 out = self.enhance(wav)[0].cpu().numpy()
+                if rng_fidelity:
+                    shape = (1, 2, 1 + wav.shape[1] // 160, 161)
+                    for _ in range(len(self._pipes[next(reversed(self._pipes))].schedule[0]) - 1):
+                        torch.randn(*shape, device=self.device, dtype=torch.float32)     # :986 randn_like, scaled by 0
                 dst = os.path.join(self.args.generated_wav, path.split("/")[-1])
                 wavio.write_wav(dst, out, 16000)
                 written.append(dst)

@@ -1,9 +1,40 @@
 """16-bit / float PCM wav read+write with the standard library only (the reference uses
 librosa.load(sr=16000) and soundfile.write, trainer/complex_ddpm_trainer.py:921, :1018;
-neither is a dependency of this package)."""
+neither is a dependency of this package).  Precondition: RIFF/WAVE PCM (8/16/32-bit integer); files the ``wave``
+module rejects (IEEE float, WAVE_FORMAT_EXTENSIBLE) raise and ``generate_wav`` skips them with a warning.  Other
+sample rates are converted with a Kaiser-windowed-sinc polyphase filter; librosa's default (soxr_hq) is a
+different filter of similar quality, so resampled inputs agree with the reference's to filter-design accuracy
+(about -80 dB), not bit for bit."""
 import wave
+from math import gcd
 
 import numpy as np
+
+
+def resample(x, sr_in, sr_out, half_width=16, beta=8.6):
+    """Rational-rate conversion: out[n] = sum_k h(n * down - k * up) x[k] with a Kaiser-windowed sinc low-pass at
+    the narrower Nyquist band, evaluated polyphase (only the taps that meet a non-zero input sample)."""
+    x = np.asarray(x, dtype=np.float64)
+    if sr_in == sr_out or x.size == 0:
+        return x.astype(np.float32)
+    g = gcd(int(sr_in), int(sr_out))
+    up, down = int(sr_out) // g, int(sr_in) // g
+    m = max(up, down)
+    half = half_width * m                                     # filter half length on the up-sampled grid
+    n_h = np.arange(-half, half + 1)
+    h = np.sinc(n_h / m) / m * np.kaiser(2 * half + 1, beta) * up
+    n_out = int(np.ceil(x.size * up / down))
+    out = np.zeros(n_out)
+    n = np.arange(n_out)
+    q = n * down                                              # position of output n on the up-sampled grid
+    k_c, r = q // up, q % up                                  # nearest input sample at or before it, offset in between
+    jmax = half // up + 1
+    for j in range(-jmax, jmax + 1):                          # input sample k_c - j sits at grid offset r + j * up
+        off = r + j * up
+        k = k_c - j
+        ok = (np.abs(off) <= half) & (k >= 0) & (k < x.size)
+        out[ok] += h[off[ok] + half] * x[k[ok]]
+    return out.astype(np.float32)
 
 
 def read_wav(path, sr=16000):
@@ -21,8 +52,7 @@ def read_wav(path, sr=16000):
     if ch > 1:
         x = x.reshape(-1, ch).mean(axis=1)  # librosa.load(mono=True)
     if rate != sr:
-        raise ValueError("%s is %d Hz; resampling to %d Hz is not built (the VoiceBank test set is 16 kHz after "
-                         "the reference's preprocessing)" % (path, rate, sr))
+        x = resample(x, rate, sr)        # librosa.load(sr=16000) resamples (VoiceBank-DEMAND ships at 48 kHz)
     return x
 
 

@@ -174,11 +174,14 @@ def test_diffunet_prior_golden(L, weights):
     assert rel_l2(out.cpu(), g["out"]) < 2e-5
 
 
-def test_operator_input_checks(L, weights):
+def test_operator_input_checks(L, weights, monkeypatch):
     op = pkg("ops").DiffUNet1Op(weights("DiffUNet1"), DEV)
     x = torch.zeros(1, 2, 8, 161, device=DEV)
     with pytest.raises(ValueError):
         op(torch.zeros(1, 2, 8, 257, device=DEV), x, torch.zeros(1, device=DEV))   # F=257 cannot run
+    with pytest.raises(IndexError):
+        op(x, x, torch.tensor([50.0]))                     # host-side steps are range-checked for free
+    monkeypatch.setenv("PDSE_CHECK_STEPS", "1")            # device-side steps: checked on request (costs a sync per call)
     with pytest.raises(IndexError):
         op(x, x, torch.tensor([50.0], device=DEV))
     with pytest.raises(L.PdseError):

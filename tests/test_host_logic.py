@@ -47,7 +47,7 @@ def test_eps_net_plan_vs_oracle(weights, chained, monkeypatch):
     net.x.copy_(x)
     net.x_init.copy_(xi)
     net.tsteps.copy_(t.view(1, B))
-    emu.run(net.descs, ctx.keep)
+    emu.run(net.descs, ctx.all_tensors())
     taps = {}
     with torch.no_grad():
         ref = R.diffunet1_forward(sd, x, xi, t, taps=taps)
@@ -66,7 +66,7 @@ def test_gcrn_and_diffunet_prior_plans_vs_oracle(weights):
     net = nets.GcrnPlan(ctx, weights("GCRN"), B, T)
     net.build()
     net.x.copy_(x)
-    emu.run(net.descs, ctx.keep)
+    emu.run(net.descs, ctx.all_tensors())
     taps = {}
     with torch.no_grad():
         ref = R.gcrn_forward(weights("GCRN"), x, taps=taps)
@@ -77,7 +77,7 @@ def test_gcrn_and_diffunet_prior_plans_vs_oracle(weights):
     p = nets.EpsNetPlan(ctx2, weights("DiffUNet"), B, T, time_cond=False)
     p.build_step(0)
     p.x.copy_(x)
-    emu.run(p.descs, ctx2.keep)
+    emu.run(p.descs, ctx2.all_tensors())
     with torch.no_grad():
         refp = R.diffunet_forward(weights("DiffUNet"), x)
     assert rel_l2(p.out, refp) < TOL
@@ -96,7 +96,7 @@ def test_whole_pipeline_plan_vs_oracle(weights, sigma):
     wav = wav * torch.tensor([0.1, 3.0])[:, None]
     P.stft.wav.copy_(wav)
     P.xT_in.copy_(x_T)
-    emu.run(P.descs, P.ctx.keep)
+    emu.run(P.descs, P.ctx.all_tensors())
     with torch.no_grad():
         ref_wav, ref_spec = R.enhance("GCRN", weights("GCRN"), weights("DiffUNet1"), wav, x_T, params.noise_schedule,
                                       params.inference_noise_schedule, True, sigma)
@@ -113,10 +113,10 @@ def test_step_descriptors_are_cloned_not_repacked(weights):
     ctx = nets.Ctx("cpu")
     net = nets.EpsNetPlan(ctx, weights("DiffUNet1"), 1, 8, time_cond=True, nsteps=3)
     net.build_step(0)
-    n_keep = len(ctx.keep)
+    n_keep = len(ctx.all_tensors())
     first = [d for d, _ in net.descs]
     net.build_step(2)
-    assert len(ctx.keep) == n_keep
+    assert len(ctx.all_tensors()) == n_keep
     second = [d for d, _ in net.descs[len(first):]]
     assert len(second) == len(first)
     delta = 2 * 1 * net.NSLOT * 32 * 4

@@ -3,6 +3,7 @@ from the reference's real modules (oracle/make_golden.py).  fp32 on both sides, 
 torch build: tolerance 2e-6 rel-L2 (summation-order noise only); the schedule is
 bit-exact."""
 import numpy as np
+import pytest
 import torch
 
 from conftest import golden, pkg, rel_l2, seeded
@@ -225,3 +226,46 @@ def test_nocon_and_deltamu_sampling(weights):
         o, init = R.sample("GCRN", weights("GCRN"), weights("Nocon"), feat, x_T, params.noise_schedule,
                            params.inference_noise_schedule, True, False, deltamu=True)
     assert rel_l2(o, gs["out"]) < 2e-5
+
+
+@pytest.mark.parametrize("tag,ddpm,kw", [
+    ("gcrn_fast_featcond", "DiffUNet1", dict(cond="feat")),
+    ("gcrn_fast_featcond_sigma", "DiffUNet1", dict(cond="feat", use_sigma=True)),
+    ("gcrn_fast_deltamu_sigma", "Nocon", dict(deltamu=True, use_sigma=True)),
+])
+def test_branches_pinned_by_the_reference_statements(weights, tag, ddpm, kw):
+    """Fixtures produced by executing the reference's own generate_wav statements (AST-extracted :941-996, see
+    oracle/make_golden.py::ref_generate_body): the third conditioning branch (neither flag set) and --sigma on top of
+    the deltamu parameterisation."""
+    params = pkg("params").params
+    g = golden("sample_" + tag)
+    feat, x_T = seeded((2, 2, 16, 161), g["seed_feat"]), seeded((2, 2, 16, 161), g["seed_xT"])
+    with torch.no_grad():
+        out, init = R.sample("GCRN", weights("GCRN"), weights(ddpm), feat, x_T, params.noise_schedule,
+                             params.inference_noise_schedule, True, **kw)
+    assert rel_l2(init, g["init"]) < 2e-6
+    assert rel_l2(out, g["out"]) < 2e-5
+
+
+def test_ragged_validation_batch_pinned_by_the_reference(weights):
+    """SURVEY 8f rank 2.  The fixture is one batch of the reference's validation loop executed from its own text
+    (Collate.collate_fn, the loop statements :409-494, com_mse_loss, compare_complex - oracle/make_golden.py::
+    ref_validation_batch): per-utterance normalisation over the true length, zero padding, batched sampling, masked
+    loss, per-utterance ISTFT cut to (frame_num - 1) * 160 samples."""
+    params = pkg("params").params
+    g = golden("ragged_validation")
+    gen = torch.Generator().manual_seed(int(g["seed"]))
+    lens = [int(n) for n in g["lens"]]
+    wavs = [0.2 * torch.randn(n, generator=gen) for n in lens]
+    x_T = torch.randn(3, 2, 1 + max(lens) // 160, 161, generator=gen)
+    assert list(g["frame_list"]) == [n // 160 + 1 for n in lens]
+    with torch.no_grad():
+        outs = R.enhance_ragged("GCRN", weights("GCRN"), weights("DiffUNet1"), wavs, x_T, params.noise_schedule,
+                                params.inference_noise_schedule, True, False)
+    for i, (w, o) in enumerate(zip(wavs, outs)):
+        c = float(np.sqrt(w.numel() / float((w.double() ** 2).sum())))      # utils/dataset.py:45: the fixture stays normalised
+        ref = g["utt%d" % i]
+        assert o.numel() == ref.shape[0] == (lens[i] // 160) * 160
+        assert rel_l2(o * c, ref) < 2e-5
+    loss = R.com_mse_loss(torch.from_numpy(g["audio"]), torch.from_numpy(g["label"]), list(g["frame_list"]))
+    assert abs(float(loss) - float(g["loss"])) <= 2e-6 * float(g["loss"])
