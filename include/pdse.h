@@ -279,6 +279,38 @@ typedef struct pdse_lstm_desc {
   int32_t B, Bp, T, H, G, pad_;
 } pdse_lstm_desc;
 
+/* Both layers of the grouped LSTM and the LayerNorm between them (gcrn.py:22-35) as a layer wavefront: T + 2
+ * launches, each carrying layer 1 at frame s, the layer-2 input projection (LayerNorm 1 folded) at frame s-1 and
+ * layer 2 at frame s-2 (csrc/lstm.hip).  Replaces two pdse_lstm_f32 calls, the LayerNorm(1024) between them and
+ * the two layer-2 input-projection GEMMs.
+ *   gx1   [G][T][4H][Bp]        layer-1 input projections + both biases (as pdse_lstm_desc.gx)
+ *   whh1, whh2 [G][H/8][H/8][64][4]   recurrent weights: slice s = gate rows q*H + 8s + u (tile row q*8 + u), K in natural
+ *                                order, four k-steps per 16-byte lane entry (packing.pack_a4)
+ *   wih2  same shape             W_ih of layer 2 times diag(gamma_ln1); K order (g', kq, i, hh): k-group gq = 32 g' + kq'
+ *                                holds units u = 8 (32 g + kq') + 2 i + hh of source group g', i.e. feature 2 u + g'
+ *   r2, c2 [G][4H]               row sums of the folded weights; W_ih beta_ln1 + b_ih + b_hh
+ *   hT1, hT2 [2][G][H/8][2][Bp][4]   states, ping-pong by frame parity, unit 8 kq + 2 i + hh at [kq][hh][b][i]
+ *   cst1, cst2 [G][H][Bp]; gx2 [2][G][4H][Bp]; part [2][G][H/8][Bp][2] (LayerNorm partial sums); all scratch
+ *   y     layer-2 output, y[b*y_sb + t*y_st + u*y_su + g*y_sg] */
+typedef struct pdse_glstm_desc {
+  const float* gx1;
+  const float* whh1;
+  const float* wih2;
+  const float* r2;
+  const float* c2;
+  const float* whh2;
+  float* hT1;
+  float* cst1;
+  float* hT2;
+  float* cst2;
+  float* gx2;
+  float* part;
+  float* y;
+  int64_t y_sb, y_st, y_su, y_sg;
+  int32_t B, Bp, T, H, G;
+  float eps;
+} pdse_glstm_desc;
+
 /* ---- DB-AIAT prior (model/dbaiat.py), channel-major [B,C,T,F] tensors ------------------- */
 
 /* LayerNorm over the bins of every (b,c,t) row + per-channel PReLU
@@ -454,7 +486,8 @@ enum pdse_op_kind {
   PDSE_OP_TCM = 17,
   PDSE_OP_CRM = 18,
   PDSE_OP_GCRNLAST = 19,
-  PDSE_OP_MASKLOSS = 20
+  PDSE_OP_MASKLOSS = 20,
+  PDSE_OP_GLSTM = 21
 };
 
 int pdse_abi_version(void);
@@ -484,6 +517,7 @@ int pdse_tcm_f32(const pdse_tcm_desc* d, pdse_stream_t s);
 int pdse_crm_f32(const pdse_crm_desc* d, pdse_stream_t s);
 int pdse_gcrnlast_f32(const pdse_gcrnlast_desc* d, pdse_stream_t s);
 int pdse_masked_mse_f32(const pdse_maskloss_desc* d, pdse_stream_t s);
+int pdse_glstm_f32(const pdse_glstm_desc* d, pdse_stream_t s);
 
 /* plans: a recorded operator sequence replayed by one call (and capturable in a hipGraph) */
 typedef struct pdse_plan pdse_plan;

@@ -121,9 +121,13 @@ int pdse_chln_launch(const pdse_chln_desc* d, hipStream_t s) {
 #define ATTN_THREADS 1024
 // HD = head dimension (8: d_model 32, 16: d_model 64; always 4 heads).  A workgroup handles one 32-channel window
 // of one line (32 / HD heads), so K and V of the window fit LDS for sequences up to 640 positions.
+// Sequences longer than one LDS image (S > 640: 10 s utterances, T = 1001) are walked in key chunks of CH positions:
+// K and V of a chunk are staged, every thread advances the online softmax of its (query, head) items over the chunk
+// and keeps (m, l, acc) in registers across chunks.  Chunks are multiples of four keys, so the rescale grouping - and
+// with it every rounding - is the one a single image would give.
 template <int HD>
-__global__ __launch_bounds__(ATTN_THREADS) void attn_kernel(const pdse_attn_desc d) {
-  extern __shared__ float kv[];  // [S][32] keys, then [S][32] values
+__global__ __launch_bounds__(ATTN_THREADS) void attn_kernel(const pdse_attn_desc d, const int CH) {
+  extern __shared__ float kv[];  // [CH][32] keys, then [CH][32] values
   constexpr int W = 32, HW = W / HD;
   const int E = d.E;
   const int b = blockIdx.y, line = blockIdx.x, c0 = blockIdx.z * W;
@@ -132,71 +136,91 @@ __global__ __launch_bounds__(ATTN_THREADS) void attn_kernel(const pdse_attn_desc
   const int64_t base = (int64_t)b * 3 * E * plane + (d.axis == 0 ? (int64_t)line * d.F : (int64_t)line);
   const int64_t ss = d.axis == 0 ? 1 : d.F;
   float* ks = kv;
-  float* vs = kv + (size_t)S * W;
-  for (int i = threadIdx.x; i < S * W; i += ATTN_THREADS) {
-    const int e = i / S, sp = i - e * S;  // consecutive threads -> consecutive sequence positions
-    ks[sp * W + e] = d.qkv[base + (int64_t)(E + c0 + e) * plane + (int64_t)sp * ss];
-    vs[sp * W + e] = d.qkv[base + (int64_t)(2 * E + c0 + e) * plane + (int64_t)sp * ss];
+  float* vs = kv + (size_t)CH * W;
+  const bool single = CH >= S;
+  auto stage = [&](const int k0, const int n) {
+    for (int i = threadIdx.x; i < n * W; i += ATTN_THREADS) {
+      const int e = i / n, sp = i - e * n;  // consecutive threads -> consecutive sequence positions
+      ks[sp * W + e] = d.qkv[base + (int64_t)(E + c0 + e) * plane + (int64_t)(k0 + sp) * ss];
+      vs[sp * W + e] = d.qkv[base + (int64_t)(2 * E + c0 + e) * plane + (int64_t)(k0 + sp) * ss];
+    }
+  };
+  if (single) {
+    stage(0, S);
+    __syncthreads();
   }
-  __syncthreads();
   const int64_t obase = (int64_t)b * E * plane + (d.axis == 0 ? (int64_t)line * d.F : (int64_t)line);
-  for (int idx = threadIdx.x; idx < S * HW; idx += ATTN_THREADS) {
-    const int hd = idx / S, sq = idx - hd * S;
+  const int rounds = (S * HW + ATTN_THREADS - 1) / ATTN_THREADS;   // uniform trip count: the chunk loop holds barriers
+  for (int round = 0; round < rounds; ++round) {
+    const int idx = round * ATTN_THREADS + threadIdx.x;
+    const bool valid = idx < S * HW;
+    const int hd = valid ? idx / S : 0, sq = valid ? idx - hd * S : 0;
     float q[HD], acc[HD];
 #pragma unroll
     for (int e = 0; e < HD; ++e) {
-      q[e] = d.qkv[base + (int64_t)(c0 + hd * HD + e) * plane + (int64_t)sq * ss];
+      q[e] = valid ? d.qkv[base + (int64_t)(c0 + hd * HD + e) * plane + (int64_t)sq * ss] : 0.f;
       acc[e] = 0.f;
     }
     float m = -1e30f, l = 0.f;
     const float* kh = ks + hd * HD;
     const float* vh = vs + hd * HD;
-    int sp = 0;
-    for (; sp + 4 <= S; sp += 4) {
-      float sc[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        float a = 0.f;
-#pragma unroll
-        for (int e4 = 0; e4 < HD; e4 += 4) {
-          const float4 k0 = *reinterpret_cast<const float4*>(kh + (sp + u) * W + e4);
-          a += q[e4] * k0.x + q[e4 + 1] * k0.y + q[e4 + 2] * k0.z + q[e4 + 3] * k0.w;
-        }
-        sc[u] = a;
+    for (int k0 = 0; k0 < S; k0 += CH) {
+      const int n = min(CH, S - k0);
+      if (!single) {
+        __syncthreads();          // every reader of the previous chunk (or round) is done with the image
+        stage(k0, n);
+        __syncthreads();
       }
-      const float mn = fmaxf(fmaxf(m, fmaxf(sc[0], sc[1])), fmaxf(sc[2], sc[3]));
-      const float corr = aia_exp(m - mn);
-      l *= corr;
+      if (!valid) continue;
+      int sp = 0;
+      for (; sp + 4 <= n; sp += 4) {
+        float sc[4];
 #pragma unroll
-      for (int e = 0; e < HD; ++e) acc[e] *= corr;
+        for (int u = 0; u < 4; ++u) {
+          float a = 0.f;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const float pw = aia_exp(sc[u] - mn);
-        l += pw;
-#pragma unroll
-        for (int e4 = 0; e4 < HD; e4 += 4) {
-          const float4 v0 = *reinterpret_cast<const float4*>(vh + (sp + u) * W + e4);
-          acc[e4] += pw * v0.x; acc[e4 + 1] += pw * v0.y; acc[e4 + 2] += pw * v0.z; acc[e4 + 3] += pw * v0.w;
+          for (int e4 = 0; e4 < HD; e4 += 4) {
+            const float4 kq = *reinterpret_cast<const float4*>(kh + (sp + u) * W + e4);
+            a += q[e4] * kq.x + q[e4 + 1] * kq.y + q[e4 + 2] * kq.z + q[e4 + 3] * kq.w;
+          }
+          sc[u] = a;
         }
+        const float mn = fmaxf(fmaxf(m, fmaxf(sc[0], sc[1])), fmaxf(sc[2], sc[3]));
+        const float corr = aia_exp(m - mn);
+        l *= corr;
+#pragma unroll
+        for (int e = 0; e < HD; ++e) acc[e] *= corr;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float pw = aia_exp(sc[u] - mn);
+          l += pw;
+#pragma unroll
+          for (int e4 = 0; e4 < HD; e4 += 4) {
+            const float4 v0 = *reinterpret_cast<const float4*>(vh + (sp + u) * W + e4);
+            acc[e4] += pw * v0.x; acc[e4 + 1] += pw * v0.y; acc[e4 + 2] += pw * v0.z; acc[e4 + 3] += pw * v0.w;
+          }
+        }
+        m = mn;
       }
-      m = mn;
+      for (; sp < n; ++sp) {
+        const float* kr = kh + sp * W;
+        float s1 = 0.f;
+#pragma unroll
+        for (int e = 0; e < HD; ++e) s1 += q[e] * kr[e];
+        const float mn = fmaxf(m, s1);
+        const float corr = aia_exp(m - mn), pw = aia_exp(s1 - mn);
+        const float* vr = vh + sp * W;
+        l = l * corr + pw;
+#pragma unroll
+        for (int e = 0; e < HD; ++e) acc[e] = acc[e] * corr + pw * vr[e];
+        m = mn;
+      }
     }
-    for (; sp < S; ++sp) {
-      const float* kr = kh + sp * W;
-      float s1 = 0.f;
+    if (valid) {
+      const float inv = 1.0f / l;
 #pragma unroll
-      for (int e = 0; e < HD; ++e) s1 += q[e] * kr[e];
-      const float mn = fmaxf(m, s1);
-      const float corr = aia_exp(m - mn), pw = aia_exp(s1 - mn);
-      const float* vr = vh + sp * W;
-      l = l * corr + pw;
-#pragma unroll
-      for (int e = 0; e < HD; ++e) acc[e] = acc[e] * corr + pw * vr[e];
-      m = mn;
+      for (int e = 0; e < HD; ++e) d.out[obase + (int64_t)(c0 + hd * HD + e) * plane + (int64_t)sq * ss] = acc[e] * inv;
     }
-    const float inv = 1.0f / l;
-#pragma unroll
-    for (int e = 0; e < HD; ++e) d.out[obase + (int64_t)(c0 + hd * HD + e) * plane + (int64_t)sq * ss] = acc[e] * inv;
   }
 }
 
@@ -206,17 +230,18 @@ int pdse_attn_launch(const pdse_attn_desc* d, hipStream_t s) {
       "attention: 4 heads, d_model 32 or 64 (dbaiat.py:123-126, :186-189)");
   REQ(d->axis == 0 || d->axis == 1, "attention: axis 0 (bins) or 1 (frames)");
   const int S = d->axis == 0 ? d->F : d->T, lines = d->axis == 0 ? d->T : d->F;
-  const size_t lds = (size_t)2 * S * 32 * sizeof(float);
-  REQ(lds <= 160 * 1024, "attention: sequence too long for one LDS image (S <= 640)");
+  // one LDS image when the sequence fits (S <= 640), else key chunks of 512 positions (128 KB; a multiple of four keys)
+  const int CH = S <= 640 ? S : 512;
+  const size_t lds = (size_t)2 * CH * 32 * sizeof(float);
   const void* fn = d->E == 32 ? (const void*)attn_kernel<8> : (const void*)attn_kernel<16>;
   if (lds > 64 * 1024)
     if (pdse_check_hip(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "attention lds attribute"))
       return 1;
   const dim3 grid(lines, d->B, d->E / 32);
   if (d->E == 32)
-    hipLaunchKernelGGL(attn_kernel<8>, grid, dim3(ATTN_THREADS), lds, s, *d);
+    hipLaunchKernelGGL(attn_kernel<8>, grid, dim3(ATTN_THREADS), lds, s, *d, CH);
   else
-    hipLaunchKernelGGL(attn_kernel<16>, grid, dim3(ATTN_THREADS), lds, s, *d);
+    hipLaunchKernelGGL(attn_kernel<16>, grid, dim3(ATTN_THREADS), lds, s, *d, CH);
   return pdse_check_launch("attention");
 }
 

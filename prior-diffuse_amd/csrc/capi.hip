@@ -45,6 +45,7 @@ union pdse_any_desc {
   pdse_crm_desc crm;
   pdse_gcrnlast_desc gcrnlast;
   pdse_maskloss_desc maskloss;
+  pdse_glstm_desc glstm;
 };
 
 struct pdse_op {
@@ -100,6 +101,7 @@ static int op_size(int kind) {
     case PDSE_OP_CRM: return (int)sizeof(pdse_crm_desc);
     case PDSE_OP_GCRNLAST: return (int)sizeof(pdse_gcrnlast_desc);
     case PDSE_OP_MASKLOSS: return (int)sizeof(pdse_maskloss_desc);
+    case PDSE_OP_GLSTM: return (int)sizeof(pdse_glstm_desc);
     default: return -1;
   }
 }
@@ -127,6 +129,7 @@ static int launch_op(const pdse_op& op, hipStream_t s) {
     case PDSE_OP_CRM: return pdse_crm_launch(&op.d.crm, s);
     case PDSE_OP_GCRNLAST: return pdse_gcrnlast_launch(&op.d.gcrnlast, s);
     case PDSE_OP_MASKLOSS: return pdse_maskloss_launch(&op.d.maskloss, s);
+    case PDSE_OP_GLSTM: return pdse_glstm_launch(&op.d.glstm, s);
     default: pdse_set_error("plan: unknown op kind"); return 1;
   }
 }
@@ -158,6 +161,7 @@ int pdse_tcm_f32(const pdse_tcm_desc* d, pdse_stream_t s) { return pdse_tcm_laun
 int pdse_crm_f32(const pdse_crm_desc* d, pdse_stream_t s) { return pdse_crm_launch(d, (hipStream_t)s); }
 int pdse_gcrnlast_f32(const pdse_gcrnlast_desc* d, pdse_stream_t s) { return pdse_gcrnlast_launch(d, (hipStream_t)s); }
 int pdse_masked_mse_f32(const pdse_maskloss_desc* d, pdse_stream_t s) { return pdse_maskloss_launch(d, (hipStream_t)s); }
+int pdse_glstm_f32(const pdse_glstm_desc* d, pdse_stream_t s) { return pdse_glstm_launch(d, (hipStream_t)s); }
 
 int pdse_plan_create(pdse_plan** out) {
   if (!out) {

@@ -93,3 +93,210 @@ int pdse_lstm_launch(const pdse_lstm_desc* d, hipStream_t s) {
   for (int t = 0; t < d->T; ++t) hipLaunchKernelGGL(lstm_step_kernel<32>, grid, block, 0, s, *d, t, t & 1);
   return pdse_check_launch("lstm");
 }
+
+// =======================================================================================
+// Both layers of the grouped LSTM + LayerNorm 1 as a LAYER WAVEFRONT (model/gcrn.py:22-35).
+//
+// The per-frame launch above leaves the chain at 2 x T dependent launches.  What is sequential is only
+// h_t -> h_{t+1} inside a layer; layer 2 can work on frame t-2 while layer 1 works on frame t.  One launch
+// per wavefront step s = 0 .. T+1 carries three stages, each a 32-row x K=512 x 32-item matvec per workgroup:
+//   A  layer 1, frame s:        gates = gx1[s] + W_hh1 h1[s-1]           -> h1[s], LayerNorm partial sums
+//   B  layer-2 input, frame s-1: gx2 = rs_b (W'_ih2 h1[s-1] - mu_b R) + C  (LayerNorm 1 folded, below)
+//   C  layer 2, frame s-2:      gates = gx2 + W_hh2 h2[s-3]               -> h2[s-2] -> y
+// so the chain is T + 2 launches instead of 2 T, the [B,T,1024] LayerNorm output, the layer-2 input projection
+// GEMMs and their 210 MB gate buffer disappear (gx2 lives for two frames), and all 256 CUs have work
+// (3 x 128 workgroups at B = 32).
+//
+// LayerNorm folded into stage B:  W_ih LN(y) = rs (W' y) - rs mu (W' 1) + (W_ih beta),  W' = W_ih diag(gamma),
+// with mu_b, rs_b = rsqrt(var_b + eps) over the 1024 interleaved outputs of both groups (stack(dim=-1) + flatten:
+// feature j = 2 u + g).  Stage A writes, per workgroup, the sums of h and h^2 over its 8 units for every batch
+// item; stage B adds the 128 partials in a fixed order (no atomics: results do not depend on scheduling).
+//
+// Operand layout: the state h is kept [H/8][2][Bp][4] (unit 8 kq + 2 i + hh at [kq][hh][b][i]), so that the B
+// operand of four consecutive k-steps is ONE 16-byte load per lane (the per-frame kernel issues four 4-byte loads),
+// and the weights are packed four k-steps deep like the gather-GEMM's (packing.pack_a4).  Stage B walks K in the
+// order (source group g', kq, i, hh) of that layout; the host permutes W'_ih2's columns to match.
+// =======================================================================================
+__device__ __forceinline__ float sigm_g(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// index of hidden unit u, batch item b in the state layout [H/8][2][Bp][4]
+__device__ __forceinline__ size_t hidx(const int u, const int b, const int Bp) {
+  return (((size_t)(u >> 3) * 2 + (u & 1)) * Bp + b) * 4 + ((u & 7) >> 1);
+}
+
+__global__ __launch_bounds__(512) void glstm_wave_kernel(const pdse_glstm_desc d, const int s) {
+  __shared__ float red[8][32][33];
+  __shared__ float stat[16][32][2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 31, h = lane >> 5;
+  const int slice = blockIdx.x, g = blockIdx.y;
+  const int nbt = d.Bp >> 5;
+  const int stage = blockIdx.z / nbt, bt = blockIdx.z - stage * nbt;
+  const int t = s - stage;
+  if (t < 0 || t >= d.T) return;
+  const int H = d.H, Bp = d.Bp, G = d.G;
+  const size_t hsz = (size_t)H * Bp;               // one group's state
+  const int par = t & 1;
+
+  // ---- operands of this stage's matvec
+  const float* Aw;                                  // [H/8 groups of 4 k-steps][64 lanes][4]
+  const float* hsrc0;                               // state read by k-groups 0..31 of this workgroup's K range
+  const float* hsrc1;                               // ... by k-groups 32..63
+  int kq0, kq1;                                     // first state row block of each half
+  bool skip = false;
+  if (stage == 0) {                                 // W_hh1 h1[t-1]
+    Aw = d.whh1;
+    hsrc0 = hsrc1 = d.hT1 + ((size_t)par * G + g) * hsz;
+    kq0 = 0, kq1 = 32;
+    skip = t == 0;
+  } else if (stage == 1) {                          // W'_ih2 y1[t]: features of chunk g = units 256g..256g+255 of BOTH groups
+    Aw = d.wih2;
+    const float* base = d.hT1 + (size_t)((t + 1) & 1) * G * hsz;   // h1[t] was written to parity (t & 1) ^ 1
+    hsrc0 = base, hsrc1 = base + hsz;               // source group g' = 0, then g' = 1
+    kq0 = kq1 = 32 * g;
+  } else {                                          // W_hh2 h2[t-1]
+    Aw = d.whh2;
+    hsrc0 = hsrc1 = d.hT2 + ((size_t)par * G + g) * hsz;
+    kq0 = 0, kq1 = 32;
+    skip = t == 0;
+  }
+  const float4* A4 = reinterpret_cast<const float4*>(Aw) + ((size_t)(g * (H / 8) + slice) * (H / 8)) * 64 + lane;
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  if (!skip) {
+    // wave w multiplies k-groups 8w .. 8w+7 (32 k-steps); all 16 loads are requested before the first MFMA
+    float4 av[8], bv[8];
+    const int q0 = wave * 8;
+    const float* hs = q0 < 32 ? hsrc0 : hsrc1;
+    const int kq = (q0 < 32 ? kq0 : kq1) + (q0 & 31);
+    const float4* B4 = reinterpret_cast<const float4*>(hs) + ((size_t)kq * 2 + h) * Bp + bt * 32 + col;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      av[i] = A4[(size_t)(q0 + i) * 64];
+      bv[i] = B4[(size_t)i * 2 * Bp];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].x, bv[i].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].y, bv[i].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].z, bv[i].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].w, bv[i].w, acc, 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue operands, requested before the reduction barrier
+  const int u = (threadIdx.x >> 5) & 7, bb = threadIdx.x & 31;   // threads 0..255: (unit, batch item)
+  const int b = bt * 32 + bb;
+  const int hu = slice * 8 + u;
+  float pre[4] = {0.f, 0.f, 0.f, 0.f};
+  float c_old = 0.f;
+  const size_t ci = ((size_t)g * H + hu) * Bp + b;
+  if (threadIdx.x < 256) {
+    if (stage == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) pre[q] = d.gx1[(((size_t)g * d.T + t) * (4 * H) + (size_t)q * H + hu) * Bp + b];
+      if (t > 0) c_old = d.cst1[ci];
+    } else if (stage == 2) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) pre[q] = d.gx2[(((size_t)par * G + g) * (4 * H) + (size_t)q * H + hu) * Bp + b];
+      if (t > 0) c_old = d.cst2[ci];
+    }
+  }
+  if (stage == 1) {
+    // LayerNorm statistics of frame t: 2 groups x H/8 slices partial (sum, sumsq) pairs per batch item, fixed order
+    const int p = threadIdx.x >> 5;                  // 16 parts of 8 entries
+    const float2* P2 = reinterpret_cast<const float2*>(d.part) + ((size_t)par * G * (H / 8)) * Bp + b;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float2 v = P2[(size_t)(p * 8 + e) * Bp];
+      s1 += v.x;
+      s2 += v.y;
+    }
+    stat[p][bb][0] = s1;
+    stat[p][bb][1] = s2;
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * h][col] = acc[r];
+  __syncthreads();
+  const bool fin = threadIdx.x < 256;               // (unit, item) threads; every wave still reaches the barrier below
+  float gate[4] = {0.f, 0.f, 0.f, 0.f};
+  if (fin) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = q * 8 + u;
+      float sum = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) sum += red[w][i][bb];
+      gate[q] = sum;
+    }
+  }
+  if (stage == 1) {
+    if (!fin) return;                               // no further barrier in this stage
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+      s1 += (double)stat[p][bb][0];
+      s2 += (double)stat[p][bb][1];
+    }
+    const double n = (double)(G * H);
+    const double mu = s1 / n;
+    const double var = fmax(s2 / n - mu * mu, 0.0);                // biased variance, like nn.LayerNorm
+    const float rs = (float)(1.0 / sqrt(var + (double)d.eps)), muf = (float)mu;
+    float* out = d.gx2 + (((size_t)par * G + g) * (4 * H)) * Bp;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const size_t row = (size_t)q * H + hu;
+      out[row * Bp + b] = rs * (gate[q] - muf * d.r2[(size_t)g * 4 * H + row]) + d.c2[(size_t)g * 4 * H + row];
+    }
+    return;
+  }
+  float hv = 0.f;
+  if (fin) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) gate[q] += pre[q];
+    const float c = sigm_g(gate[1]) * c_old + sigm_g(gate[0]) * tanhf(gate[2]);
+    hv = sigm_g(gate[3]) * tanhf(c);
+    if (stage == 0) {
+      d.cst1[ci] = c;
+      d.hT1[((size_t)(par ^ 1) * G + g) * hsz + hidx(hu, b, Bp)] = hv;
+      stat[u][bb][0] = hv;                          // stat[] is unused in stages 0 / 2: staging for the partial sums
+    } else {
+      d.cst2[ci] = c;
+      d.hT2[((size_t)(par ^ 1) * G + g) * hsz + hidx(hu, b, Bp)] = hv;
+      if (b < d.B) d.y[(int64_t)b * d.y_sb + (int64_t)t * d.y_st + (int64_t)hu * d.y_su + (int64_t)g * d.y_sg] = hv;
+    }
+  }
+  if (stage != 0) return;
+  __syncthreads();
+  // LayerNorm partial sums over this workgroup's 8 units (the same summation order at every batch size)
+  if (threadIdx.x < 32) {
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float v = stat[k][bb][0];
+      s1 += v;
+      s2 += v * v;
+    }
+    float2* P2 = reinterpret_cast<float2*>(d.part) + (((size_t)par * G + g) * (H / 8) + slice) * Bp + b;
+    *P2 = make_float2(s1, s2);
+  }
+}
+
+int pdse_glstm_launch(const pdse_glstm_desc* d, hipStream_t s) {
+  if (!d || !d->gx1 || !d->whh1 || !d->wih2 || !d->r2 || !d->c2 || !d->whh2 || !d->hT1 || !d->cst1 || !d->hT2 ||
+      !d->cst2 || !d->gx2 || !d->part || !d->y) {
+    pdse_set_error("glstm: null pointer");
+    return 1;
+  }
+  if (d->B <= 0 || d->T <= 0 || d->G != 2 || d->H != 512 || d->Bp % 32 != 0 || d->Bp < d->B || (d->Bp / 32) * 3 > 65535) {
+    pdse_set_error("glstm: bad sizes (H == 512, G == 2 as in gcrn.py:9-16, Bp % 32 == 0, Bp >= B)");
+    return 1;
+  }
+  const dim3 grid(d->H / 8, d->G, 3 * (d->Bp / 32)), block(512);
+  for (int st = 0; st < d->T + 2; ++st) hipLaunchKernelGGL(glstm_wave_kernel, grid, block, 0, s, *d, st);
+  return pdse_check_launch("glstm");
+}

@@ -733,22 +733,27 @@ class EpsNetPlan(PlanBase):
 # ==========================================================================
 class GcrnPlan(PlanBase):
     fused_last = True       # last decoder stage + Linear(161,161) as one persistent launch (pdse_gcrnlast_desc)
+    fused_glstm = True      # both LSTM layers + LayerNorm 1 as a layer wavefront, T + 2 launches (pdse_glstm_desc)
     ENC_C = [2, 16, 32, 64, 128, 256]
     ENC_F = [161, 80, 39, 19, 9, 4]
 
     def __init__(self, ctx, sd, B, T, plan=None):
-        super().__init__(ctx, plan, ns=(id(sd), self.fused_last))
+        super().__init__(ctx, plan, ns=(id(sd), self.fused_last, self.fused_glstm))
         self.sd, self.B, self.T = sd, B, T
         a = ctx.alloc
-        self.Bp = (B + 31) // 32 * 32
+        self.Bp = Bp = (B + 31) // 32 * 32
         self.x = a(B, 2, T, F0)
         self.out = a(B, 2, T, F0)
         self.e = [a(B, self.ENC_C[i + 1], T, self.ENC_F[i + 1]) for i in range(5)]
-        self.gx = a(2, T, 2048, self.Bp, zero=True)
-        self.hT = a(2, 2, 512, self.Bp, zero=True)
-        self.cst = a(2, 512, self.Bp, zero=True)
+        self.gx = a(2, T, 2048, Bp, zero=True)
+        self.hT = a(2, 2, 512, Bp, zero=True)
+        self.cst = a(2, 512, Bp, zero=True)
         self.y = a(B, T, 1024)
-        self.yn = a(B, 1024, T)
+        if self.fused_glstm and not self.force_generic:
+            self.hT2, self.cst2 = a(2, 2, 512, Bp, zero=True), a(2, 512, Bp, zero=True)
+            self.gx2, self.part = a(2, 2, 2048, Bp, zero=True), a(2, 2, 64, Bp, 2, zero=True)
+        else:
+            self.yn = a(B, 1024, T)
         self.glstm = a(B, 256, T, 4)
         self.d = [a(B, 128, T, 9), a(B, 64, T, 19), a(B, 32, T, 39), a(B, 16, T, 80), a(B, 1, T, 161)]
 
@@ -781,6 +786,44 @@ class GcrnPlan(PlanBase):
         d.hT, d.cst, d.y = self.hT.data_ptr(), self.cst.data_ptr(), self.y.data_ptr()
         d.y_sb, d.y_st, d.y_su, d.y_sg = T * 1024, 1024, y_su, y_sg
         d.B, d.Bp, d.T, d.H, d.G = B, Bp, T, 512, 2
+        self.add(d, TAG_LSTM)
+
+    def _glstm_wavefront(self, proj1):
+        """gcrn.py:22-35 as one operator (csrc/lstm.hip, glstm_wave_kernel): layer 1 at frame s, LayerNorm 1 + the
+        layer-2 input projection at frame s-1, layer 2 at frame s-2, T + 2 launches.  Only the layer-1 input projection
+        stays a batched GEMM in front of it."""
+        B, T, Bp = self.B, self.T, self.Bp
+        for g in range(2):
+            p = "glstm.lstm_list1.%d." % g
+            in0, Tin, Fin, taps, wk_fn, Tout, Fout, ost, osf = proj1(g)
+            self.gconv(in0=in0, Tin=Tin, Fin=Fin, taps=taps, sf_in=1, Cout=2048,
+                       W=lambda p=p, wk_fn=wk_fn: dict(wk0=wk_fn(self.w(p + "weight_ih_l0")),
+                                                       bias0=self.w(p + "bias_ih_l0") + self.w(p + "bias_hh_l0")),
+                       out=self.gx, out_strides=(1, Bp, 0, ost, osf), out_off=g * T * 2048 * Bp, B=B, Tout=Tout, Fout=Fout,
+                       tag=TAG_PRIOR, label=p + "ih")
+
+        def pack():
+            up = lambda a: self.ctx.up(a).data_ptr()   # noqa: E731
+            gam, bet = self.w("glstm.ln1.weight"), self.w("glstm.ln1.bias")
+            whh1 = np.stack([P.pack_lstm_slices(self.w("glstm.lstm_list1.%d.weight_hh_l0" % g)) for g in range(2)], 0)
+            whh2 = np.stack([P.pack_lstm_slices(self.w("glstm.lstm_list2.%d.weight_hh_l0" % g)) for g in range(2)], 0)
+            wih2, r2, c2 = [], [], []
+            for g in range(2):
+                p = "glstm.lstm_list2.%d." % g
+                Wih = self.w(p + "weight_ih_l0")                                     # [2048, 512] over chunk g of LN1's output
+                Wf = Wih * gam[512 * g:512 * g + 512][None, :]                       # LayerNorm scale folded in
+                wih2.append(P.pack_lstm_slices(Wf, P.glstm_ih2_korder(g)))
+                r2.append(Wf.sum(1))
+                c2.append(Wih @ bet[512 * g:512 * g + 512] + self.w(p + "bias_ih_l0") + self.w(p + "bias_hh_l0"))
+            return dict(whh1=up(whh1), whh2=up(whh2), wih2=up(np.stack(wih2, 0)), r2=up(np.stack(r2, 0)), c2=up(np.stack(c2, 0)))
+
+        d = L.GlstmDesc()
+        for k, v in self.memo("glstm.wavefront", pack).items():
+            setattr(d, k, v)
+        d.gx1, d.gx2, d.part = self.gx.data_ptr(), self.gx2.data_ptr(), self.part.data_ptr()
+        d.hT1, d.cst1, d.hT2, d.cst2 = self.hT.data_ptr(), self.cst.data_ptr(), self.hT2.data_ptr(), self.cst2.data_ptr()
+        d.y, d.y_sb, d.y_st, d.y_su, d.y_sg = self.y.data_ptr(), T * 1024, 1024, 1, 512     # cat: index g*512 + u
+        d.B, d.Bp, d.T, d.H, d.G, d.eps = B, Bp, T, 512, 2, 1e-5
         self.add(d, TAG_LSTM)
 
     def _ln(self, name, out_t, osb, os_hi, os_lo, os_t, r):
@@ -817,14 +860,17 @@ class GcrnPlan(PlanBase):
             s = self.src(self.e[4], 128, *nchw(256, T, 4), off=128 * g * T * 4)
             return s, T, 4, [(0, f) for f in range(4)], wk, T, 1, 2048 * Bp, 0
 
-        self._lstm_layer("lstm_list1", proj1, y_su=2, y_sg=1)               # stack(dim=-1)+flatten: index u*2+g
-        self._ln("glstm.ln1", self.yn, 1024 * T, T, 0, 1, 1)                 # -> [B,1024,T]
+        if self.fused_glstm and not self.force_generic:
+            self._glstm_wavefront(proj1)
+        else:
+            self._lstm_layer("lstm_list1", proj1, y_su=2, y_sg=1)           # stack(dim=-1)+flatten: index u*2+g
+            self._ln("glstm.ln1", self.yn, 1024 * T, T, 0, 1, 1)             # -> [B,1024,T]
 
-        def proj2(g):
-            s = self.src(self.yn, 512, 1024 * T, T, 0, 1, off=512 * g * T)
-            return s, 1, T, [(0, 0)], (lambda Wih: Wih.T), 1, T, 0, 2048 * Bp
+            def proj2(g):
+                s = self.src(self.yn, 512, 1024 * T, T, 0, 1, off=512 * g * T)
+                return s, 1, T, [(0, 0)], (lambda Wih: Wih.T), 1, T, 0, 2048 * Bp
 
-        self._lstm_layer("lstm_list2", proj2, y_su=1, y_sg=512)              # cat: index g*512+u
+            self._lstm_layer("lstm_list2", proj2, y_su=1, y_sg=512)          # cat: index g*512+u
         self._ln("glstm.ln2", self.glstm, 256 * T * 4, T * 4, 1, 4, 4)       # j = c*4+f -> [B,256,T,4]
 
         # two decoders (gcrn.py:150-164)

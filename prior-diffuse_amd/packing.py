@@ -188,6 +188,39 @@ def istft_kmat(n_fft=320):
 
 
 # ------------------------------------------------------------------------------------------
+# grouped LSTM, layer wavefront (csrc/lstm.hip: glstm_wave_kernel; include/pdse.h: pdse_glstm_desc)
+# ------------------------------------------------------------------------------------------
+def pack_lstm_slices(W, korder=None):
+    """W [4H, K] (gate-major rows i,f,g,o) -> float32 [H/8 slices][K/8 k-groups][64 lanes][4]: slice s holds gate rows
+    q*H + 8s + u as tile row q*8 + u; lane (col, h) of k-group q, entry i = W[row(col), korder[2*(4q+i) + h]]."""
+    W = np.asarray(W, np.float64)
+    H4, K = W.shape
+    H = H4 // 4
+    kk = np.arange(K) if korder is None else np.asarray(korder)
+    col = np.arange(32)
+    rows = (col // 8)[None, :] * H + 8 * np.arange(H // 8)[:, None] + (col % 8)[None, :]          # [S, 32]
+    q, h, i = np.arange(K // 8)[:, None, None], np.arange(2)[None, :, None], np.arange(4)[None, None, :]
+    kidx = kk[2 * (4 * q + i) + h]                                                                  # [Q, 2, 4]
+    out = W[rows[:, None, None, :, None], kidx[None, :, :, None, :]]                                # [S, Q, 2, 32, 4]
+    return np.ascontiguousarray(out.reshape(H // 8, K // 8, 64, 4), np.float32)
+
+
+def glstm_ih2_korder(g, H=512):
+    """K order of stage B (layer-2 input projection) for chunk g of the interleaved layer-1 output: position
+    k' = 2*(4*gq + i) + hh reads source group g' = gq >> 5, unit u = 8*(32g + (gq & 31)) + 2i + hh, which is feature
+    2u + g' of the LayerNorm input; returns the column of W_ih (chunk-local feature index) for every k'."""
+    order = np.empty(H, np.int64)
+    for gq in range(H // 8):
+        gs, kq = gq >> 5, (H // 16) * g + (gq & 31)
+        for i in range(4):
+            for hh in range(2):
+                u = 8 * kq + 2 * i + hh
+                order[2 * (4 * gq + i) + hh] = 2 * u + gs - H * g
+    assert sorted(order.tolist()) == list(range(H))
+    return order
+
+
+# ------------------------------------------------------------------------------------------
 # fused TCM residual block (csrc/tcm.hip, include/pdse.h: pdse_tcm_desc)
 # ------------------------------------------------------------------------------------------
 _RHO = np.array([[(r & 3) + 8 * (r >> 2) + 4 * h for h in (0, 1)] for r in range(16)])

@@ -353,6 +353,59 @@ def run_lstm(d, mem):
             yflat[idx] = h
 
 
+def _unpack_lstm_slices(w, H, K):
+    """[H/8][K/8][64][4] -> [4H, K] in the packed K order (inverse of packing.pack_lstm_slices with korder = identity)."""
+    w = w.reshape(H // 8, K // 8, 2, 32, 4)                  # [s, q, h, col, i]
+    W = np.zeros((4 * H, K), np.float32)
+    col = np.arange(32)
+    for s_ in range(H // 8):
+        rows = (col // 8) * H + 8 * s_ + (col % 8)
+        for q in range(K // 8):
+            for h in range(2):
+                for i in range(4):
+                    W[rows, 2 * (4 * q + i) + h] = w[s_, q, h, :, i]
+    return W
+
+
+def run_glstm(d, mem):
+    """pdse_glstm_desc: both LSTM layers + the folded LayerNorm, from the packed operands, frame by frame."""
+    H, G, T, Bp, B = d.H, d.G, d.T, d.Bp, d.B
+    gx1 = mem.arr(d.gx1, G * T * 4 * H * Bp).reshape(G, T, 4 * H, Bp)
+    n = G * (H // 8) * (H // 8) * 256
+    W1 = [_unpack_lstm_slices(w, H, H) for w in mem.arr(d.whh1, n).reshape(G, -1)]
+    W2 = [_unpack_lstm_slices(w, H, H) for w in mem.arr(d.whh2, n).reshape(G, -1)]
+    Wi = [_unpack_lstm_slices(w, H, H) for w in mem.arr(d.wih2, n).reshape(G, -1)]
+    r2, c2 = mem.arr(d.r2, G * 4 * H).reshape(G, 4 * H), mem.arr(d.c2, G * 4 * H).reshape(G, 4 * H)
+    yflat, yoff = mem.view(d.y)
+
+    def cell(gate, c):
+        i_, f_, g_, o_ = np.split(gate, 4, axis=1)
+        c = _sig(f_) * c + _sig(i_) * np.tanh(g_)
+        return (_sig(o_) * np.tanh(c)).astype(np.float32), c
+
+    h1 = np.zeros((G, B, H), np.float32)
+    c1 = np.zeros((G, B, H), np.float32)
+    h2 = np.zeros((G, B, H), np.float32)
+    c2s = np.zeros((G, B, H), np.float32)
+    for t in range(T):
+        for g in range(G):
+            h1[g], c1[g] = cell(gx1[g, t, :, :B].T + h1[g] @ W1[g].T, c1[g])
+        allh = np.stack([h1[0], h1[1]], -1).reshape(B, -1).astype(np.float64)       # feature 2u + g'
+        mu, var = allh.mean(1), allh.var(1)
+        rs = 1.0 / np.sqrt(var + d.eps)
+        for g in range(G):
+            xk = np.zeros((B, H), np.float32)                                       # B operand in stage B's K order
+            for gq in range(H // 8):
+                gs, kq = gq >> 5, (H // 16) * g + (gq & 31)
+                for i in range(4):
+                    for hh in range(2):
+                        xk[:, 2 * (4 * gq + i) + hh] = h1[gs][:, 8 * kq + 2 * i + hh]
+            gx2 = rs[:, None] * (xk @ Wi[g].T - mu[:, None] * r2[g][None, :]) + c2[g][None, :]
+            h2[g], c2s[g] = cell(gx2.astype(np.float32) + h2[g] @ W2[g].T, c2s[g])
+            idx = (yoff + np.arange(B)[:, None] * d.y_sb + t * d.y_st + np.arange(H)[None, :] * d.y_su + g * d.y_sg)
+            yflat[idx] = h2[g]
+
+
 def run_tcm(d, mem):
     """pdse_tcm_desc: fused TCM residual block + the next block's conv1, from the packed operands."""
     B, T, dil = d.B, d.T, d.dil
@@ -415,7 +468,7 @@ def run_gcrnlast(d, mem):
 
 RUNNERS = {L.GcrnLastDesc: run_gcrnlast, L.TcmDesc: run_tcm, L.GconvDesc: run_gconv, L.TimeDesc: run_time, L.EwDesc: run_ew, L.CompandDesc: run_compand,
            L.WavprepDesc: run_wavprep, L.OlaDesc: run_ola, L.SigmaDesc: run_sigma, L.LnDesc: run_ln,
-           L.LstmDesc: run_lstm}
+           L.LstmDesc: run_lstm, L.GlstmDesc: run_glstm}
 
 
 def run(descs, keep, begin=0, end=None):

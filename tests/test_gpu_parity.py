@@ -91,7 +91,7 @@ def test_error_reporting(L):
     pb = nets.PlanBase(nets.Ctx(DEV), plan=None)
     x, y = torch.randn(1, 4, 2, 40, device=DEV), torch.empty(1, 32, 2, 40, device=DEV)
     bias = torch.zeros(40, device=DEV)
-    d = pb.gconv(in0=pb.src(x, 4, *nets.nchw(4, 2, 40)), Tin=2, Fin=40, taps=[(0, 0)], sf_in=1, wk0=np.ones((4, 32)), Cout=32,
+    d = pb.gconv(in0=pb.src(x, 4, *nets.nchw(4, 2, 40)), Tin=2, Fin=40, taps=[(0, 0)], sf_in=1, W=lambda: dict(wk0=np.ones((4, 32))), Cout=32,
                  bias0=bias, out=y, out_strides=nets.nchw_out(32, 2, 40), B=1, Tout=2, Fout=40)
     L.launch(d)
     _sync()
@@ -462,10 +462,19 @@ def test_full_50_step_schedule_at_t401(L, weights, R):
                                            fast_sampling=False)
     assert pipe.nsteps == 50 and np.array_equal(pipe.schedule[4], np.arange(50, dtype=np.float32))
     spec, init = pipe.sample(feat.to(DEV), x_T.to(DEV))
+    w64 = [{k: v.double() for k, v in weights(a).items()} for a in ("GCRN", "DiffUNet1")]
     with torch.no_grad():
         ref, _ = R.sample("GCRN", weights("GCRN"), weights("DiffUNet1"), feat, x_T, params.noise_schedule,
                           params.inference_noise_schedule, False, False)
-    assert rel_l2(spec.cpu(), ref) < 1e-4
+        exact, _ = R.sample("GCRN", w64[0], w64[1], feat.double(), x_T.double(), params.noise_schedule,
+                            params.inference_noise_schedule, False, False)
+    e_ref, e_exact, e_ref_exact = rel_l2(spec.cpu(), ref), rel_l2(spec.cpu(), exact), rel_l2(ref, exact)
+    print("50 steps, T=401: HIP vs fp32 CPU oracle %.2e | HIP vs float64 evaluation %.2e | fp32 CPU oracle vs float64 "
+          "evaluation %.2e" % (e_ref, e_exact, e_ref_exact))
+    # 50 steps amplify rounding noise: the fp32 CPU path itself sits ~4e-5 from the exact-arithmetic answer, so two
+    # correct fp32 implementations may differ by about the sum of their distances to it
+    assert e_exact < 1e-4
+    assert e_ref < 1e-4 + e_ref_exact
 
 
 def test_long_utterance_t1001(L, weights, R):

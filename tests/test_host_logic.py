@@ -58,8 +58,12 @@ def test_eps_net_plan_vs_oracle(weights, chained, monkeypatch):
     assert rel_l2(net.out, ref) < TOL
 
 
-def test_gcrn_and_diffunet_prior_plans_vs_oracle(weights):
+@pytest.mark.parametrize("fused_glstm", [True, False])
+def test_gcrn_and_diffunet_prior_plans_vs_oracle(weights, fused_glstm, monkeypatch):
+    """fused_glstm: both LSTM layers + LayerNorm 1 as one layer-wavefront operator (LayerNorm folded into the layer-2
+    input projection, permuted K order); False: two per-frame LSTM operators with the LayerNorm and projections between."""
     nets = pkg("nets")
+    monkeypatch.setattr(nets.GcrnPlan, "fused_glstm", fused_glstm)
     B, T = 2, 10
     x = seeded((B, 2, T, 161), 5)
     ctx = nets.Ctx("cpu")
