@@ -9,6 +9,7 @@
 // transposed [H][Bp] (ping-pong) so the B operand is a coalesced 128-B row per k.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "pdse.h"
 #include "pdse_internal.h"
@@ -124,7 +125,7 @@ __device__ __forceinline__ size_t hidx(const int u, const int b, const int Bp) {
   return (((size_t)(u >> 3) * 2 + (u & 1)) * Bp + b) * 4 + ((u & 7) >> 1);
 }
 
-__global__ __launch_bounds__(512) void glstm_wave_kernel(const pdse_glstm_desc d, const int s) {
+__global__ __launch_bounds__(512) void glstm_wave_kernel(const pdse_glstm_desc d, const int s, const int stage_mask) {
   __shared__ float red[8][32][33];
   __shared__ float stat[16][32][2];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(512) void glstm_wave_kernel(const pdse_glstm_desc d
   const int nbt = d.Bp >> 5;
   const int stage = blockIdx.z / nbt, bt = blockIdx.z - stage * nbt;
   const int t = s - stage;
-  if (t < 0 || t >= d.T) return;
+  if (t < 0 || t >= d.T || !((stage_mask >> stage) & 1)) return;
   const int H = d.H, Bp = d.Bp, G = d.G;
   const size_t hsz = (size_t)H * Bp;               // one group's state
   const int par = t & 1;
@@ -297,6 +298,8 @@ int pdse_glstm_launch(const pdse_glstm_desc* d, hipStream_t s) {
     return 1;
   }
   const dim3 grid(d->H / 8, d->G, 3 * (d->Bp / 32)), block(512);
-  for (int st = 0; st < d->T + 2; ++st) hipLaunchKernelGGL(glstm_wave_kernel, grid, block, 0, s, *d, st);
+  // PDSE_GLSTM_MASK (diagnostic, tools/time_glstm.py): run only some stages to time them apart - results are then wrong
+  static const int mask = getenv("PDSE_GLSTM_MASK") ? atoi(getenv("PDSE_GLSTM_MASK")) : 7;
+  for (int st = 0; st < d->T + 2; ++st) hipLaunchKernelGGL(glstm_wave_kernel, grid, block, 0, s, *d, st, mask);
   return pdse_check_launch("glstm");
 }
