@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 # algorithmic work per utterance: flops of one eps-net forward at T=401
 EPS_GFLOP_PER_UTT_STEP = 10.29
 FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md, fp32 matrix = fp32 vector peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0         # MI355X_MICROARCH.md, dense bf16 MFMA
 
 
 def _free_port():
@@ -83,6 +84,9 @@ def main():
     ap.add_argument("--streams", type=int, default=1, help="concurrent sub-batch pipelines per GPU")
     ap.add_argument("--full-schedule", action="store_true",
                     help="BASELINE config 3: the full 50-step reverse schedule instead of 6-step fast sampling")
+    ap.add_argument("--split-bf16", action="store_true",
+                    help="eps-net BIGLU blocks on the bf16 matrix cores with exact three-way bf16 operand splits "
+                         "(fp32-level accuracy, parity-tested at the fp32 tolerances); dtype reads bf16x3")
     ap.add_argument("--dry-run", action="store_true",
                     help="rehearse the launch / rendezvous / timing-reduction / reporting path on CPU (gloo, no GPU, no "
                          "kernels): the JSON line carries \"dry_run\": true and value null")
@@ -145,13 +149,13 @@ def main():
     use_graph = not args.no_graph
     if args.overlap:
         runner = pipeline.PipelinedSampler(dev, args.prior, gs, ds, B, L_, depth=args.depth, by_batch=args.by_batch,
-                                           graph=use_graph, fast_sampling=fast)
+                                           graph=use_graph, fast_sampling=fast, split_bf16=args.split_bf16)
         pipe = runner.pipes[0]
     elif args.streams > 1:
-        runner = pipeline.ConcurrentSampler(dev, args.prior, gs, ds, B, L_=L_, nsplit=args.streams, fast_sampling=fast)
+        runner = pipeline.ConcurrentSampler(dev, args.prior, gs, ds, B, L_=L_, nsplit=args.streams, fast_sampling=fast, split_bf16=args.split_bf16)
         pipe = runner.pipes[0]
     else:
-        runner = pipe = pipeline.SamplerPipeline(dev, args.prior, gs, ds, B, L_=L_, fast_sampling=fast)
+        runner = pipe = pipeline.SamplerPipeline(dev, args.prior, gs, ds, B, L_=L_, fast_sampling=fast, split_bf16=args.split_bf16)
 
     def step():
         if args.overlap:
@@ -201,7 +205,7 @@ def main():
         bank = pipe.bank
         del runner
         torch.cuda.empty_cache()
-        pipe = pipeline.SamplerPipeline(dev, args.prior, gs, ds, B, L_=L_, fast_sampling=fast, bank=bank)
+        pipe = pipeline.SamplerPipeline(dev, args.prior, gs, ds, B, L_=L_, fast_sampling=fast, bank=bank, split_bf16=args.split_bf16)
     pipe.stft.wav.copy_(wav)
     pipe.xT_in.copy_(x_T)
     torch.cuda.synchronize()
@@ -233,9 +237,15 @@ def main():
     if os.path.exists(tpath) and B == 32 and T == 401 and fast and args.prior == "GCRN":
         pj = json.load(open(tpath))["eps_net_one_pass"]
         traffic = round((pj["fetch_size_bytes_x2"] + pj["write_size_bytes"]) / pj["launches"])
-    roofline = {"bound": "mfma", "kernel": "gconv2_kernel + tcm_block_kernel (eps-net: BiConvGLU/BiConvTransGLU/TCM launches)",
-                "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+    # split-bf16 mode: an fp32-equivalent FMA costs six bf16 MFMA products, so the roof of the algorithmic FLOP rate is the
+    # dense bf16 peak / 6 (2.5 PF / 6); the TCM blocks inside the family still run on the fp32 matrix cores
+    peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if args.split_bf16 else FP32_MFMA_PEAK_TFLOPS
+    roofline = {"bound": "mfma", "kernel": ("gconv3_kernel (split-bf16 BIGLU blocks) + tcm_block_kernel" if args.split_bf16 else
+                                            "gconv2_kernel + tcm_block_kernel") + " (eps-net: BiConvGLU/BiConvTransGLU/TCM launches)",
+                "achieved": round(achieved, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
+                "peak_note": ("dense bf16 MFMA 2500 TFLOP/s / 6 products per fp32-equivalent multiply-add" if args.split_bf16
+                              else "fp32 MFMA (v_mfma_f32_32x32x2_f32)"),
+                "frac": round(achieved / peak, 4), "traffic": traffic,
                 "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/%s)" % os.path.basename(tpath),
                 "algorithmic_flop_per_launch": round(eps_flop / n_eps_launch),
                 "avg_launch_ms": round(eps_ms / max(1, sum(per_tag[k]["launches"] for k in ("eps_block", "eps_conv1", "tcm"))), 5),
@@ -266,9 +276,10 @@ def main():
     top_tf = gconv_flops(top_d) / (top_ms * 1e-3) / 1e12
     roofline["largest_launch"] = {
         "kernel": "gconv2_kernel BIGLU%s, %d taps, %d -> 32 -> %d channels, %d x %d x %d positions" % (
-            " dual-phase" if top_d.w2 else "", top_d.ntaps, top_d.in0.C, top_d.C2, top_d.B, top_d.Tout, top_d.Fout),
+            " dual-phase" if top_d.w2 else "", top_d.ntaps, top_d.in0.C, top_d.C2, top_d.B, top_d.Tout, top_d.Fout)
+                  .replace("gconv2_kernel", "gconv3_kernel" if top_d.korder == 2 else "gconv2_kernel"),
         "ms": round(top_ms, 4), "algorithmic_gflop": round(gconv_flops(top_d) / 1e9, 2),
-        "achieved": round(top_tf, 2), "frac": round(top_tf / FP32_MFMA_PEAK_TFLOPS, 4)}
+        "achieved": round(top_tf, 2), "frac": round(top_tf / peak, 4)}
 
     cpu = None
     if not args.no_cpu_baseline:
@@ -300,7 +311,9 @@ def main():
         "ms_per_step": round(ms_per_step, 3), "ms_per_step_sequential": round(ms_sequential, 3),
         "value_sequential": round(B * args.seconds / (ms_sequential * 1e-3), 2),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "bf16x3" if args.split_bf16 else "f32", "data": "synthetic",
+        "dtype_note": ("eps-net blocks: fp32 operands split exactly into three bf16 terms, six-product bf16 MFMA, fp32 accumulate "
+                       "(fp32-level accuracy, same parity tolerances); everything else fp32") if args.split_bf16 else "fp32 throughout",
         "frames_per_s_per_gpu": round(args.steps * B * T / elapsed, 1),
         "config": {"workload": "B=%d x %.0f s 16 kHz utterances per GPU, [B,2,%d,161] spectrograms, %s prior + "
                                "DiffUNet1 %d-step sampling, STFT..ISTFT, seeded random weights" % (B, args.seconds, T, args.prior, pipe.nsteps),

@@ -107,7 +107,14 @@ typedef struct pdse_gconv_desc {
   int32_t out_cr; /* co -> (co / out_cr)*out_sc_hi + (co % out_cr)*out_sc_lo */
   int32_t B, Tout, Fout;
   /* K order of the packed weights: 0: k = tap*Cin + ci (generic kernel); 1: k-step =
-     (ci/2)*ntaps + tap, k = 2*kstep + (ci&1) (pipelined kernel: taps innermost, unrolled) */
+     (ci/2)*ntaps + tap, k = 2*kstep + (ci&1) (pipelined kernel: taps innermost, unrolled);
+     2: split-bf16 BIGLU blocks (csrc/gconv3.hip; Cin = 32, Cout = 32, C2 in {64, 1}): every weight is stored as its
+     exact three-way bf16 split (packing.split_bf16x3) in v_mfma_f32_32x32x16_bf16 A-fragment order -
+       w0..w3  [ntaps*2 blocks][3 planes][64 lanes][8 bf16]: block tap*2 + q, lane (row, h), element j =
+               W[k = tap*32 + 16q + 8h + j][row]
+       wlc, wrc [2][3][64][8]; wc2 [2 tiles][2][3][64][8] (C2 == 64; C2 == 1: the fp32 vector [32] as before);
+       nx_w [nx_n][4][3][64][8]: chained tiles, k order of an accumulator tile used as B operand
+               (packing.rho_bf16).  Activations, biases, BatchNorm and every output stay fp32. */
   int32_t korder;
   /* Dual-phase stride-(1,2) ConvTranspose2d (BIGLU only, korder 1): one launch computes the even
      output bins f_o = 2j (weights w0/w1 over all ntaps taps) AND the odd bins 2j+1 (weights w2/w3

@@ -181,7 +181,7 @@ int pdse_gconv_launch(const pdse_gconv_desc* d, hipStream_t s) {
   PDSE_REQUIRE(d->resid == nullptr || d->act == PDSE_ACT_NONE, "a residual input excludes an activation (x + f(..) is the last op)");
   if (d->nx_n != 0) {
     PDSE_REQUIRE(d->nx_n > 0 && d->nx_n <= 3 && d->nx_w, "nx: 1..3 chained tiles and their weights");
-    PDSE_REQUIRE(d->epi == PDSE_EPI_BIGLU && d->korder == 1 && d->C2 == 64 && d->out_cr == 1,
+    PDSE_REQUIRE(d->epi == PDSE_EPI_BIGLU && (d->korder == 1 || d->korder == 2) && d->C2 == 64 && d->out_cr == 1,
                  "nx: chained 1x1 tiles need the pipelined BIGLU kernel with a 64-channel block output");
     for (int i = 0; i < d->nx_n; ++i) PDSE_REQUIRE(d->nx_bias[i] && d->nx_out[i], "nx: bias / output pointer missing");
     PDSE_REQUIRE(d->nx_row0 < d->nx_n, "nx_row0 out of range");
@@ -195,6 +195,11 @@ int pdse_gconv_launch(const pdse_gconv_desc* d, hipStream_t s) {
   if (d->korder == 1) {
     PDSE_REQUIRE(!d->cin1, "korder 1 needs Cin >= 2");
     return pdse_gconv2_launch(d, s);
+  }
+  if (d->korder == 2) {   // split-bf16 BIGLU blocks (gconv3.hip)
+    PDSE_REQUIRE(d->resid == nullptr, "BIGLU has no residual input");
+    PDSE_REQUIRE(d->act == PDSE_ACT_NONE || d->act == PDSE_ACT_PRELU, "BIGLU stages end in PReLU or no activation");
+    return pdse_gconv3_launch(d, s);
   }
   PDSE_REQUIRE(d->korder == 0, "unknown korder");
   const int mtiles = (d->Cout + 31) / 32;

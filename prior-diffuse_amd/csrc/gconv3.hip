@@ -1,0 +1,209 @@
+// gconv3.hip — the BiConvGLU / BiConvTransGLU blocks of the eps-net on the bf16 matrix cores with EXACT three-way
+// bf16 operand splits (korder 2): same descriptors, same fp32 [B,C,T,F] tensors in HBM and the same epilogues as
+// gconv2.hip; only the arithmetic of the contractions changes.
+//
+// Why: the fp32 MFMA (v_mfma_f32_32x32x2_f32) runs at 1/16 of the bf16 rate, and these blocks are bound by it
+// (profiles/r01_*: 0.53-0.68 of the fp32 matrix peak).  An fp32 number is the exact sum of three bf16 numbers
+// (3 x 8 significand bits, split by truncation: packing.split_bf16x3 / split8()), so a product a b is the sum of nine
+// bf16 x bf16 products, each exact in fp32.  The six leading ones (a1b1, a1b2, a2b1, a1b3, a3b1, a2b2) are issued as
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation; the three dropped ones are below 2^-23 |a b|, i.e. about one fp32
+// rounding of the product.  Six bf16 MFMAs (32 cycles each, K = 16) replace eight fp32 MFMAs (64 cycles each, K = 2):
+// 2.67x fewer matrix-pipe cycles at fp32-level accuracy (tests: the same goldens and tolerances as the fp32 path).
+//
+// Structure (Cin = 32, Cout = 32 per gated branch - every eps-net block but the composed encoder stage 1):
+//   * a workgroup of 8 waves shares ONE LDS image of all weight fragments of the launch (gather weights of both
+//     branches and both output phases, the chained 1x1 tails, biases, folded BatchNorm): 108-134 KB, filled once with
+//     16-byte copies; fragments reach the matrix cores through ds_read_b128 (the fp32 kernel re-reads its A fragments
+//     from L1/L2 in every wave: at 1.5x the bytes per weight that path would bound this kernel);
+//   * K order (tap, channel): lane (position, half h) gathers channels 16q + 8h .. +7 of its position for tap `tap` -
+//     eight 4-byte loads per (tap, q), the same number of vector-memory instructions per K as the fp32 kernel - splits
+//     them in registers (~6 VALU operations per value) and feeds 12 MFMAs (L and R branch);
+//   * taps are software-pipelined: the loads of tap t+1 are in flight while tap t is split and multiplied;
+//   * the BIGLU tail, the chained next-stage 1x1 tiles and the stores are gconv_common.h's, instantiated on the
+//     split-bf16 tail image (accumulator tiles are re-split in registers and used as B operands, k order rho_bf16).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pdse.h"
+#include "pdse_internal.h"
+
+#include "gconv_common.h"
+
+constexpr int popc3(int m) { return m ? (m & 1) + popc3(m >> 1) : 0; }
+constexpr int rank3(int m, int tap) { return popc3(m & ((1 << tap) - 1)); }
+
+#define S3_THREADS 512
+#define S3_FLOATS 640   // float operands behind the fragment areas (see image layout in the kernel)
+
+// fragment counts (blocks of 3 planes x 64 lanes, 192 uint4 = 3 KB each)
+__host__ __device__ constexpr int s3_blocks(int nt, int p1mask, int c2, int nx_n) {
+  return 2 * (2 * nt) + 2 * (2 * popc3(p1mask)) + 2 + 2 + (c2 == 1 ? 0 : 4) + 4 * nx_n;
+}
+
+template <int NT, int P1MASK, bool NX>
+__global__ __launch_bounds__(S3_THREADS, 2) void gconv3_kernel(const pdse_gconv_desc d) {
+  constexpr int NB = 2 * NT, NT1 = popc3(P1MASK), NB1 = 2 * NT1;
+  extern __shared__ uint4 img[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, h = lane >> 5;
+  const int b = blockIdx.y;
+  const int P = d.Tout * d.Fout;
+  const int p = (blockIdx.x * 8 + wave) * 32 + col;
+  const bool pvalid = p < P;
+  const int t = pvalid ? p / d.Fout : 0;
+  const int j = pvalid ? p - t * d.Fout : 0;
+
+  // ---- LDS image: [gL NB][gR NB][gL1 NB1][gR1 NB1][lc 2][rc 2][c2 4 | 0][nx 4 nx_n] blocks, then the float operands
+  const int c2b = d.C2 == 1 ? 0 : 4;
+  const int o_gR = NB * 192, o_gL1 = 2 * NB * 192, o_gR1 = o_gL1 + NB1 * 192, o_lc = o_gR1 + NB1 * 192;
+  const int o_rc = o_lc + 384, o_c2 = o_rc + 384, o_nx = o_c2 + c2b * 192, o_f = o_nx + d.nx_n * 768;
+  {
+    auto copy = [&](const float* src, const int dst, const int n) {   // n uint4 entries
+      const uint4* s4 = reinterpret_cast<const uint4*>(src);
+      for (int i = tid; i < n; i += S3_THREADS) img[dst + i] = s4[i];
+    };
+    copy(d.w0, 0, NB * 192);
+    copy(d.w1, o_gR, NB * 192);
+    if constexpr (P1MASK != 0) {
+      copy(d.w2, o_gL1, NB1 * 192);
+      copy(d.w3, o_gR1, NB1 * 192);
+    }
+    copy(d.wlc, o_lc, 384);
+    copy(d.wrc, o_rc, 384);
+    if (c2b) copy(d.wc2, o_c2, 768);
+    if (d.nx_n > 0) copy(d.nx_w, o_nx, d.nx_n * 768);
+    float* f = reinterpret_cast<float*>(img + o_f);
+    // floats: bl 0, br 32, bl0 64, br0 96, blc 128, brc 160, bc2 192 (64), ps 256 (64), pt 320 (64), nxb 384 (96), wc2v 480 (32)
+    if (tid < 32) {
+      const float bl = d.bias0[(int64_t)b * d.bias0_sb + tid], br = d.bias1[(int64_t)b * d.bias1_sb + tid];
+      f[tid] = bl;
+      f[32 + tid] = br;
+      f[64 + tid] = d.bias0_t0 ? d.bias0_t0[(int64_t)b * d.bias0_sb + tid] : bl;
+      f[96 + tid] = d.bias1_t0 ? d.bias1_t0[(int64_t)b * d.bias1_sb + tid] : br;
+      f[128 + tid] = d.blc[tid];
+      f[160 + tid] = d.brc[tid];
+      if (d.C2 == 1) f[480 + tid] = d.wc2[tid];
+    }
+    if (tid >= 64 && tid < 64 + d.C2) {
+      const int c = tid - 64;
+      f[192 + c] = d.bc2[c];
+      f[256 + c] = d.post_scale ? d.post_scale[c] : 1.0f;
+      f[320 + c] = d.post_scale ? d.post_shift[c] : 0.0f;
+    }
+    if (tid >= 128 && tid < 128 + 32 * d.nx_n) {
+      const int i = (tid - 128) >> 5, c = (tid - 128) & 31;
+      f[384 + 32 * i + c] = d.nx_bias[i][(int64_t)b * d.nx_bias_sb[i] + c];
+    }
+  }
+
+  // ---- per-tap gather state
+  int off[NT];
+  unsigned inb_mask = 0;
+#pragma unroll
+  for (int tap = 0; tap < NT; ++tap) {
+    const int dt = d.taps[2 * tap], df = d.taps[2 * tap + 1];
+    const int tin = t + dt, fin = j * d.sf_in + df;
+    const bool inb = pvalid && fin >= 0 && fin < d.Fin && tin >= 0 && tin < d.Tin;
+    if (inb) inb_mask |= 1u << tap;
+    off[tap] = inb ? (int)((int64_t)b * d.in0.sb + (int64_t)tin * d.in0.st + (int64_t)fin * d.in0.sf) : 0;
+  }
+  const int sc = (int)d.in0.sc;
+  const float* sp = d.in0.ptr + (int64_t)(8 * h) * sc;   // this lane half's first channel of every 16-channel block
+
+  f32x16 aL, aR, aL1, aR1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) aL[r] = aR[r] = aL1[r] = aR1[r] = 0.f;
+
+  float raw[2][16];   // [ping-pong][q * 8 + j]: channels 16q + 8h + j of one tap
+  auto issue = [&](float (&v)[16], const int tap) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[q * 8 + e] = sp[off[tap] + (16 * q + e) * sc];
+  };
+  issue(raw[0], 0);
+  __syncthreads();   // the image is complete (its copies were issued ahead of the first activation loads)
+
+#pragma unroll
+  for (int tap = 0; tap < NT; ++tap) {
+    if (tap + 1 < NT) issue(raw[(tap + 1) & 1], tap + 1);
+    const bool inb = (inb_mask >> tap) & 1u;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      float x[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = inb ? raw[tap & 1][q * 8 + e] : 0.f;
+      uint4 b1, b2, b3;
+      split8(x, b1, b2, b3);
+      const int blk = (tap * 2 + q) * 192 + lane;
+      aL = mfma6(img + blk, b1, b2, b3, aL);
+      aR = mfma6(img + o_gR + blk, b1, b2, b3, aR);
+      if constexpr (P1MASK != 0) {
+        if ((P1MASK >> tap) & 1) {   // folds after unrolling
+          const int blk1 = (rank3(P1MASK, tap) * 2 + q) * 192 + lane;
+          aL1 = mfma6(img + o_gL1 + blk1, b1, b2, b3, aL1);
+          aR1 = mfma6(img + o_gR1 + blk1, b1, b2, b3, aR1);
+        }
+      }
+    }
+  }
+
+  const float* f = reinterpret_cast<const float*>(img + o_f);
+  const pdse_tail_s3 tl{img + o_lc, img + o_rc, img + o_c2, img + o_nx, f + 480, f, f + 32, f + 128, f + 160,
+                        f + 192, f + 256, f + 320, f + 384, f + 64, f + 96};
+  if constexpr (P1MASK != 0)
+    biglu_dual_epilogue<NX>(d, tl, aL, aR, aL1, aR1, b, t, j, pvalid, lane, h);
+  else
+    biglu_nx_epilogue(d, tl, aL, aR, b, t, j, pvalid, lane, h);
+}
+
+template <int NT, int P1MASK, bool NX>
+static int launch3(const pdse_gconv_desc* d, hipStream_t s) {
+  const int P = d->Tout * d->Fout;
+  const dim3 grid(((P + 31) / 32 + 7) / 8, d->B, 1), block(S3_THREADS);
+  const size_t lds = (size_t)s3_blocks(NT, P1MASK, d->C2, d->nx_n) * 192 * sizeof(uint4) + S3_FLOATS * sizeof(float);
+  if (lds > 160 * 1024) {
+    pdse_set_error("gconv3: LDS image too large");
+    return 1;
+  }
+  const void* fn = (const void*)gconv3_kernel<NT, P1MASK, NX>;
+  static bool attr_done = false;   // per instantiation
+  if (!attr_done) {
+    if (pdse_check_hip(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "gconv3 lds attribute")) return 1;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((gconv3_kernel<NT, P1MASK, NX>), grid, block, lds, s, *d);
+  return pdse_check_launch("gconv3");
+}
+
+// korder 2: BIGLU, one source of 32 channels, 32 + 32 output channels, C2 in {64, 1}; validated by pdse_gconv_launch
+int pdse_gconv3_launch(const pdse_gconv_desc* d, hipStream_t s) {
+  const long long span0 = (long long)d->B * d->in0.sb;
+  if (d->epi != PDSE_EPI_BIGLU || d->in1.C != 0 || d->in0.C != 32 || d->Cout != 32 || d->xf_mode != 0 || d->out_cr != 1 ||
+      !(d->C2 == 64 || d->C2 == 1) || d->padrow != nullptr || d->cin1 || span0 >= (1ll << 31) || d->in0.sc * 40 >= (1ll << 31)) {
+    pdse_set_error("gconv3: split-bf16 kernels cover BIGLU blocks with one 32-channel source, C2 in {64, 1}, out_cr 1");
+    return 1;
+  }
+  if (!d->bias0 || !d->bias1 || !d->w1 || !d->wlc || !d->wrc || !d->blc || !d->brc || !d->wc2 || !d->bc2) {
+    pdse_set_error("gconv3: null operand");
+    return 1;
+  }
+  if (d->w2 != nullptr) {
+    if (d->w3 == nullptr || (d->out_sf & 1) || d->nx_n > 1 || (d->nx_n == 1 && d->C2 != 64)) {
+      pdse_set_error("gconv3: dual phase needs w2 and w3, an even out_sf, at most one chained tile");
+      return 1;
+    }
+    if (d->ntaps == 4 && d->p1mask == 5) return d->nx_n ? launch3<4, 5, true>(d, s) : launch3<4, 5, false>(d, s);
+    if (d->ntaps == 6 && d->p1mask == 27 && d->nx_n == 0) return launch3<6, 27, false>(d, s);
+  } else {
+    if (d->C2 != 64 || d->nx_n > 3) {
+      pdse_set_error("gconv3: single phase needs C2 == 64 and at most three chained tiles");
+      return 1;
+    }
+    if (d->ntaps == 6) return launch3<6, 0, false>(d, s);
+    if (d->ntaps == 4) return launch3<4, 0, false>(d, s);
+  }
+  pdse_set_error("gconv3: no split-bf16 instantiation for this (taps, phases)");
+  return 1;
+}

@@ -97,6 +97,86 @@ __device__ __forceinline__ pdse_tail tail_from_desc(const pdse_gconv_desc& d) {
                    d.bias0, d.bias1};
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Split-bf16 operands (csrc/gconv3.hip, packing.split_bf16x3): an fp32 value is the exact sum of three bf16 numbers
+// (8 + 8 + 8 significand bits, by truncation), and a product is evaluated as its six leading cross terms on the bf16
+// matrix cores with fp32 accumulation.  Fragments are 8 bf16 per lane (one uint4) per plane.
+// ---------------------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ f32x16 mfma_bf16(const uint4& a, const uint4& b, const f32x16 c) {
+  union { uint4 u; bf16x8 v; } A, B;
+  A.u = a;
+  B.u = b;
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.v, B.v, c, 0, 0, 0);
+}
+
+// x[0..7] -> three planes of 8 bf16 (element j in the low / high half of dword j >> 1), x == p1 + p2 + p3 exactly
+__device__ __forceinline__ void split8(const float (&x)[8], uint4& p1, uint4& p2, uint4& p3) {
+  uint32_t q1[4], q2[4], q3[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float a = x[2 * i], b = x[2 * i + 1];
+    const uint32_t a1 = __float_as_uint(a) & 0xffff0000u, b1 = __float_as_uint(b) & 0xffff0000u;
+    const float ra = a - __uint_as_float(a1), rb = b - __uint_as_float(b1);
+    const uint32_t a2 = __float_as_uint(ra) & 0xffff0000u, b2 = __float_as_uint(rb) & 0xffff0000u;
+    const float sa = ra - __uint_as_float(a2), sb = rb - __uint_as_float(b2);
+    q1[i] = (a1 >> 16) | b1;
+    q2[i] = (a2 >> 16) | b2;
+    q3[i] = (__float_as_uint(sa) >> 16) | (__float_as_uint(sb) & 0xffff0000u);
+  }
+  p1 = make_uint4(q1[0], q1[1], q1[2], q1[3]);
+  p2 = make_uint4(q2[0], q2[1], q2[2], q2[3]);
+  p3 = make_uint4(q3[0], q3[1], q3[2], q3[3]);
+}
+
+// acc += A B with A given as three fragment planes at w[0], w[64], w[128] (uint4 units, this lane's entry) and B as
+// the three planes of an exact split: smallest terms first
+__device__ __forceinline__ f32x16 mfma6(const uint4* w, const uint4& b1, const uint4& b2, const uint4& b3, f32x16 acc) {
+  const uint4 a1 = w[0], a2 = w[64], a3 = w[128];
+  acc = mfma_bf16(a1, b3, acc);
+  acc = mfma_bf16(a3, b1, acc);
+  acc = mfma_bf16(a2, b2, acc);
+  acc = mfma_bf16(a1, b2, acc);
+  acc = mfma_bf16(a2, b1, acc);
+  acc = mfma_bf16(a1, b1, acc);
+  return acc;
+}
+
+// Y = W X for a 32-channel accumulator tile X used as the B operand (two k-blocks of 8 registers each);
+// w: LDS fragments [2 blocks][3 planes][64 lanes] of this output tile, already offset by the lane
+__device__ __forceinline__ f32x16 chain_s3(const uint4* w, const f32x16& X, f32x16 acc) {
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = X[8 * s + j];
+    uint4 b1, b2, b3;
+    split8(x, b1, b2, b3);
+    acc = mfma6(w + s * 192, b1, b2, b3, acc);
+  }
+  return acc;
+}
+
+// LDS image of the split-bf16 BIGLU tail (gconv3.hip fills it): fragment areas in uint4 units, then the float operands
+struct pdse_tail_s3 {
+  const uint4* wlc;   // [2][3][64]
+  const uint4* wrc;
+  const uint4* wc2;   // [2 tiles][2][3][64]   (C2 == 64)
+  const uint4* nxw;   // [nx_n][4][3][64]
+  const float* wc2v;  // [32]                   (C2 == 1)
+  const float* bl;
+  const float* br;
+  const float* blc;
+  const float* brc;
+  const float* bc2;
+  const float* ps;
+  const float* pt;
+  const float* nxb;
+  const float* bl0;
+  const float* br0;
+};
+
 template <int EPI, int MT, bool CR1>
 __device__ __forceinline__ void gconv_epilogue_impl(const pdse_gconv_desc& d, const pdse_tail& tl, f32x16* acc0,
                                                     f32x16* acc1, const int b, const int t, const int j,
@@ -335,14 +415,74 @@ __device__ __forceinline__ f32x16 nx_tile(const pdse_tail& tl, const int i, cons
   return Z;
 }
 
+// ---- the same tail on split-bf16 operands (overloads selected by the tail image type)
+template <typename Sink>
+__device__ __forceinline__ void biglu_tail_values(const pdse_gconv_desc& d, const pdse_tail_s3& tl, const f32x16& accL,
+                                                  const f32x16& accR, const int lane, const int h, Sink&& sink,
+                                                  const bool frame0 = false) {
+  f32x16 L = accL, R = accR;
+  const float slope = d.act == PDSE_ACT_PRELU ? d.act_slope : 1.0f;
+  L += ld16((frame0 ? tl.bl0 : tl.bl) + 4 * h);
+  R += ld16((frame0 ? tl.br0 : tl.br) + 4 * h);
+  f32x16 mL = ld16(tl.blc + 4 * h), mR = ld16(tl.brc + 4 * h);    // the biases seed the accumulators
+  mL = chain_s3(tl.wlc + lane, L, mL);
+  mR = chain_s3(tl.wrc + lane, R, mR);
+  f32x16 G;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) G[r] = L[r] * sigmoid_f(mR[r]) + R[r] * sigmoid_f(mL[r]);
+  if (d.C2 == 1) {
+    const f32x16 vw = ld16(tl.wc2v + 4 * h);
+    float part = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part += vw[r] * G[r];
+    float v = part + __shfl_xor(part, 32) + tl.bc2[0];
+    v = v * tl.ps[0] + tl.pt[0];
+    sink(0, 0, v > 0.f ? v : slope * v);
+  } else {
+#pragma unroll
+    for (int m2 = 0; m2 < 2; ++m2) {
+      const int c0 = 32 * m2 + 4 * h;
+      f32x16 O = ld16(tl.bc2 + c0);
+      O = chain_s3(tl.wc2 + m2 * 384 + lane, G, O);
+      const f32x16 vs = ld16(tl.ps + c0), vt = ld16(tl.pt + c0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = O[r] * vs[r] + vt[r];
+        sink(m2, r, v > 0.f ? v : slope * v);
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ f32x16 nx_tile_acc(const pdse_tail_s3& tl, const int i, const float (&Y)[2][16], const int lane,
+                                              f32x16 Z) {
+  const uint4* w = tl.nxw + (size_t)i * 768 + lane;
+#pragma unroll
+  for (int m2 = 0; m2 < 2; ++m2) {
+    f32x16 X;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) X[r] = Y[m2][r];
+    Z = chain_s3(w + m2 * 384, X, Z);
+  }
+  return Z;
+}
+
+__device__ __forceinline__ f32x16 nx_tile(const pdse_tail_s3& tl, const int i, const float (&Y)[2][16], const int lane) {
+  f32x16 Z;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) Z[r] = 0.f;
+  return nx_tile_acc(tl, i, Y, lane, Z);
+}
+
 // Single-phase BIGLU tail with chained next-stage 1x1 convolutions (pdse.h: nx_*); out_cr == 1, C2 == 64.
-__device__ __forceinline__ void biglu_nx_epilogue(const pdse_gconv_desc& d, const pdse_tail& tl, const f32x16& a0,
+template <typename TL>
+__device__ __forceinline__ void biglu_nx_epilogue(const pdse_gconv_desc& d, const TL& tl, const f32x16& a0,
                                                   const f32x16& a1, const int b, const int t, const int j,
                                                   const bool pvalid, const int lane, const int h) {
   float Y[2][16];
   float* const obase = d.out + ((int64_t)b * d.out_sb + (int64_t)t * d.out_st + (int64_t)j * d.out_sf + d.out_off);
   const int64_t cstep = d.out_sc_hi;
-  const bool keep = d.nx_keep != 0 && pvalid;
+  const bool keep = (d.nx_keep != 0 || d.nx_n == 0) && pvalid;   // no chained tile: the block output itself is the result
   biglu_tail_values(d, tl, a0, a1, lane, h, [&](const int m2, const int r, const float v) {
     Y[m2][r] = v;
     if (keep) obase[(int64_t)(32 * m2 + 4 * h) * cstep + (int64_t)PDSE_KR(r) * cstep] = v;
@@ -384,8 +524,8 @@ __device__ __forceinline__ void store_pair(float* p, const float a, const float 
 
 // Dual-phase epilogue (out_cr == 1, C2 == 64 or 1): even bin at obase, odd bin one bin stride later.
 // NX: the launch chains the next stage's conv1 (its own register budget: a separate instantiation).
-template <bool NX>
-__device__ __forceinline__ void biglu_dual_epilogue(const pdse_gconv_desc& d, const pdse_tail& tl, const f32x16& a0,
+template <bool NX, typename TL>
+__device__ __forceinline__ void biglu_dual_epilogue(const pdse_gconv_desc& d, const TL& tl, const f32x16& a0,
                                                     const f32x16& a1, const f32x16& a2, const f32x16& a3, const int b,
                                                     const int t, const int j, const bool pvalid, const int lane,
                                                     const int h) {

@@ -115,6 +115,32 @@ class PlanBase:
     def src(self, t, C_, sb, sc, st, sf, off=0, act=L.ACT_NONE):
         return L.Src(Ctx.ptr(t, off), sb, sc, st, sf, C_, act)
 
+    def _gconv_weights_s3(self, w, ntaps):
+        """korder 2 (csrc/gconv3.hip): exact three-way bf16 splits of a BIGLU block's weights, MFMA bf16 fragment order."""
+        ctx = self.ctx
+        up = lambda a: ctx.up(a).data_ptr()   # noqa: E731
+        up16 = lambda a: ctx.up(np.ascontiguousarray(a).view(np.int16), np.int16).data_ptr()   # noqa: E731
+        f = {"korder": 2, "ksteps": ntaps * 16}
+        f["w0"], f["w1"] = up16(P.pack_s3_gather(w["wk0"], ntaps)), up16(P.pack_s3_gather(w["wk1"], ntaps))
+        if w.get("wk2") is not None:
+            f["w2"], f["w3"] = up16(P.pack_s3_gather(w["wk2"], w["ntaps1"])), up16(P.pack_s3_gather(w["wk3"], w["ntaps1"]))
+            f["ksteps1"] = w["ntaps1"] * 16
+        f["bias0"], f["bias1"] = up(w["bias0"]), up(w["bias1"])
+        if w.get("post") is not None:
+            f["post_scale"], f["post_shift"] = up(w["post"][0]), up(w["post"][1])
+        chain = w["chain"]
+        f["C2"] = chain["C2"]
+        f["wlc"], f["wrc"] = up16(P.pack_s3_chain(chain["wlc"])), up16(P.pack_s3_chain(chain["wrc"]))
+        f["blc"], f["brc"], f["bc2"] = up(chain["blc"]), up(chain["brc"]), up(chain["bc2"])
+        f["wc2"] = up(np.asarray(chain["wc2"], np.float64).reshape(32)) if chain["C2"] == 1 else up16(P.pack_s3_chain(chain["wc2"]))
+        nx = w.get("nx")
+        if nx:
+            for i, tl in enumerate(nx):
+                if tl.get("bias") is not None:
+                    f[("nx_bias", i)] = up(tl["bias"])
+            f["nx_w"] = up16(np.stack([P.pack_s3_chain(tl["w"])[0] for tl in nx], 0))
+        return f
+
     def _gconv_weights(self, w, ntaps, c0, c1, epi, cin1, pipelined_ok):
         """Pack and upload the weight side of one gather-GEMM launch; returns {descriptor field: value}.
         w: dict with wk0 [K, Cout] (k-major float64), optional wk1, wk2/wk3 (odd phase), bias0/bias1, post (scale, shift),
@@ -173,7 +199,7 @@ class PlanBase:
               bias1=None, bias1_sb=0, epi=L.EPI_LINEAR, act=L.ACT_NONE, act_slope=0.0,
               padrow=None, padrow_sb=0, padrow_off=0, cin1=False, resid=None, out,
               out_strides, out_off=0, out_cr=1, B, Tout, Fout, tag=TAG_NONE, bias0_off=0, phase1=None, nx=None,
-              bias1_off=0, bias_t0=None, label="gconv"):
+              bias1_off=0, bias_t0=None, label="gconv", s3=False):
         """W: callable -> dict of the launch's weight-derived operands (see ``_gconv_weights``); evaluated only when the
         weight bank does not hold this launch yet.  bias0 / bias1 / padrow / bias_t0 here are per-plan DEVICE tensors
         (time-conditioned biases); constant biases travel inside W.
@@ -198,8 +224,12 @@ class PlanBase:
         d.cin1 = 1 if cin1 else 0
         c0, c1 = d.in0.C, d.in1.C
         pipelined_ok = padrow is None and not self.force_generic
-        site = "%s:%d:%d:%d:%d:%d:%d" % (label, epi, len(ttaps), c0, c1, Cout, pipelined_ok)
-        f = self.memo(site, lambda: self._gconv_weights(W(), len(ttaps), c0, c1, epi, cin1, pipelined_ok))
+        s3 = bool(s3) and pipelined_ok and epi == L.EPI_BIGLU and c0 == 32 and c1 == 0
+        site = "%s:%d:%d:%d:%d:%d:%d:%d" % (label, epi, len(ttaps), c0, c1, Cout, pipelined_ok, s3)
+        if s3:
+            f = self.memo(site, lambda: self._gconv_weights_s3(W(), len(ttaps)))
+        else:
+            f = self.memo(site, lambda: self._gconv_weights(W(), len(ttaps), c0, c1, epi, cin1, pipelined_ok))
         for k, v in f.items():
             if isinstance(k, tuple):
                 d.nx_bias[k[1]] = v
@@ -214,7 +244,7 @@ class PlanBase:
         if bias_t0 is not None:                               # (tensor, offset of bias0_t0, offset of bias1_t0)
             d.bias0_t0, d.bias1_t0 = Ctx.ptr(bias_t0[0], bias_t0[1]), Ctx.ptr(bias_t0[0], bias_t0[2])
         d.epi, d.act, d.act_slope = epi, act, float(act_slope)
-        if phase1 is not None and d.korder == 1:
+        if phase1 is not None and d.korder in (1, 2):
             d.p1mask, d.Fout1 = phase1["mask"], phase1["Fout1"]
         if nx is not None:
             tiles = nx["tiles"]
@@ -260,13 +290,17 @@ class EpsNetPlan(PlanBase):
     fused_tcm = True        # one launch per TCM residual block (csrc/tcm.hip); False: three gather-GEMM launches
     chain_conv1 = True      # every stage's 1x1 input convolution rides on the previous stage's tail (pdse.h: nx_*)
     compose_stage1 = True   # (with chain_conv1) encoder stage 1: conv1 composed into the gather weights
+    split_bf16 = False      # BIGLU blocks on the bf16 matrix cores with exact 3-way operand splits (csrc/gconv3.hip)
     NSLOT = 20  # 15 stages + en1 real-row bias + 4 composed encoder-stage-1 biases (l/r x frame >= 1 / frame 0)
 
-    def __init__(self, ctx, sd, B, T, time_cond=True, nsteps=1, plan=None, table=None, with_pre=None):
-        """with_pre False + time_cond True: ``Nocon`` (model/piror_grad.py), DiffUNet1 without Preprocess."""
+    def __init__(self, ctx, sd, B, T, time_cond=True, nsteps=1, plan=None, table=None, with_pre=None, split_bf16=None):
+        """with_pre False + time_cond True: ``Nocon`` (model/piror_grad.py), DiffUNet1 without Preprocess.
+        split_bf16: run the BIGLU blocks on the bf16 matrix cores with exact 3-way operand splits (None: class default)."""
         with_pre = time_cond if with_pre is None else with_pre
+        if split_bf16 is not None:
+            self.split_bf16 = bool(split_bf16)
         super().__init__(ctx, plan, ns=(id(sd), bool(time_cond), bool(with_pre), self.fused_tcm, self.chain_conv1,
-                                        self.compose_stage1, None if table is None else id(table)))
+                                        self.compose_stage1, self.split_bf16, None if table is None else id(table)))
         self.sd, self.B, self.T, self.time_cond, self.nsteps = sd, B, T, time_cond, nsteps
         self.with_pre = with_pre
         a = ctx.alloc
@@ -471,7 +505,8 @@ class EpsNetPlan(PlanBase):
 
         self.gconv(in0=self.src(H, 32, *nchw(32, HT, Fin)), Tin=HT, Fin=Fin, taps=taps, sf_in=2, W=W,
                    Cout=32, epi=L.EPI_BIGLU, act=L.ACT_PRELU, act_slope=self._slope("en.en%d.1.weight" % k),
-                   out=out_t, out_strides=out_strides, B=B, Tout=T, Fout=Fout, tag=TAG_EPS_BLOCK, nx=nx, label="en%d" % k)
+                   out=out_t, out_strides=out_strides, B=B, Tout=T, Fout=Fout, tag=TAG_EPS_BLOCK, nx=nx, label="en%d" % k,
+                   s3=self.split_bf16)
         return Fout
 
     def _biconvtransglu(self, step, slot, p, k, in0, in1, Fin, out_t, out_strides_fn, bn_prefix, prelu_key, out_off=0,
@@ -523,7 +558,8 @@ class EpsNetPlan(PlanBase):
             # activation loads are shared and every wave stores neighbouring (2j, 2j+1) bins together
             mask = sum(1 << taps0.index(tp) for tp in taps1)
             self.gconv(in0=src_h, Tin=T, Fin=Fin, taps=taps0, sf_in=1, W=Wph(kk0, True, nx), out_off=out_off,
-                       Fout=(Fout + 1) // 2, phase1=dict(mask=mask, Fout1=Fout // 2), nx=nx, label=p, **common)
+                       Fout=(Fout + 1) // 2, phase1=dict(mask=mask, Fout1=Fout // 2), nx=nx, label=p,
+                       s3=self.split_bf16, **common)
         else:
             for phase, (kk, taps) in enumerate(((kk0, taps0), (kk1, taps1))):
                 self.gconv(in0=src_h, Tin=T, Fin=Fin, taps=taps, sf_in=1, W=Wph(kk, False, None),

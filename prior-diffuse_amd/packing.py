@@ -255,3 +255,83 @@ def pack_tcm_next(w1):
                         cin = 64 * w + 32 * q + rows
                         out[w, q, :, g, h, :, e] = w1[:, cin].reshape(2, 32)
     return out.reshape(4, 2, 2, 4, 64, 4)
+
+
+# ------------------------------------------------------------------------------------------
+# split-bf16 operands (csrc/gconv3.hip): every fp32 value is the EXACT sum of three bf16 numbers
+#   x = b1 + b2 + b3,   b1 = trunc16(x), b2 = trunc16(x - b1), b3 = x - b1 - b2
+# (24 significand bits = 3 x 8), so a product a*b = sum_ij a_i b_j; the kernels evaluate the six leading terms
+# (a1b1, a1b2, a2b1, a1b3, a3b1, a2b2) on the bf16 matrix cores with fp32 accumulation - what is dropped is below
+# 2^-23 of the product, i.e. fp32-level accuracy at 16/6 of the fp32 MFMA rate.
+# ------------------------------------------------------------------------------------------
+def split_bf16x3(w):
+    """float array -> (b1, b2, b3) uint16 arrays (the bf16 bit patterns), w == b1 + b2 + b3 exactly in fp32."""
+    w = np.ascontiguousarray(w, np.float32)
+    m = np.uint32(0xFFFF0000)
+    u1 = w.view(np.uint32) & m
+    r1 = w - u1.view(np.float32)
+    u2 = r1.view(np.uint32) & m
+    r2 = r1 - u2.view(np.float32)
+    u3 = r2.view(np.uint32) & m
+    assert np.array_equal(u1.view(np.float32) + u2.view(np.float32) + u3.view(np.float32), w) or not np.all(np.isfinite(w))
+    return tuple((u >> np.uint32(16)).astype(np.uint16) for u in (u1, u2, u3))
+
+
+def join_bf16x3(planes):
+    """Inverse of split_bf16x3 on uint16 planes [..., 3 stacked first]."""
+    f = [(np.asarray(p, np.uint16).astype(np.uint32) << np.uint32(16)).view(np.float32) for p in planes]
+    return f[0] + f[1] + f[2]
+
+
+def rho_bf16(s, j, h):
+    """Accumulator row held by element j of k-block s on lane half h when a 32x32 f32 accumulator tile is used as the
+    B operand of v_mfma_f32_32x32x16_bf16 (registers 8s..8s+7): row of register r = (r & 3) + 8 (r >> 2) + 4 h."""
+    r = 8 * s + j
+    return (r & 3) + 8 * (r >> 2) + 4 * h
+
+
+def pack_s3_gather(wk, ntaps, cin=32):
+    """wk [ntaps*cin, 32] (k = tap*cin + c, k-major) -> uint16 [ntaps*cin/16 blocks][3 planes][64 lanes][8]:
+    block tap*(cin/16) + q, lane (row = lane & 31, h = lane >> 5), element j = wk[tap*cin + 16q + 8h + j][row]."""
+    wk = np.asarray(wk, np.float64).astype(np.float32)
+    assert wk.shape == (ntaps * cin, 32) and cin % 16 == 0
+    nb = ntaps * cin // 16
+    k = (16 * np.arange(nb)[:, None, None] + 8 * np.arange(2)[None, :, None] + np.arange(8)[None, None, :])   # [nb, h, j]
+    frag = wk[k][:, :, :, :].transpose(0, 1, 3, 2)                      # [nb, h, row, j]
+    frag = frag.reshape(nb, 64, 8)
+    p = split_bf16x3(frag)
+    return np.ascontiguousarray(np.stack(p, 1))                          # [nb, 3, 64, 8]
+
+
+def unpack_s3_gather(packed, ntaps, cin=32):
+    packed = np.asarray(packed, np.uint16).reshape(ntaps * cin // 16, 3, 2, 32, 8)     # [nb, plane, h, row, j]
+    f = join_bf16x3([packed[:, i] for i in range(3)])                                  # [nb, h, row, j]
+    return f.transpose(0, 1, 3, 2).reshape(ntaps * cin, 32)                             # k = 16 nb + 8h + j
+
+
+def pack_s3_chain(w):
+    """w [Mout, Kin] (out x in; Kin = 32 or 64 accumulator channels) -> uint16 [mtiles][Kin/16 blocks][3][64][8]:
+    block s, lane (row, h), element j = w[32 mt + row][32 (s >> 1) + rho_bf16(s & 1, j, h)]."""
+    w = np.asarray(w, np.float64).astype(np.float32)
+    M, K = w.shape
+    assert K % 32 == 0
+    mt = (M + 31) // 32
+    pad = np.zeros((mt * 32, K), np.float32)
+    pad[:M] = w
+    s_, h_, j_ = np.meshgrid(np.arange(K // 16), np.arange(2), np.arange(8), indexing="ij")
+    kk = 32 * (s_ >> 1) + ((8 * (s_ & 1) + j_) & 3) + 8 * ((8 * (s_ & 1) + j_) >> 2) + 4 * h_    # [nb, h, j]
+    frag = pad.reshape(mt, 32, K)[:, :, kk]                               # [mt, row, nb, h, j]
+    frag = frag.transpose(0, 2, 3, 1, 4).reshape(mt, K // 16, 64, 8)      # lane = h*32 + row
+    p = split_bf16x3(frag)
+    return np.ascontiguousarray(np.stack(p, 2))                           # [mt, nb, 3, 64, 8]
+
+
+def unpack_s3_chain(packed, mt, K):
+    packed = np.asarray(packed, np.uint16).reshape(mt, K // 16, 3, 2, 32, 8)   # [mt, nb, plane, h, row, j]
+    f = join_bf16x3([packed[:, :, i] for i in range(3)])                      # [mt, nb, h, row, j]
+    out = np.zeros((mt * 32, K), np.float32)
+    for s in range(K // 16):
+        for h in range(2):
+            for j in range(8):
+                out[:, 32 * (s >> 1) + rho_bf16(s & 1, j, h)] = f[:, s, h, :, j].reshape(-1)
+    return out

@@ -31,13 +31,16 @@ def _expect(t, like, name):
 
 class SamplerPipeline:
     def __init__(self, device, prior_name, prior_sd, ddpm_sd, B, T=None, L_=None, fast_sampling=True,
-                 use_sigma=False, params=default_params, with_signal=None, deltamu=False, cond="init", bank=None):
+                 use_sigma=False, params=default_params, with_signal=None, deltamu=False, cond="init", bank=None,
+                 split_bf16=None):
         """deltamu: the alternative parameterisation of utils/params.py:36 — ddpm_sd is a ``Nocon`` state_dict,
         x_T = noise + X_init/11 (:947-948), eps = Nocon(x, t) (:970-971), no final ``+ X_init`` (:995).
         cond (deltamu False): what conditions DiffUNet1 — "init": X_init/11 (pirorgrad, :967-969, + X_init at the end,
         :994-995); "feat": the noisy feature / 11 (the branch with neither flag set, :74-75, :972-974; no final add).
         bank: a ``nets.WeightBank`` shared with other pipelines built from the same state_dicts (packed weights are
-        uploaded once, every further (B, T) only records descriptors)."""
+        uploaded once, every further (B, T) only records descriptors).
+        split_bf16: the eps-net's (and a DiffUNet prior's) BIGLU blocks on the bf16 matrix cores with exact three-way
+        operand splits - fp32-level accuracy at 16/6 of the fp32 MFMA rate (csrc/gconv3.hip); None: the plan default."""
         if L_ is not None:
             T = 1 + L_ // 160
         if with_signal is None:
@@ -66,7 +69,7 @@ class SamplerPipeline:
         if prior_name == "GCRN":
             self.prior = adopt(nets.GcrnPlan(ctx, prior_sd, B, T, plan=self.plan))
         elif prior_name == "DiffUNet":
-            self.prior = adopt(nets.EpsNetPlan(ctx, prior_sd, B, T, time_cond=False, plan=self.plan))
+            self.prior = adopt(nets.EpsNetPlan(ctx, prior_sd, B, T, time_cond=False, plan=self.plan, split_bf16=split_bf16))
         elif prior_name == "aia_complex_trans_ri":
             self.prior = adopt(nets.AiaPlan(ctx, prior_sd, B, T, plan=self.plan))
         elif prior_name == "dual_aia_trans_merge_crm":
@@ -74,7 +77,8 @@ class SamplerPipeline:
         else:
             raise ValueError("prior %r not built (GCRN, DiffUNet, aia_complex_trans_ri, dual_aia_trans_merge_crm)" % prior_name)
         self.eps = adopt(nets.EpsNetPlan(ctx, ddpm_sd, B, T, time_cond=True, nsteps=S, plan=self.plan,
-                                         with_pre=not deltamu))
+                                         with_pre=not deltamu, split_bf16=split_bf16))
+        self.split_bf16 = self.eps.split_bf16
         self.deltamu = deltamu
         self.cond_feat = cond_feat = (cond == "feat") and not deltamu
         self.istft = adopt(nets.IstftPlan(ctx, B, T, L_, plan=self.plan)) if with_signal else None

@@ -36,7 +36,7 @@ class Mem:
             if lo <= ptr < hi:
                 flat = t.view(-1).numpy()
                 assert flat.dtype == dtype, (flat.dtype, dtype)
-                return flat, (ptr - lo) // 4
+                return flat, (ptr - lo) // t.element_size()
         raise KeyError("pointer %x not inside any known tensor" % ptr)
 
     def arr(self, ptr, n, dtype=np.float32):
@@ -89,6 +89,11 @@ def run_gconv(d, mem):
             out[rows[rows >= 0]] = wk[rows >= 0]
             assert np.all(wk[rows < 0] == 0)
             return out
+    elif d.korder == 2:   # split-bf16 BIGLU block (csrc/gconv3.hip): exact 3-way bf16 splits in bf16 MFMA fragment order
+        assert d.epi == L.EPI_BIGLU and Cin == 32 and d.Cout == 32
+
+        def unpack(ptr):
+            return P.unpack_s3_gather(mem.arr(ptr, d.ntaps * 2 * 3 * 64 * 8, np.int16).view(np.uint16), d.ntaps)
     else:
         def unpack(ptr):
             return _unpack_a(mem.arr(ptr, mtiles * d.ksteps * 64), mtiles, d.ksteps)
@@ -97,14 +102,18 @@ def run_gconv(d, mem):
     ph1 = None
     if d.w2:    # dual-phase transposed conv: odd output bins from the taps in p1mask
         sel = [i for i in range(d.ntaps) if (d.p1mask >> i) & 1]
-        rows1 = P.korder1_rows(len(sel), d.in0.C, 0, P.V2_CP[(d.epi, d.ntaps, False, d.xf_mode)])
-        assert len(rows1) == 2 * d.ksteps1
+        if d.korder == 2:
+            def unpack1(ptr):
+                return P.unpack_s3_gather(mem.arr(ptr, len(sel) * 2 * 3 * 64 * 8, np.int16).view(np.uint16), len(sel))
+        else:
+            rows1 = P.korder1_rows(len(sel), d.in0.C, 0, P.V2_CP[(d.epi, d.ntaps, False, d.xf_mode)])
+            assert len(rows1) == 2 * d.ksteps1
 
-        def unpack1(ptr):
-            wk = P.unpack_a4(mem.arr(ptr, d.ksteps1 * 64), 1, d.ksteps1)
-            out = np.zeros((len(sel) * Cin, 32), np.float32)
-            out[rows1[rows1 >= 0]] = wk[rows1 >= 0]
-            return out
+            def unpack1(ptr):
+                wk = P.unpack_a4(mem.arr(ptr, d.ksteps1 * 64), 1, d.ksteps1)
+                out = np.zeros((len(sel) * Cin, 32), np.float32)
+                out[rows1[rows1 >= 0]] = wk[rows1 >= 0]
+                return out
         ph1 = (sel, unpack1(d.w2), unpack1(d.w3), np.zeros((B, 32, To, Fo), np.float32), np.zeros((B, 32, To, Fo), np.float32))
     bI = np.arange(B)[:, None, None, None]
     tI = np.arange(To)[None, None, :, None]
@@ -190,8 +199,13 @@ def run_gconv(d, mem):
             if d.bias0_t0:                                                                   # output frame 0 has its own biases
                 Lh[:, :, 0] = (aL[:, :32] + bias(d.bias0_t0, d.bias0_sb, 32))[:, :, 0]
                 Rh[:, :, 0] = (aR[:, :32] + bias(d.bias1_t0, d.bias1_sb, 32))[:, :, 0]
-            Wlc = _unpack_chain(mem.arr(d.wlc, 16 * 64), 1)
-            Wrc = _unpack_chain(mem.arr(d.wrc, 16 * 64), 1)
+            def chain_w(ptr, mt, K=32):
+                if d.korder == 2:
+                    return P.unpack_s3_chain(mem.arr(ptr, mt * (K // 16) * 3 * 64 * 8, np.int16).view(np.uint16), mt, K)
+                assert K == 32
+                return _unpack_chain(mem.arr(ptr, mt * 16 * 64), mt)
+
+            Wlc, Wrc = chain_w(d.wlc, 1), chain_w(d.wrc, 1)
             mL = _sig(np.einsum("oc,bctf->botf", Wlc, Lh) + mem.arr(d.blc, 32)[None, :, None, None])
             mR = _sig(np.einsum("oc,bctf->botf", Wrc, Rh) + mem.arr(d.brc, 32)[None, :, None, None])
             G = Lh * mR + Rh * mL
@@ -199,7 +213,7 @@ def run_gconv(d, mem):
                 y = np.einsum("c,bctf->btf", mem.arr(d.wc2, 32), G)[:, None] + mem.arr(d.bc2, 1)[0]
             else:
                 t2 = (d.C2 + 31) // 32
-                Wc2 = _unpack_chain(mem.arr(d.wc2, t2 * 16 * 64), t2)[:d.C2]
+                Wc2 = chain_w(d.wc2, t2)[:d.C2]
                 y = np.einsum("oc,bctf->botf", Wc2, G) + mem.arr(d.bc2, d.C2)[None, :, None, None]
             y = post(y.astype(np.float32), d.C2)
             if d.nx_n == 0 or d.nx_keep:
@@ -210,8 +224,12 @@ def run_gconv(d, mem):
                 out_flat[idx[..., :jmax]] = y[..., :jmax]
             # chained next-stage 1x1 tiles (pdse.h: nx_*)
             for i in range(d.nx_n):
-                Wn = np.concatenate([_unpack_chain(mem.arr(d.nx_w, 6 * 1024)[(2 * i + m2) * 1024:(2 * i + m2 + 1) * 1024], 1)
-                                     for m2 in (0, 1)], axis=1)                    # [32 out, 64 in]
+                if d.korder == 2:
+                    n16 = 4 * 3 * 64 * 8
+                    Wn = P.unpack_s3_chain(mem.arr(d.nx_w, d.nx_n * n16, np.int16).view(np.uint16)[i * n16:(i + 1) * n16], 1, 64)
+                else:
+                    Wn = np.concatenate([_unpack_chain(mem.arr(d.nx_w, 6 * 1024)[(2 * i + m2) * 1024:(2 * i + m2 + 1) * 1024], 1)
+                                         for m2 in (0, 1)], axis=1)                    # [32 out, 64 in]
                 bflat, boff = mem.view(d.nx_bias[i])
                 bz = bflat[boff + np.arange(B)[:, None] * d.nx_bias_sb[i] + np.arange(32)[None, :]][:, :, None, None]
                 z = (np.einsum("oc,bctf->botf", Wn, y) + bz).astype(np.float32)

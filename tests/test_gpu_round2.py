@@ -344,3 +344,81 @@ def test_aia_prior_long_sequence_t1001(L, weights, R):
     ref_att = torch.softmax(q @ k.transpose(-1, -2), dim=-1) @ v                                        # q is pre-scaled
     ref_att = ref_att.permute(0, 2, 4, 3, 1).reshape(B, E, T, F_)
     assert rel_l2(out.cpu(), ref_att.cpu()) < 2e-6
+
+
+# ------------------------------------------------------------------ split-bf16 BIGLU blocks (csrc/gconv3.hip)
+def test_split_bf16_networks_vs_goldens(L, weights, monkeypatch):
+    """The eps-net with its BIGLU blocks on the bf16 matrix cores (exact three-way operand splits, six products, fp32
+    accumulate) against the SAME golden vectors and tolerances as the fp32 path: small T with the TCM input as an
+    intermediate, integer steps, T = 401 rows, the DiffUNet prior; and its distance to the fp32 kernels."""
+    nets, ops = pkg("nets"), pkg("ops")
+    g = golden("diffunet1_small")
+    B, T = int(g["B"]), int(g["T"])
+    x = seeded((B, 2, T, 161), g["seed_x"])
+    xi = seeded((B, 2, T, 161), g["seed_init"]) * float(g["init_scale"])
+    t = torch.from_numpy(g["t"]).to(DEV)
+    out32 = ops.DiffUNet1Op(weights("DiffUNet1"), DEV)(x.to(DEV), xi.to(DEV), t)
+    monkeypatch.setattr(nets.EpsNetPlan, "split_bf16", True)
+    op = ops.DiffUNet1Op(weights("DiffUNet1"), DEV)
+    out = op(x.to(DEV), xi.to(DEV), t)
+    net = op._plans[(B, T)]
+    torch.cuda.synchronize()
+    assert sum(1 for d, _ in net.descs if isinstance(d, L.GconvDesc) and d.korder == 2) == 14
+    assert rel_l2(net.en[4].cpu().permute(0, 1, 3, 2), g["en5"]) < 2e-5
+    print("split-bf16 vs golden %.2e | fp32 kernels vs golden %.2e | split vs fp32 kernels %.2e" % (
+        rel_l2(out.cpu(), g["out"]), rel_l2(out32.cpu(), g["out"]), rel_l2(out.cpu(), out32.cpu())))
+    assert rel_l2(out.cpu(), g["out"]) < 2e-5
+    assert rel_l2(out.cpu(), out32.cpu()) < 5e-6
+    gi = golden("diffunet1_int_t")
+    assert rel_l2(op(x.to(DEV), xi.to(DEV), torch.from_numpy(gi["t"]).to(DEV)).cpu(), gi["out"]) < 2e-5
+    g4 = golden("diffunet1_t401")
+    x4 = seeded((1, 2, 401, 161), g4["seed_x"])
+    xi4 = seeded((1, 2, 401, 161), g4["seed_init"]) * 0.3
+    out4 = op(x4.to(DEV), xi4.to(DEV), torch.tensor([float(g4["t"])], device=DEV)).cpu()
+    assert rel_l2(out4[0, :, ::16, :], g4["rows"]) < 2e-5
+    gp = golden("diffunet_prior_small")
+    outp = ops.DiffUNetOp(weights("DiffUNet"), DEV)(seeded(tuple(gp["out"].shape), gp["seed_x"]).to(DEV))
+    assert rel_l2(outp.cpu(), gp["out"]) < 2e-5
+
+
+@pytest.mark.parametrize("tag,fast", [("gcrn_fast", True), ("gcrn_full", False)])
+def test_split_bf16_sampling_vs_goldens(L, weights, tag, fast):
+    """6-step trace and 50-step result of the reference's loop (goldens) with the split-bf16 eps-net: <= 1e-4."""
+    g = golden("sample_" + tag)
+    feat, x_T = seeded((2, 2, 16, 161), g["seed_feat"]), seeded((2, 2, 16, 161), g["seed_xT"])
+    pipe = pkg("pipeline").SamplerPipeline(DEV, "GCRN", weights("GCRN"), weights("DiffUNet1"), 2, T=16, fast_sampling=fast,
+                                           split_bf16=True)
+    assert pipe.split_bf16
+    spec, init = pipe.sample(feat.to(DEV), x_T.to(DEV))
+    e = rel_l2(spec.cpu(), g["out"])
+    print("split-bf16 sampling %s: rel-L2 vs golden %.2e" % (tag, e))
+    assert e < 1e-4
+
+
+def test_split_bf16_full_size_b32(L, weights, R):
+    """B=32, T=401, 6 steps with the split-bf16 eps-net: batch invariance bit for bit, utterance 0 vs the fp32 CPU
+    oracle and vs the float64 evaluation <= 1e-4; and the 50-step schedule at T=401 (B=1) against the float64
+    evaluation, printed beside the fp32 kernels' distance."""
+    params = pkg("params").params
+    B, T = 32, 401
+    feat, x_T = pkg("synth").synthetic_spectrogram(B, T, seed=1234)
+    P = pkg("pipeline").SamplerPipeline
+    big = P(DEV, "GCRN", weights("GCRN"), weights("DiffUNet1"), B, T=T, split_bf16=True)
+    spec, init = big.sample(feat.to(DEV), x_T.to(DEV))
+    bank = big.bank
+    del big
+    one = P(DEV, "GCRN", weights("GCRN"), weights("DiffUNet1"), 1, T=T, split_bf16=True, bank=bank)
+    for b in (0, 17, 31):
+        s1, _ = one.sample(feat[b:b + 1].to(DEV), x_T[b:b + 1].to(DEV))
+        assert torch.equal(s1[0], spec[b]), b
+    e_ref, e_exact, e_ref_exact = _errors_vs_fp32_and_exact(R, weights, feat[:1], x_T[:1], spec[:1].cpu(), fast=True)
+    print("split-bf16, 6 steps, B=32: vs fp32 CPU oracle %.2e | vs float64 evaluation %.2e | fp32 CPU oracle vs float64 %.2e"
+          % (e_ref, e_exact, e_ref_exact))
+    assert e_ref < 1e-4 and e_exact < 1e-4
+    feat1, x_T1 = pkg("synth").synthetic_spectrogram(1, T, seed=77)
+    full = P(DEV, "GCRN", weights("GCRN"), weights("DiffUNet1"), 1, T=T, fast_sampling=False, split_bf16=True, bank=bank)
+    s50, _ = full.sample(feat1.to(DEV), x_T1.to(DEV))
+    e_ref, e_exact, e_ref_exact = _errors_vs_fp32_and_exact(R, weights, feat1, x_T1, s50.cpu(), fast=False)
+    print("split-bf16, 50 steps, T=401: vs fp32 CPU oracle %.2e | vs float64 evaluation %.2e | fp32 CPU oracle vs float64 %.2e"
+          % (e_ref, e_exact, e_ref_exact))
+    assert e_exact < 1e-4 and e_ref < 1e-4 + e_ref_exact

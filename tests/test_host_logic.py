@@ -28,12 +28,14 @@ def test_pack_roundtrip():
     assert sorted(P.RHO.reshape(-1).tolist()) == list(range(32))
 
 
-@pytest.mark.parametrize("chained", [True, False])
-def test_eps_net_plan_vs_oracle(weights, chained, monkeypatch):
+@pytest.mark.parametrize("chained,split", [(True, False), (False, False), (True, True)])
+def test_eps_net_plan_vs_oracle(weights, chained, split, monkeypatch):
     """chained: every stage's conv1 rides on the previous stage's tail and the encoder/decoder block outputs are never
-    stored (only en[4], the TCM input, is); unchained: the per-stage launches with all intermediates in memory."""
+    stored (only en[4], the TCM input, is); unchained: the per-stage launches with all intermediates in memory.
+    split: the BIGLU blocks' weights as exact three-way bf16 splits in bf16 MFMA fragment order (korder 2)."""
     nets = pkg("nets")
     monkeypatch.setattr(nets.EpsNetPlan, "chain_conv1", chained)
+    monkeypatch.setattr(nets.EpsNetPlan, "split_bf16", split)
     B, T = 2, 12
     sd = weights("DiffUNet1")
     ctx = nets.Ctx("cpu")
@@ -42,6 +44,8 @@ def test_eps_net_plan_vs_oracle(weights, chained, monkeypatch):
     net.build_step(0)
     n_conv1 = sum(1 for _, tag in net.descs if tag == nets.TAG_EPS_CONV1)
     assert n_conv1 == (2 if chained else 16)          # chained: only decoder stage 5 x 2 (encoder stage 1 is composed)
+    n_split = sum(1 for d, _ in net.descs if isinstance(d, pkg("_lib").GconvDesc) and d.korder == 2)
+    assert n_split == (14 if split else 0)            # encoder stages 2-5 + 2 x 5 decoder stages
     x, xi = seeded((B, 2, T, 161), 3), seeded((B, 2, T, 161), 4) * 0.3
     t = torch.tensor([4.086654, 22.992493])
     net.x.copy_(x)
