@@ -275,9 +275,8 @@ def main():
     top_d = pipe.descs[top_i][0]
     top_tf = gconv_flops(top_d) / (top_ms * 1e-3) / 1e12
     roofline["largest_launch"] = {
-        "kernel": "gconv2_kernel BIGLU%s, %d taps, %d -> 32 -> %d channels, %d x %d x %d positions" % (
-            " dual-phase" if top_d.w2 else "", top_d.ntaps, top_d.in0.C, top_d.C2, top_d.B, top_d.Tout, top_d.Fout)
-                  .replace("gconv2_kernel", "gconv3_kernel" if top_d.korder == 2 else "gconv2_kernel"),
+        "kernel": ("gconv3_kernel" if top_d.korder == 2 else "gconv2_kernel") + " BIGLU%s, %d taps, %d -> 32 -> %d channels, %d x %d x %d positions" % (
+            " dual-phase" if top_d.w2 else "", top_d.ntaps, top_d.in0.C, top_d.C2, top_d.B, top_d.Tout, top_d.Fout),
         "ms": round(top_ms, 4), "algorithmic_gflop": round(gconv_flops(top_d) / 1e9, 2),
         "achieved": round(top_tf, 2), "frac": round(top_tf / peak, 4)}
 

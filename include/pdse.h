@@ -148,6 +148,9 @@ typedef struct pdse_gconv_desc {
      pad bias, through the kt = 0 taps. */
   const float* bias0_t0;
   const float* bias1_t0;
+  /* host copy of the first 12 entries of `taps` (korder 1 / 2 kernels, ntaps <= 10): read from the kernel arguments,
+     i.e. from scalar registers - the device table costs every workgroup one dependent L2 round trip per tap */
+  int32_t tap_dt[12], tap_df[12];
 } pdse_gconv_desc;
 
 /* Diffusion-step embedding + every per-stage time bias folded through the following 1x1

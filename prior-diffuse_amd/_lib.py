@@ -50,6 +50,7 @@ class GconvDesc(C.Structure):
         ("nx_sb", _i64 * 3), ("nx_sc", _i64 * 3), ("nx_st", _i64 * 3), ("nx_sf", _i64 * 3), ("nx_off", _i64 * 3),
         ("nx_n", _i32), ("nx_keep", _i32), ("nx_row0", _i32), ("nx_pad_", _i32),
         ("bias0_t0", _fp), ("bias1_t0", _fp),
+        ("tap_dt", _i32 * 12), ("tap_df", _i32 * 12),
     ]
 
 

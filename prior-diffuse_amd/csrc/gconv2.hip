@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256, PDSE_WAVES_PER_EU) void gconv2_kernel(const pd
   unsigned inb_mask = 0;
 #pragma unroll
   for (int tap = 0; tap < NT; ++tap) {
-    const int dt = d.taps[2 * tap], df = d.taps[2 * tap + 1];
+    const int dt = d.tap_dt[tap], df = d.tap_df[tap];   // kernel arguments (scalar registers), not the device table
     const int tin = t + dt, fin = j * d.sf_in + df;
     const bool inb = pvalid && fin >= 0 && fin < d.Fin && tin >= 0 && tin < d.Tin;
     if (inb) inb_mask |= 1u << tap;

@@ -12,13 +12,13 @@
 //
 // Structure (Cin = 32, Cout = 32 per gated branch - every eps-net block but the composed encoder stage 1):
 //   * a workgroup of 8 waves shares ONE LDS image of all weight fragments of the launch (gather weights of both
-//     branches and both output phases, the chained 1x1 tails, biases, folded BatchNorm): 108-134 KB, filled once with
-//     16-byte copies; fragments reach the matrix cores through ds_read_b128 (the fp32 kernel re-reads its A fragments
+//     branches and both output phases, the chained 1x1 tails, biases, folded BatchNorm): 108-134 KB, filled once by
+//     LDS-DMA (global_load_lds_dwordx4) while the tile's activation loads are in flight; fragments reach the matrix cores through ds_read_b128 (the fp32 kernel re-reads its A fragments
 //     from L1/L2 in every wave: at 1.5x the bytes per weight that path would bound this kernel);
 //   * K order (tap, channel): lane (position, half h) gathers channels 16q + 8h .. +7 of its position for tap `tap` -
 //     eight 4-byte loads per (tap, q), the same number of vector-memory instructions per K as the fp32 kernel - splits
 //     them in registers (~6 VALU operations per value) and feeds 12 MFMAs (L and R branch);
-//   * taps are software-pipelined: the loads of tap t+1 are in flight while tap t is split and multiplied;
+//   * all taps of a tile are requested before the K loop (16 NT registers) and overlap the LDS image fill;
 //   * the BIGLU tail, the chained next-stage 1x1 tiles and the stores are gconv_common.h's, instantiated on the
 //     split-bf16 tail image (accumulator tiles are re-split in registers and used as B operands, k order rho_bf16).
 #include <hip/hip_runtime.h>
@@ -33,6 +33,12 @@ constexpr int popc3(int m) { return m ? (m & 1) + popc3(m >> 1) : 0; }
 constexpr int rank3(int m, int tap) { return popc3(m & ((1 << tap) - 1)); }
 
 #define S3_THREADS 512
+
+// one 16-byte LDS-DMA: LDS destination = wave-uniform base + lane * 16 (the fragment areas are lane-linear)
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l,
+                                   16, 0, 0);
+}
 #define S3_FLOATS 640   // float operands behind the fragment areas (see image layout in the kernel)
 
 // fragment counts (blocks of 3 planes x 64 lanes, 192 uint4 = 3 KB each)
@@ -59,41 +65,27 @@ __global__ __launch_bounds__(S3_THREADS, 2) void gconv3_kernel(const pdse_gconv_
   const int o_gR = NB * 192, o_gL1 = 2 * NB * 192, o_gR1 = o_gL1 + NB1 * 192, o_lc = o_gR1 + NB1 * 192;
   const int o_rc = o_lc + 384, o_c2 = o_rc + 384, o_nx = o_c2 + c2b * 192, o_f = o_nx + d.nx_n * 768;
   {
-    auto copy = [&](const float* src, const int dst, const int n) {   // n uint4 entries
-      const uint4* s4 = reinterpret_cast<const uint4*>(src);
-      for (int i = tid; i < n; i += S3_THREADS) img[dst + i] = s4[i];
-    };
-    copy(d.w0, 0, NB * 192);
-    copy(d.w1, o_gR, NB * 192);
-    if constexpr (P1MASK != 0) {
-      copy(d.w2, o_gL1, NB1 * 192);
-      copy(d.w3, o_gR1, NB1 * 192);
-    }
-    copy(d.wlc, o_lc, 384);
-    copy(d.wrc, o_rc, 384);
-    if (c2b) copy(d.wc2, o_c2, 768);
-    if (d.nx_n > 0) copy(d.nx_w, o_nx, d.nx_n * 768);
-    float* f = reinterpret_cast<float*>(img + o_f);
-    // floats: bl 0, br 32, bl0 64, br0 96, blc 128, brc 160, bc2 192 (64), ps 256 (64), pt 320 (64), nxb 384 (96), wc2v 480 (32)
-    if (tid < 32) {
-      const float bl = d.bias0[(int64_t)b * d.bias0_sb + tid], br = d.bias1[(int64_t)b * d.bias1_sb + tid];
-      f[tid] = bl;
-      f[32 + tid] = br;
-      f[64 + tid] = d.bias0_t0 ? d.bias0_t0[(int64_t)b * d.bias0_sb + tid] : bl;
-      f[96 + tid] = d.bias1_t0 ? d.bias1_t0[(int64_t)b * d.bias1_sb + tid] : br;
-      f[128 + tid] = d.blc[tid];
-      f[160 + tid] = d.brc[tid];
-      if (d.C2 == 1) f[480 + tid] = d.wc2[tid];
-    }
-    if (tid >= 64 && tid < 64 + d.C2) {
-      const int c = tid - 64;
-      f[192 + c] = d.bc2[c];
-      f[256 + c] = d.post_scale ? d.post_scale[c] : 1.0f;
-      f[320 + c] = d.post_scale ? d.post_shift[c] : 0.0f;
-    }
-    if (tid >= 128 && tid < 128 + 32 * d.nx_n) {
-      const int i = (tid - 128) >> 5, c = (tid - 128) & 31;
-      f[384 + 32 * i + c] = d.nx_bias[i][(int64_t)b * d.nx_bias_sb[i] + c];
+    // fragment areas: LDS-DMA (global_load_lds_dwordx4: no registers, nothing to wait for until the barrier), one 1 KB
+    // chunk = one wave instruction.  The areas sit in the image in the order of this table, so chunk c of the image is
+    // chunk (c - first chunk of its area) of one source array; wave w takes chunks w, w + 8, ... in ONE loop (a loop per
+    // area made hipcc drain the DMA queue between areas).
+    const uint4* const srcs[8] = {reinterpret_cast<const uint4*>(d.w0), reinterpret_cast<const uint4*>(d.w1),
+                                  reinterpret_cast<const uint4*>(d.w2), reinterpret_cast<const uint4*>(d.w3),
+                                  reinterpret_cast<const uint4*>(d.wlc), reinterpret_cast<const uint4*>(d.wrc),
+                                  reinterpret_cast<const uint4*>(d.wc2), reinterpret_cast<const uint4*>(d.nx_w)};
+    const int cnt[8] = {NB * 3, NB * 3, NB1 * 3, NB1 * 3, 6, 6, c2b * 3, d.nx_n * 12};
+    const int total = o_f >> 6;
+    for (int c = __builtin_amdgcn_readfirstlane(wave); c < total; c += S3_THREADS / 64) {
+      int cc = c;
+      const uint4* src = nullptr;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (src == nullptr) {
+          if (cc < cnt[k]) src = srcs[k] + cc * 64;
+          else cc -= cnt[k];
+        }
+      }
+      glds16(src + lane, img + c * 64);
     }
   }
 
@@ -102,7 +94,7 @@ __global__ __launch_bounds__(S3_THREADS, 2) void gconv3_kernel(const pdse_gconv_
   unsigned inb_mask = 0;
 #pragma unroll
   for (int tap = 0; tap < NT; ++tap) {
-    const int dt = d.taps[2 * tap], df = d.taps[2 * tap + 1];
+    const int dt = d.tap_dt[tap], df = d.tap_df[tap];   // kernel arguments (scalar registers), not the device table
     const int tin = t + dt, fin = j * d.sf_in + df;
     const bool inb = pvalid && fin >= 0 && fin < d.Fin && tin >= 0 && tin < d.Tin;
     if (inb) inb_mask |= 1u << tap;
@@ -115,25 +107,48 @@ __global__ __launch_bounds__(S3_THREADS, 2) void gconv3_kernel(const pdse_gconv_
 #pragma unroll
   for (int r = 0; r < 16; ++r) aL[r] = aR[r] = aL1[r] = aR1[r] = 0.f;
 
-  float raw[2][16];   // [ping-pong][q * 8 + j]: channels 16q + 8h + j of one tap
-  auto issue = [&](float (&v)[16], const int tap) {
+  // All taps' activations are requested up front (16 NT registers): with the matrix work of a tap down to ~800 cycles,
+  // a one-tap-ahead pipeline left every tap waiting for its loads (measured: 31k cycles per tile against 9k of MFMA
+  // issue).  The requests overlap the LDS image fill; the tile then runs its K loop back to back.
+  float raw[NT][16];   // [tap][q * 8 + e]: channels 16q + 8h + e
+#pragma unroll
+  for (int tap = 0; tap < NT; ++tap)
 #pragma unroll
     for (int q = 0; q < 2; ++q)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[q * 8 + e] = sp[off[tap] + (16 * q + e) * sc];
-  };
-  issue(raw[0], 0);
-  __syncthreads();   // the image is complete (its copies were issued ahead of the first activation loads)
+      for (int e = 0; e < 8; ++e) raw[tap][q * 8 + e] = sp[off[tap] + (16 * q + e) * sc];
+  {
+    // float operands, one slot per thread (512 slots, one load each, issued behind the DMA and the activation requests):
+    // bl 0, br 32, bl0 64, br0 96, blc 128, brc 160, bc2 192 (64), ps 256 (64), pt 320 (64), nxb 384 (96), wc2v 480 (32)
+    const int k = tid & 31, c64 = (tid - 192) & 63;
+    const bool bn = d.post_scale != nullptr;
+    float v;
+    if (tid < 32) v = d.bias0[(int64_t)b * d.bias0_sb + k];
+    else if (tid < 64) v = d.bias1[(int64_t)b * d.bias1_sb + k];
+    else if (tid < 96) v = (d.bias0_t0 ? d.bias0_t0 : d.bias0)[(int64_t)b * d.bias0_sb + k];
+    else if (tid < 128) v = (d.bias1_t0 ? d.bias1_t0 : d.bias1)[(int64_t)b * d.bias1_sb + k];
+    else if (tid < 160) v = d.blc[k];
+    else if (tid < 192) v = d.brc[k];
+    else if (tid < 256) v = c64 < d.C2 ? d.bc2[c64] : 0.f;
+    else if (tid < 320) v = (bn && c64 < d.C2) ? d.post_scale[c64] : 1.0f;
+    else if (tid < 384) v = (bn && c64 < d.C2) ? d.post_shift[c64] : 0.0f;
+    else if (tid < 480) {
+      const int i = (tid - 384) >> 5;
+      v = i < d.nx_n ? d.nx_bias[i][(int64_t)b * d.nx_bias_sb[i] + k] : 0.f;
+    } else v = d.C2 == 1 ? d.wc2[k] : 0.f;
+    reinterpret_cast<float*>(img + o_f)[tid] = v;
+  }
+  __builtin_amdgcn_sched_barrier(0);   // keep every request ahead of the barrier (hipcc sinks loads to their uses otherwise)
+  __syncthreads();   // the image is complete: DMA, float operands and this tile's activations have landed
 
 #pragma unroll
   for (int tap = 0; tap < NT; ++tap) {
-    if (tap + 1 < NT) issue(raw[(tap + 1) & 1], tap + 1);
     const bool inb = (inb_mask >> tap) & 1u;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       float x[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) x[e] = inb ? raw[tap & 1][q * 8 + e] : 0.f;
+      for (int e = 0; e < 8; ++e) x[e] = inb ? raw[tap][q * 8 + e] : 0.f;
       uint4 b1, b2, b3;
       split8(x, b1, b2, b3);
       const int blk = (tap * 2 + q) * 192 + lane;

@@ -221,6 +221,8 @@ class PlanBase:
             tp = ctx.bank.items[tkey] = ctx.up(P.taps_array(ttaps), np.int32)
             ctx._banking -= 1
         d.taps, d.ntaps, d.sf_in = tp.data_ptr(), len(ttaps), sf_in
+        for i, (dt_, df_) in enumerate(ttaps[:12]):             # by-value copy for the unrolled-tap kernels
+            d.tap_dt[i], d.tap_df[i] = dt_, df_
         d.cin1 = 1 if cin1 else 0
         c0, c1 = d.in0.C, d.in1.C
         pipelined_ok = padrow is None and not self.force_generic
