@@ -84,9 +84,11 @@ def main():
     ap.add_argument("--streams", type=int, default=1, help="concurrent sub-batch pipelines per GPU")
     ap.add_argument("--full-schedule", action="store_true",
                     help="BASELINE config 3: the full 50-step reverse schedule instead of 6-step fast sampling")
-    ap.add_argument("--split-bf16", action="store_true",
-                    help="eps-net BIGLU blocks on the bf16 matrix cores with exact three-way bf16 operand splits "
-                         "(fp32-level accuracy, parity-tested at the fp32 tolerances); dtype reads bf16x3")
+    ap.add_argument("--fp32", action="store_true",
+                    help="exact fp32 MFMA arithmetic everywhere (v_mfma_f32_32x32x2_f32).  Default for fast sampling: the "
+                         "eps-net's BIGLU blocks run on the bf16 matrix cores with exact three-way bf16 operand splits "
+                         "(six products, fp32 accumulate) - fp32-level accuracy, parity-tested against the same goldens "
+                         "and tolerances; the full 50-step schedule always runs exact fp32")
     ap.add_argument("--dry-run", action="store_true",
                     help="rehearse the launch / rendezvous / timing-reduction / reporting path on CPU (gloo, no GPU, no "
                          "kernels): the JSON line carries \"dry_run\": true and value null")
@@ -98,6 +100,7 @@ def main():
     if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
         sys.exit("bench.py: --gpus %d does not match WORLD_SIZE=%s of the launcher" % (args.gpus, os.environ["WORLD_SIZE"]))
     fast = not args.full_schedule
+    args.split_bf16 = fast and not args.fp32
     args.overlap = args.inflight > 1
     args.depth, args.by_batch = max(2, args.inflight), not args.stage_streams
 
@@ -218,6 +221,20 @@ def main():
         pipe.run(graph=use_graph)
     torch.cuda.synchronize()
     ms_sequential = (time.perf_counter() - ts) / seq_steps * 1e3
+    fp32_exact = None
+    if args.split_bf16:   # the same pass with exact fp32 MFMA arithmetic everywhere, measured in the same run
+        p32 = pipeline.SamplerPipeline(dev, args.prior, gs, ds, B, L_=L_, fast_sampling=fast, split_bf16=False)
+        p32.enhance(wav, x_T, graph=use_graph)
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        for _ in range(seq_steps):
+            p32.run(graph=use_graph)
+        torch.cuda.synchronize()
+        ms32 = (time.perf_counter() - ts) / seq_steps * 1e3
+        fp32_exact = {"ms_per_step_sequential": round(ms32, 3), "value_sequential": round(B * args.seconds / (ms32 * 1e-3), 2),
+                      "note": "same workload, v_mfma_f32_32x32x2_f32 everywhere (bench.py --fp32), one batch at a time"}
+        del p32
+        torch.cuda.empty_cache()
     per_tag = {}
     for name, tag in (("eps_block", nets.TAG_EPS_BLOCK), ("eps_conv1", nets.TAG_EPS_CONV1), ("tcm", nets.TAG_TCM),
                       ("prior_conv", nets.TAG_PRIOR), ("lstm", nets.TAG_LSTM), ("signal", nets.TAG_SIGNAL),
@@ -319,7 +336,7 @@ def main():
                    "global_batch": B * world, "frames": T, "parallelism": "batch-shard x%d" % world,
                    "graph": use_graph and (not args.overlap or args.by_batch), "streams_per_gpu": args.streams,
                    "batches_in_flight": args.inflight},
-        "roofline": roofline, "cpu_baseline": cpu,
+        "roofline": roofline, "cpu_baseline": cpu, "fp32_exact": fp32_exact,
     }
     print(json.dumps(out))
     if dist is not None:

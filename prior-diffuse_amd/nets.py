@@ -115,17 +115,24 @@ class PlanBase:
     def src(self, t, C_, sb, sc, st, sf, off=0, act=L.ACT_NONE):
         return L.Src(Ctx.ptr(t, off), sb, sc, st, sf, C_, act)
 
-    def _gconv_weights_s3(self, w, ntaps):
-        """korder 2 (csrc/gconv3.hip): exact three-way bf16 splits of a BIGLU block's weights, MFMA bf16 fragment order."""
+    def _gconv_weights_s3(self, w, ntaps, cin=32):
+        """korder 2 (csrc/gconv3.hip): exact three-way bf16 splits of a BIGLU block's weights, MFMA bf16 fragment order.
+        cin 4: the composed encoder stage 1 (K = 10 taps x 4 channels = 40, zero-padded to three 16-deep blocks)."""
         ctx = self.ctx
         up = lambda a: ctx.up(a).data_ptr()   # noqa: E731
         up16 = lambda a: ctx.up(np.ascontiguousarray(a).view(np.int16), np.int16).data_ptr()   # noqa: E731
-        f = {"korder": 2, "ksteps": ntaps * 16}
-        f["w0"], f["w1"] = up16(P.pack_s3_gather(w["wk0"], ntaps)), up16(P.pack_s3_gather(w["wk1"], ntaps))
+        f = {"korder": 2, "ksteps": ntaps * cin // 2}
+        if cin == 4:
+            pad = lambda wk: np.concatenate([np.asarray(wk, np.float64), np.zeros((8, 32))], 0)   # noqa: E731  [48, 32]
+            f["w0"], f["w1"] = up16(P.pack_s3_gather(pad(w["wk0"]), 3, 16)), up16(P.pack_s3_gather(pad(w["wk1"]), 3, 16))
+        else:
+            f["w0"], f["w1"] = up16(P.pack_s3_gather(w["wk0"], ntaps)), up16(P.pack_s3_gather(w["wk1"], ntaps))
         if w.get("wk2") is not None:
             f["w2"], f["w3"] = up16(P.pack_s3_gather(w["wk2"], w["ntaps1"])), up16(P.pack_s3_gather(w["wk3"], w["ntaps1"]))
             f["ksteps1"] = w["ntaps1"] * 16
-        f["bias0"], f["bias1"] = up(w["bias0"]), up(w["bias1"])
+        for k in ("bias0", "bias1"):                           # time-conditioned launches get device biases instead
+            if w.get(k) is not None:
+                f[k] = up(w[k])
         if w.get("post") is not None:
             f["post_scale"], f["post_shift"] = up(w["post"][0]), up(w["post"][1])
         chain = w["chain"]
@@ -226,10 +233,11 @@ class PlanBase:
         d.cin1 = 1 if cin1 else 0
         c0, c1 = d.in0.C, d.in1.C
         pipelined_ok = padrow is None and not self.force_generic
-        s3 = bool(s3) and pipelined_ok and epi == L.EPI_BIGLU and c0 == 32 and c1 == 0
+        s3 = bool(s3) and pipelined_ok and epi == L.EPI_BIGLU and ((c0, c1) == (32, 0) or ((c0, c1, len(ttaps)) == (2, 2, 10)
+                                                                                          and phase1 is None))
         site = "%s:%d:%d:%d:%d:%d:%d:%d" % (label, epi, len(ttaps), c0, c1, Cout, pipelined_ok, s3)
         if s3:
-            f = self.memo(site, lambda: self._gconv_weights_s3(W(), len(ttaps)))
+            f = self.memo(site, lambda: self._gconv_weights_s3(W(), len(ttaps), c0 + c1))
         else:
             f = self.memo(site, lambda: self._gconv_weights(W(), len(ttaps), c0, c1, epi, cin1, pipelined_ok))
         for k, v in f.items():
@@ -292,7 +300,9 @@ class EpsNetPlan(PlanBase):
     fused_tcm = True        # one launch per TCM residual block (csrc/tcm.hip); False: three gather-GEMM launches
     chain_conv1 = True      # every stage's 1x1 input convolution rides on the previous stage's tail (pdse.h: nx_*)
     compose_stage1 = True   # (with chain_conv1) encoder stage 1: conv1 composed into the gather weights
-    split_bf16 = False      # BIGLU blocks on the bf16 matrix cores with exact 3-way operand splits (csrc/gconv3.hip)
+    # BIGLU blocks on the bf16 matrix cores with exact 3-way operand splits (csrc/gconv3.hip): fp32-level accuracy
+    # (same goldens, same tolerances) at 16/6 of the fp32 MFMA rate.  False: v_mfma_f32_32x32x2_f32 throughout.
+    split_bf16 = True
     NSLOT = 20  # 15 stages + en1 real-row bias + 4 composed encoder-stage-1 biases (l/r x frame >= 1 / frame 0)
 
     def __init__(self, ctx, sd, B, T, time_cond=True, nsteps=1, plan=None, table=None, with_pre=None, split_bf16=None):
@@ -433,7 +443,7 @@ class EpsNetPlan(PlanBase):
 
         self.gconv(in0=src_x, in1=src_init, Tin=T, Fin=Fin, taps=taps, sf_in=2, W=W, Cout=32, epi=L.EPI_BIGLU,
                    act=L.ACT_PRELU, act_slope=self._slope("en.en1.1.weight"), out=out_t, out_strides=out_strides,
-                   B=B, Tout=T, Fout=Fout, tag=TAG_EPS_BLOCK, nx=nx, label="en1c", **bias)
+                   B=B, Tout=T, Fout=Fout, tag=TAG_EPS_BLOCK, nx=nx, label="en1c", s3=self.split_bf16, **bias)
         return Fout
 
     def _slope(self, key):

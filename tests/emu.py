@@ -90,9 +90,11 @@ def run_gconv(d, mem):
             assert np.all(wk[rows < 0] == 0)
             return out
     elif d.korder == 2:   # split-bf16 BIGLU block (csrc/gconv3.hip): exact 3-way bf16 splits in bf16 MFMA fragment order
-        assert d.epi == L.EPI_BIGLU and Cin == 32 and d.Cout == 32
+        assert d.epi == L.EPI_BIGLU and Cin in (32, 4) and d.Cout == 32
 
         def unpack(ptr):
+            if Cin == 4:    # composed encoder stage 1: K = 40 padded to three 16-deep blocks
+                return P.unpack_s3_gather(mem.arr(ptr, 3 * 3 * 64 * 8, np.int16).view(np.uint16), 3, 16)[:d.ntaps * 4]
             return P.unpack_s3_gather(mem.arr(ptr, d.ntaps * 2 * 3 * 64 * 8, np.int16).view(np.uint16), d.ntaps)
     else:
         def unpack(ptr):

@@ -45,7 +45,7 @@ def test_eps_net_plan_vs_oracle(weights, chained, split, monkeypatch):
     n_conv1 = sum(1 for _, tag in net.descs if tag == nets.TAG_EPS_CONV1)
     assert n_conv1 == (2 if chained else 16)          # chained: only decoder stage 5 x 2 (encoder stage 1 is composed)
     n_split = sum(1 for d, _ in net.descs if isinstance(d, pkg("_lib").GconvDesc) and d.korder == 2)
-    assert n_split == (14 if split else 0)            # encoder stages 2-5 + 2 x 5 decoder stages
+    assert n_split == (15 if split else 0)            # encoder stages 1-5 + 2 x 5 decoder stages
     x, xi = seeded((B, 2, T, 161), 3), seeded((B, 2, T, 161), 4) * 0.3
     t = torch.tensor([4.086654, 22.992493])
     net.x.copy_(x)
