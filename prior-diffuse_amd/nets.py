@@ -233,8 +233,9 @@ class PlanBase:
         d.cin1 = 1 if cin1 else 0
         c0, c1 = d.in0.C, d.in1.C
         pipelined_ok = padrow is None and not self.force_generic
-        s3 = bool(s3) and pipelined_ok and epi == L.EPI_BIGLU and ((c0, c1) == (32, 0) or ((c0, c1, len(ttaps)) == (2, 2, 10)
-                                                                                          and phase1 is None))
+        # split-bf16 instantiations (csrc/gconv3.hip): 32-channel blocks with 4 or 6 taps, the composed encoder stage 1
+        s3 = bool(s3) and pipelined_ok and epi == L.EPI_BIGLU and (
+            ((c0, c1) == (32, 0) and len(ttaps) in (4, 6)) or ((c0, c1, len(ttaps)) == (2, 2, 10) and phase1 is None))
         site = "%s:%d:%d:%d:%d:%d:%d:%d" % (label, epi, len(ttaps), c0, c1, Cout, pipelined_ok, s3)
         if s3:
             f = self.memo(site, lambda: self._gconv_weights_s3(W(), len(ttaps), c0 + c1))

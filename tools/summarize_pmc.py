@@ -19,7 +19,7 @@ def load(path):
 
 
 def short(n):
-    m = re.match(r"void (gconv2?_kernel)<(.*)>\(", n)
+    m = re.match(r"void (gconv[23]?_kernel)<(.*)>\(", n)
     if m:
         return m.group(1).replace("_kernel", "") + "<" + m.group(2).replace("false", "F").replace("true", "T").replace(" ", "") + ">"
     return re.sub(r"\(.*", "", n)[:30]
