@@ -193,45 +193,64 @@ __global__ __launch_bounds__(1024, 4) void gconv3_in4_kernel(const pdse_gconv_de
 
 // WV: waves per workgroup.  8 (two per SIMD, up to 256 registers each): every tap's activations are requested before the
 // K loop.  16 (single-phase blocks only; four per SIMD, 128 registers): one tap in flight, the other waves cover its latency.
-template <int NT, int P1MASK, bool NX, int WV>
+// PF: request every tap's activations before the K loop (16 NT registers); false: one tap in flight.
+// PERSIST: the workgroup walks rounds blockIdx.x, blockIdx.x + gridDim.x, ... of its batch item (image filled once); false:
+// one round per workgroup - the 16-wave form has no registers left for the loop-carried state (32 spills, 181 -> 200 us).
+template <int NT, int P1MASK, bool NX, int WV, bool PF = (WV != 16), bool PERSIST = (WV != 16)>
 __global__ __launch_bounds__(64 * WV, WV / 4) void gconv3_kernel(const pdse_gconv_desc d) {
-  constexpr int NB = 2 * NT, NT1 = popc3(P1MASK), NB1 = 2 * NT1, S3_THREADS = 64 * WV;
+  constexpr int NB = 2 * NT, NT1 = popc3(P1MASK), NB1 = 2 * NT1;
   extern __shared__ uint4 img[];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int col = lane & 31, h = lane >> 5;
   const int b = blockIdx.y;
   const int P = d.Tout * d.Fout;
-  const int p = (blockIdx.x * WV + wave) * 32 + col;
-  const bool pvalid = p < P;
-  const int t = pvalid ? p / d.Fout : 0;
-  const int j = pvalid ? p - t * d.Fout : 0;
 
+  // The workgroup is PERSISTENT over the position tiles of its batch item: the LDS image (weights of the launch, the
+  // item's biases) is filled once, then rounds blockIdx.x, blockIdx.x + gridDim.x, ... of WV tiles each are walked with
+  // no barrier in between, so the waves drift apart and one wave's VALU-heavy tail runs beside another's MFMA-heavy K
+  // loop; the next round's activations are requested before the current round's tail.  (One round per workgroup left
+  // ~45 % of a round to fill latency, launch gaps and barrier skew: the image allows one workgroup per CU.)
   const s3_layout LY = s3_make_layout(NB, NB1, d);
   const int o_gR = LY.o_gR, o_gL1 = LY.o_gL1, o_gR1 = LY.o_gR1;
   s3_fill(img, d, LY, NB, NB1, lane, wave, WV);
+  s3_float_operands(img, d, LY, b, tid);
+  __syncthreads();   // the image is complete (DMA + float operands)
+  const pdse_tail_s3 tl = s3_tail(img, LY);
+  const int nrounds = ((P + 31) / 32 + WV - 1) / WV;
 
-  // ---- per-tap gather state
-  unsigned off[NT];   // per-lane element offset of (tap, this half's first channel): 32-bit, added to a scalar channel base
-  unsigned inb_mask = 0;
+  // position of this lane in round rd and its per-tap gather state
+  struct pos_t {
+    int t, j;
+    bool pvalid;
+    unsigned inb_mask;
+    unsigned off[NT];   // per-lane element offset of (tap, this half's first channel): 32-bit, added to a scalar channel base
+  };
+  auto locate = [&](const int rd, pos_t& ps) {
+    const int p = (rd * WV + wave) * 32 + col;
+    ps.pvalid = p < P;
+    ps.t = ps.pvalid ? p / d.Fout : 0;
+    ps.j = ps.pvalid ? p - ps.t * d.Fout : 0;
+    ps.inb_mask = 0;
 #pragma unroll
-  for (int tap = 0; tap < NT; ++tap) {
-    const int dt = d.tap_dt[tap], df = d.tap_df[tap];   // kernel arguments (scalar registers), not the device table
-    const int tin = t + dt, fin = j * d.sf_in + df;
-    const bool inb = pvalid && fin >= 0 && fin < d.Fin && tin >= 0 && tin < d.Tin;
-    if (inb) inb_mask |= 1u << tap;
-    off[tap] = (unsigned)((inb ? (int64_t)b * d.in0.sb + (int64_t)tin * d.in0.st + (int64_t)fin * d.in0.sf : 0) +
-                          (int64_t)(8 * h) * d.in0.sc);
-  }
+    for (int tap = 0; tap < NT; ++tap) {
+      const int dt = d.tap_dt[tap], df = d.tap_df[tap];   // kernel arguments (scalar registers), not the device table
+      const int tin = ps.t + dt, fin = ps.j * d.sf_in + df;
+      const bool inb = ps.pvalid && fin >= 0 && fin < d.Fin && tin >= 0 && tin < d.Tin;
+      if (inb) ps.inb_mask |= 1u << tap;
+      ps.off[tap] = (unsigned)((inb ? (int64_t)b * d.in0.sb + (int64_t)tin * d.in0.st + (int64_t)fin * d.in0.sf : 0) +
+                               (int64_t)(8 * h) * d.in0.sc);
+    }
+  };
   // channel c of the 16q + e enumeration: a wave-uniform base (scalar registers) + the lane's 32-bit offset - the
   // global_load saddr form, no per-load 64-bit address arithmetic or address registers
   auto chan = [&](const int c) -> const float* { return d.in0.ptr + (int64_t)c * d.in0.sc; };
 
   f32x16 aL, aR, aL1, aR1;
+  auto zero_acc = [&]() {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) aL[r] = aR[r] = aL1[r] = aR1[r] = 0.f;
-
-  auto float_operands = [&]() { s3_float_operands(img, d, LY, b, tid); };
+    for (int r = 0; r < 16; ++r) aL[r] = aR[r] = aL1[r] = aR1[r] = 0.f;
+  };
   auto block = [&](const float (&x)[8], const int tap, const int q) {   // one 16-channel K block of one tap
     uint4 b1, b2, b3;
     split8(x, b1, b2, b3);
@@ -246,20 +265,13 @@ __global__ __launch_bounds__(64 * WV, WV / 4) void gconv3_kernel(const pdse_gcon
       }
     }
   };
-
-  const pdse_tail_s3 tl = s3_tail(img, LY);
-
-  if constexpr (WV == 8) {
-    // All taps' activations are requested up front (16 NT registers): with the matrix work of a tap down to ~800 cycles,
-    // a one-tap-ahead pipeline left every tap waiting for its loads.  The requests overlap the LDS image fill.
-    float raw[NT][16];   // [tap][q * 8 + e]: channels 16q + 8h + e
+  auto request_all = [&](const pos_t& ps, float (&raw)[NT][16]) {   // [tap][q * 8 + e]: channels 16q + 8h + e
 #pragma unroll
     for (int tap = 0; tap < NT; ++tap)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) raw[tap][e] = chan((e >> 3) * 16 + (e & 7))[off[tap]];
-    float_operands();
-    __builtin_amdgcn_sched_barrier(0);   // keep every request ahead of the barrier (hipcc sinks loads to their uses otherwise)
-    __syncthreads();   // the image is complete: DMA, float operands and this tile's activations have landed
+      for (int e = 0; e < 16; ++e) raw[tap][e] = chan((e >> 3) * 16 + (e & 7))[ps.off[tap]];
+  };
+  auto kloop_all = [&](const unsigned inb_mask, const float (&raw)[NT][16]) {
 #pragma unroll
     for (int tap = 0; tap < NT; ++tap) {
       const bool inb = (inb_mask >> tap) & 1u;
@@ -271,16 +283,15 @@ __global__ __launch_bounds__(64 * WV, WV / 4) void gconv3_kernel(const pdse_gcon
         block(x, tap, q);
       }
     }
-  } else {
+  };
+  auto kloop_tap = [&](const pos_t& ps) {   // one tap in flight
     float cur[16];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) cur[e] = chan((e >> 3) * 16 + (e & 7))[off[0]];
-    float_operands();
+    for (int e = 0; e < 16; ++e) cur[e] = chan((e >> 3) * 16 + (e & 7))[ps.off[0]];
     __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
 #pragma unroll
     for (int tap = 0; tap < NT; ++tap) {
-      const bool inb = (inb_mask >> tap) & 1u;
+      const bool inb = (ps.inb_mask >> tap) & 1u;
       float x0[8], x1[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -289,35 +300,141 @@ __global__ __launch_bounds__(64 * WV, WV / 4) void gconv3_kernel(const pdse_gcon
       }
       if (tap + 1 < NT) {   // the next tap's requests go out before this tap's matrix work
 #pragma unroll
-        for (int e = 0; e < 16; ++e) cur[e] = chan((e >> 3) * 16 + (e & 7))[off[tap + 1]];
+        for (int e = 0; e < 16; ++e) cur[e] = chan((e >> 3) * 16 + (e & 7))[ps.off[tap + 1]];
       }
       block(x0, tap, 0);
       block(x1, tap, 1);
     }
-  }
+  };
 
-  if constexpr (P1MASK != 0)
-    biglu_dual_epilogue<NX>(d, tl, aL, aR, aL1, aR1, b, t, j, pvalid, lane, h);
-  else
-    biglu_nx_epilogue(d, tl, aL, aR, b, t, j, pvalid, lane, h);
+  auto epilogue = [&](const int t, const int j, const bool pvalid) {
+    if constexpr (P1MASK != 0 && NX) {
+      // Two-phase block chained into the next stage's conv1 (gconv_common.h: biglu_dual_epilogue<true>), with the block
+      // output streamed into the chained tile one 32-channel half at a time instead of being kept whole (16 registers less)
+      const int64_t scz = d.nx_sc[0], nbin = d.nx_sf[0] >> 1;
+      const int64_t offz = (int64_t)b * d.nx_sb[0] + (int64_t)t * d.nx_st[0] + (int64_t)j * d.nx_sf[0] + d.nx_off[0] + (int64_t)(4 * h) * scz;
+      float* const zb = d.nx_out[0] + offz;
+      const float* const ab = d.nx_add[0] ? d.nx_add[0] + offz : nullptr;
+      const bool two = pvalid && j < d.Fout1;
+      f32x16 Z0, Z1, Yt;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Z0[r] = (ab && pvalid) ? ab[(int64_t)PDSE_KR(r) * scz] : 0.f;
+      __builtin_amdgcn_sched_barrier(0);
+      biglu_tail_values(d, tl, aL, aR, lane, h, [&](const int m2, const int r, const float v) {
+        Yt[r] = v;
+        if (r == 15) Z0 = chain_s3(tl.nxw + m2 * 384 + lane, Yt, Z0);
+      });
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Z1[r] = (ab && two) ? ab[(int64_t)PDSE_KR(r) * scz + nbin] : 0.f;
+      __builtin_amdgcn_sched_barrier(0);
+      biglu_tail_values(d, tl, aL1, aR1, lane, h, [&](const int m2, const int r, const float v) {
+        Yt[r] = v;
+        if (r == 15) Z1 = chain_s3(tl.nxw + m2 * 384 + lane, Yt, Z1);
+      });
+      const f32x16 pb = ld16(tl.nxb + 4 * h);
+      if (nbin == 1 && two) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) store_pair(zb + (int64_t)PDSE_KR(r) * scz, Z0[r] + pb[r], Z1[r] + pb[r]);
+      } else if (pvalid) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zb[(int64_t)PDSE_KR(r) * scz] = Z0[r] + pb[r];
+        if (two) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) zb[(int64_t)PDSE_KR(r) * scz + nbin] = Z1[r] + pb[r];
+        }
+      }
+    } else if constexpr (P1MASK == 27) {
+      // last decoder stage (kernel (2,5), ONE output channel - validated at launch): one value per position and phase;
+      // the generic two-phase epilogue keeps a 64-channel copy of the even phase, which at 256 registers spilled
+      float ve = 0.f, vo = 0.f;
+      biglu_tail_values(d, tl, aL, aR, lane, h, [&](const int, const int, const float v) { ve = v; });
+      __builtin_amdgcn_sched_barrier(0);
+      biglu_tail_values(d, tl, aL1, aR1, lane, h, [&](const int, const int, const float v) { vo = v; });
+      float* const po = d.out + ((int64_t)b * d.out_sb + (int64_t)t * d.out_st + (int64_t)j * d.out_sf + d.out_off);
+      const int64_t bin = d.out_sf >> 1;
+      const bool both = pvalid && j < d.Fout1;
+      if (h == 0) {
+        if (both && bin == 1) store_pair(po, ve, vo);
+        else if (pvalid) {
+          po[0] = ve;
+          if (both) po[bin] = vo;
+        }
+      }
+    } else if constexpr (P1MASK != 0) {
+      biglu_dual_epilogue<NX>(d, tl, aL, aR, aL1, aR1, b, t, j, pvalid, lane, h);
+    } else {
+      biglu_nx_epilogue(d, tl, aL, aR, b, t, j, pvalid, lane, h);
+    }
+  };
+
+  if constexpr (PERSIST && PF) {
+    // software pipeline over the rounds: round r+1's activations are requested between round r's K loop and its tail
+    pos_t ps;
+    float raw[NT][16];
+    int rd = blockIdx.x;
+    if (rd < nrounds) {
+      locate(rd, ps);
+      request_all(ps, raw);
+    }
+    while (rd < nrounds) {
+      zero_acc();
+      __builtin_amdgcn_sched_barrier(0);   // every request of this round is out before its K loop starts
+      kloop_all(ps.inb_mask, raw);
+      const int t = ps.t, j = ps.j;
+      const bool pvalid = ps.pvalid;
+      rd += gridDim.x;
+      if (rd < nrounds) {
+        locate(rd, ps);
+        request_all(ps, raw);
+      }
+      __builtin_amdgcn_sched_barrier(0);   // ... and the next round's before this round's tail
+      epilogue(t, j, pvalid);
+    }
+  } else {
+    auto round = [&](const int rd) {
+      pos_t ps;
+      locate(rd, ps);
+      zero_acc();
+      if constexpr (PF) {
+        float raw[NT][16];
+        request_all(ps, raw);
+        __builtin_amdgcn_sched_barrier(0);
+        kloop_all(ps.inb_mask, raw);
+      } else {
+        kloop_tap(ps);
+      }
+      epilogue(ps.t, ps.j, ps.pvalid);
+    };
+    if constexpr (PERSIST) {
+      for (int rd = blockIdx.x; rd < nrounds; rd += gridDim.x) round(rd);
+    } else {
+      round(blockIdx.x);   // one round per workgroup (grid.x == nrounds)
+    }
+  }
 }
 
-template <int NT, int P1MASK, bool NX, int WV>
+template <int NT, int P1MASK, bool NX, int WV, bool PF = (WV != 16), bool PERSIST = (WV != 16)>
 static int launch3(const pdse_gconv_desc* d, hipStream_t s) {
   const int P = d->Tout * d->Fout;
-  const dim3 grid(((P + 31) / 32 + WV - 1) / WV, d->B, 1), block(64 * WV);
+  const int rounds = ((P + 31) / 32 + WV - 1) / WV;
+  // one workgroup per CU holds the image: about 256 persistent workgroups in all, each walking its share of its item's rounds
+  static const int wgs = getenv("PDSE_S3_WGS") ? atoi(getenv("PDSE_S3_WGS")) : 256;
+  int gx = (wgs + d->B - 1) / d->B;
+  if (gx > rounds || !PERSIST) gx = rounds;
+  if (gx < 1) gx = 1;
+  const dim3 grid(gx, d->B, 1), block(64 * WV);
   const size_t lds = (size_t)s3_blocks(NT, P1MASK, d->C2, d->nx_n) * 192 * sizeof(uint4) + S3_FLOATS * sizeof(float);
   if (lds > 160 * 1024) {
     pdse_set_error("gconv3: LDS image too large");
     return 1;
   }
-  const void* fn = (const void*)gconv3_kernel<NT, P1MASK, NX, WV>;
+  const void* fn = (const void*)gconv3_kernel<NT, P1MASK, NX, WV, PF, PERSIST>;
   static bool attr_done = false;   // per instantiation
   if (!attr_done) {
     if (pdse_check_hip(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "gconv3 lds attribute")) return 1;
     attr_done = true;
   }
-  hipLaunchKernelGGL((gconv3_kernel<NT, P1MASK, NX, WV>), grid, block, lds, s, *d);
+  hipLaunchKernelGGL((gconv3_kernel<NT, P1MASK, NX, WV, PF, PERSIST>), grid, block, lds, s, *d);
   return pdse_check_launch("gconv3");
 }
 
@@ -372,8 +489,13 @@ int pdse_gconv3_launch(const pdse_gconv_desc* d, hipStream_t s) {
     // transposed (two-phase) blocks always run 8 waves: a 16-wave form (the phases one after the other on one accumulator
     // pair to fit 128 registers, odd-phase taps gathered and split a second time) measured the same - 213 vs 211 us on
     // the 401 x 40 stage, 340 vs 346 us on the last stage - and was dropped
-    if (d->ntaps == 4 && d->p1mask == 5) return d->nx_n ? launch3<4, 5, true, 8>(d, s) : launch3<4, 5, false, 8>(d, s);
-    if (d->ntaps == 6 && d->p1mask == 27 && d->nx_n == 0) return launch3<6, 27, false, 8>(d, s);
+    static const bool pf_off = getenv("PDSE_S3_PF") && atoi(getenv("PDSE_S3_PF")) == 0;   // tuning: one tap in flight
+    if (d->ntaps == 4 && d->p1mask == 5) {
+      if (d->nx_n) return pf_off ? launch3<4, 5, true, 8, false>(d, s) : launch3<4, 5, true, 8>(d, s);
+      return launch3<4, 5, false, 8, false>(d, s);
+    }
+    if (d->ntaps == 6 && d->p1mask == 27 && d->nx_n == 0 && d->C2 == 1)
+      return pf_off ? launch3<6, 27, false, 8, false>(d, s) : launch3<6, 27, false, 8>(d, s);
   } else {
     if (d->C2 != 64 || d->nx_n > 3) {
       pdse_set_error("gconv3: single phase needs C2 == 64 and at most three chained tiles");
