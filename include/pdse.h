@@ -114,7 +114,10 @@ typedef struct pdse_gconv_desc {
                W[k = tap*32 + 16q + 8h + j][row]
        wlc, wrc [2][3][64][8]; wc2 [2 tiles][2][3][64][8] (C2 == 64; C2 == 1: the fp32 vector [32] as before);
        nx_w [nx_n][4][3][64][8]: chained tiles, k order of an accumulator tile used as B operand
-               (packing.rho_bf16).  Activations, biases, BatchNorm and every output stay fp32. */
+               (packing.rho_bf16).  Activations, biases, BatchNorm and every output stay fp32.
+     3: split-bf16 GEMM-shaped convolutions (csrc/gconv4.hip; LINEAR / GLU, channel counts in multiples of 16, no load
+     transform): w0 (w1) [K blocks][ceil(Cout/32) tiles][3 planes][64 lanes][8 bf16], K blocks of 16 channels in the
+     order (source, tap, channel block); lane (row, h), element j = W[tap*Cin + cbase + 16cb + 8h + j][32 tile + row]. */
   int32_t korder;
   /* Dual-phase stride-(1,2) ConvTranspose2d (BIGLU only, korder 1): one launch computes the even
      output bins f_o = 2j (weights w0/w1 over all ntaps taps) AND the odd bins 2j+1 (weights w2/w3

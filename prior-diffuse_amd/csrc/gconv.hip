@@ -165,6 +165,7 @@ int pdse_gconv_launch(const pdse_gconv_desc* d, hipStream_t s) {
     PDSE_REQUIRE(d->in1.C == 0 || d->in1.ptr, "in1 has channels but no pointer");
     if (d->korder == 0) PDSE_REQUIRE(d->ksteps == d->ntaps * (Cin / 2), "ksteps != ntaps*Cin/2");
     else PDSE_REQUIRE(d->ksteps >= d->ntaps * (Cin / 2), "ksteps < ntaps*Cin/2");
+    PDSE_REQUIRE(d->korder < 3 || d->epi != PDSE_EPI_BIGLU, "korder 3 has LINEAR / GLU epilogues only");
   }
   if (d->xf_mode) {
     PDSE_REQUIRE(d->xf_scale0 && d->xf_shift0, "xf_mode set without scale/shift");
@@ -196,6 +197,7 @@ int pdse_gconv_launch(const pdse_gconv_desc* d, hipStream_t s) {
     PDSE_REQUIRE(!d->cin1, "korder 1 needs Cin >= 2");
     return pdse_gconv2_launch(d, s);
   }
+  if (d->korder == 3) return pdse_gconv4_launch(d, s);   // split-bf16 GEMM-shaped convolutions (gconv4.hip)
   if (d->korder == 2) {   // split-bf16 BIGLU blocks (gconv3.hip)
     PDSE_REQUIRE(d->resid == nullptr, "BIGLU has no residual input");
     PDSE_REQUIRE(d->act == PDSE_ACT_NONE || d->act == PDSE_ACT_PRELU, "BIGLU stages end in PReLU or no activation");

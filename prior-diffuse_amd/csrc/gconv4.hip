@@ -1,0 +1,225 @@
+// gconv4.hip — the GEMM-shaped gather convolutions (korder 3) on the bf16 matrix cores with exact three-way bf16
+// operand splits: GCRN's gated (transposed) convolutions and LSTM input projection, DB-AIAT's dilated dense blocks.
+// Same descriptors, same fp32 tensors in HBM and the same LINEAR / GLU epilogues as gconv2.hip (gconv_common.h); only
+// the contraction changes (arithmetic: see gconv3.hip / packing.split_bf16x3 - six bf16 products per fp32
+// multiply-add, fp32 accumulation, fp32-level accuracy at 16/6 of the fp32 MFMA rate).
+//
+// Unlike the eps-net blocks (gconv3.hip: K <= 192, all weights of a launch in one LDS image) these layers have K up to
+// 1024 and up to 2 x 256 output channels, i.e. up to 1.5 MB of split weights: a GEMM main loop.
+//   * workgroup = 8 waves = 8 tiles of 32 positions of one batch item x MT channel tiles (x 2 branches for GLU);
+//   * K is walked in chunks of G4_CH 16-channel blocks of one (source, tap); the chunk's A fragments
+//     ([block][branch][tile][3 planes][64 lanes] uint4) are streamed into a double-buffered LDS ring by LDS-DMA
+//     (global_load_lds_dwordx4) while the previous chunk is multiplied; one barrier per chunk;
+//   * B operand: lane (position, half h) gathers channels 16 cb + 8h .. +7 of its position (eight 4-byte loads per block,
+//     scalar channel base + 32-bit lane offset), ELU-on-load for GCRN's skip source, exact split in registers; the next
+//     chunk's requests are issued before the current chunk's matrix work;
+//   * every (branch, tile) accumulator of the wave reuses the split B operand: 6 x branches x MT MFMAs per block.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "pdse.h"
+#include "pdse_internal.h"
+
+#include "gconv_common.h"
+
+#define G4_CH 4   // 16-channel K blocks per LDS chunk
+
+__device__ __forceinline__ void glds16_g4(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l,
+                                   16, 0, 0);
+}
+
+// One gathered activation: global_load_dword (scalar base + 32-bit lane offset) written as inline asm.  While an LDS-DMA is
+// in flight hipcc puts s_waitcnt vmcnt(0) in front of the first use of ANY compiler-visible load result
+// (cdna_hip_programming.md §5, "Pipelining across barriers"), which made every K block wait for the next chunk's DMA and
+// gather.  The compiler does not see these loads; what orders them is the chunk barrier: a chunk's values are requested
+// one barrier before they are used, and __syncthreads() drains vmcnt (the DMA is compiler-visible) before it releases.
+__device__ __forceinline__ float g4_load(const float* sbase, const unsigned byte_off) {
+  float v;
+  asm volatile("global_load_dword %0, %1, %2" : "=v"(v) : "v"(byte_off), "s"(sbase) : "memory");
+  return v;
+}
+// no instruction: pins the point after which the values may be read (register-only uses could otherwise be scheduled above
+// the barrier that makes them valid)
+__device__ __forceinline__ void g4_landed(float (&raw)[G4_CH][8]) {
+#pragma unroll
+  for (int i = 0; i < G4_CH; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(raw[i][e]));
+}
+
+struct g4_chunk {
+  int s, tap, cb0, n, kb0;   // source, tap, first 16-channel block, blocks in the chunk, first K block in the packed weights
+};
+
+template <int EPI, int MT>
+__global__ __launch_bounds__(512, 2) void gconv4_kernel(const pdse_gconv_desc d) {
+  constexpr bool DUAL = (EPI != PDSE_EPI_LINEAR);
+  constexpr int NBR = DUAL ? 2 : 1, FR = NBR * MT;   // fragments (3 planes each) per K block and workgroup
+  extern __shared__ uint4 ring[];                     // [2 buffers][G4_CH blocks][FR][192]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, h = lane >> 5;
+  const int b = blockIdx.y;
+  const int P = d.Tout * d.Fout;
+  const int p = (blockIdx.x * 8 + wave) * 32 + col;
+  const bool pvalid = p < P;
+  const int t = pvalid ? p / d.Fout : 0;
+  const int j = pvalid ? p - t * d.Fout : 0;
+  const int mtiles = (d.Cout + 31) >> 5;
+  const int mt0 = blockIdx.z * MT;
+
+  const int cbn0 = d.in0.C >> 4, cbn1 = d.in1.C >> 4;                    // 16-channel blocks per source
+  const int cps0 = (cbn0 + G4_CH - 1) / G4_CH, cps1 = (cbn1 + G4_CH - 1) / G4_CH;   // chunks per (source, tap)
+  const int nch0 = d.ntaps * cps0, nch = nch0 + d.ntaps * cps1;
+
+  // Everything about a chunk is wave-uniform; readfirstlane says so to the compiler (without it the source select and the
+  // channel bases were treated as per-lane values and every gather load sat in a waterfall loop)
+  auto uni = [](const int v) { return __builtin_amdgcn_readfirstlane(v); };
+  auto decode = [&](const int ci) {
+    g4_chunk c;
+    c.s = uni(ci >= nch0);
+    const int q = c.s ? ci - nch0 : ci, cps = c.s ? cps1 : cps0, cbn = c.s ? cbn1 : cbn0;
+    c.tap = uni(q / cps);
+    c.cb0 = uni((q - c.tap * cps) * G4_CH);
+    c.n = uni(min(G4_CH, cbn - c.cb0));
+    c.kb0 = uni((c.s ? d.ntaps * cbn0 : 0) + c.tap * cbn + c.cb0);
+    return c;
+  };
+  // A fragments of a chunk -> ring buffer `buf`: one 1 KB piece (= one plane of one fragment) per wave instruction
+  auto dma = [&](const g4_chunk& c, const int buf) {
+    const int npieces = c.n * FR * 3;
+    for (int pc = __builtin_amdgcn_readfirstlane(wave); pc < npieces; pc += 8) {
+      const int i = pc / (FR * 3), rem = pc - i * (FR * 3), f = rem / 3, part = rem - f * 3;
+      const int br = f / MT, m = f - br * MT;
+      if (mt0 + m < mtiles) {   // tiles past Cout keep stale fragments: their accumulators are never stored
+        const uint4* src = reinterpret_cast<const uint4*>(br ? d.w1 : d.w0) + ((size_t)(c.kb0 + i) * mtiles + mt0 + m) * 192 +
+                           part * 64 + lane;
+        glds16_g4(src, ring + ((buf * G4_CH + i) * FR + f) * 192 + part * 64);
+      }
+    }
+  };
+  // B operand of a chunk: raw[i][e] = channel 16 (cb0 + i) + 8h + e of this lane's position at the chunk's tap
+  auto gather = [&](const g4_chunk& c, float (&raw)[G4_CH][8], bool& inb) {
+    const bool s1 = c.s != 0;   // field-by-field scalar selects (a reference to one of two kernel-argument structs is not)
+    const float* const sptr = s1 ? d.in1.ptr : d.in0.ptr;
+    const int64_t ssb = s1 ? d.in1.sb : d.in0.sb, ssc = s1 ? d.in1.sc : d.in0.sc, sst = s1 ? d.in1.st : d.in0.st,
+                  ssf = s1 ? d.in1.sf : d.in0.sf;
+    int dt = 0, df = 0;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {   // kernel-argument table, scalar compares instead of a dynamically indexed load
+      dt = c.tap == k ? d.tap_dt[k] : dt;
+      df = c.tap == k ? d.tap_df[k] : df;
+    }
+    const int tin = t + dt, fin = j * d.sf_in + df;
+    inb = pvalid && fin >= 0 && fin < d.Fin && tin >= 0 && tin < d.Tin;
+    const unsigned off = 4u * (unsigned)((inb ? (int64_t)b * ssb + (int64_t)tin * sst + (int64_t)fin * ssf : 0) + (int64_t)(8 * h) * ssc);
+#pragma unroll
+    for (int i = 0; i < G4_CH; ++i) {
+      if (i < c.n) {   // wave-uniform
+        const float* base = sptr + (int64_t)(16 * (c.cb0 + i)) * ssc;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) raw[i][e] = g4_load(base + (int64_t)e * ssc, off);
+      }
+    }
+  };
+
+  f32x16 acc0[MT], acc1[DUAL ? MT : 1];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      acc0[m][r] = 0.f;
+      if (DUAL) acc1[m][r] = 0.f;
+    }
+  }
+  auto compute = [&](const g4_chunk& c, const float (&raw)[G4_CH][8], const bool inb, const int buf) {
+    const bool elu = uni((c.s ? d.in1.act : d.in0.act) == PDSE_ACT_ELU) != 0;   // GCRN re-applies ELU to the skip half (gcrn.py:152-155)
+#pragma unroll
+    for (int i = 0; i < G4_CH; ++i) {
+      if (i < c.n) {
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = inb ? raw[i][e] : 0.f;
+        if (elu) {   // wave-uniform; exp2-based like the epilogues' ELU (act_c); elu(0) = 0 keeps masked lanes zero
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x[e] = x[e] < 0.f ? fast_exp(x[e]) - 1.0f : x[e];
+        }
+        uint4 b1, b2, b3;
+        split8(x, b1, b2, b3);
+        const uint4* w = ring + ((buf * G4_CH + i) * FR) * 192 + lane;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          acc0[m] = mfma6(w + m * 192, b1, b2, b3, acc0[m]);
+          if constexpr (DUAL) acc1[m] = mfma6(w + (MT + m) * 192, b1, b2, b3, acc1[m]);
+        }
+      }
+    }
+  };
+
+  float rawA[G4_CH][8], rawB[G4_CH][8];
+  bool inbA = false, inbB = false;
+  g4_chunk cA = decode(0), cB = cA;
+  gather(cA, rawA, inbA);
+  dma(cA, 0);
+  __syncthreads();   // DMA and gather of chunk 0 have landed (the fence waits vmcnt(0) while LDS-DMA is in flight)
+  g4_landed(rawA);
+  for (int ci = 0; ci < nch; ci += 2) {
+    const bool hasB = ci + 1 < nch;
+    if (hasB) {      // chunk ci+1: requests and DMA go out before chunk ci's matrix work
+      cB = decode(ci + 1);
+      gather(cB, rawB, inbB);
+      dma(cB, 1);
+    }
+    compute(cA, rawA, inbA, 0);
+    __syncthreads();   // buffer 1 complete; every wave is done reading buffer 0
+    if (!hasB) break;
+    g4_landed(rawB);
+    const bool hasA = ci + 2 < nch;
+    if (hasA) {
+      cA = decode(ci + 2);
+      gather(cA, rawA, inbA);
+      dma(cA, 0);
+    }
+    compute(cB, rawB, inbB, 1);
+    __syncthreads();
+    g4_landed(rawA);
+  }
+  gconv_epilogue<EPI, MT>(d, tail_from_desc(d), acc0, acc1, b, t, j, pvalid, lane, h, mt0, mtiles);
+}
+
+template <int EPI, int MT>
+static int launch4(const pdse_gconv_desc* d, hipStream_t s, const int mtiles) {
+  const int P = d->Tout * d->Fout;
+  const dim3 grid(((P + 31) / 32 + 7) / 8, d->B, (mtiles + MT - 1) / MT), block(512);
+  constexpr int FR = (EPI == PDSE_EPI_LINEAR ? 1 : 2) * MT;
+  const size_t lds = (size_t)2 * G4_CH * FR * 192 * sizeof(uint4);
+  static bool attr_done = false;   // per instantiation
+  if (!attr_done && lds > 64 * 1024) {
+    if (pdse_check_hip(hipFuncSetAttribute((const void*)gconv4_kernel<EPI, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+                       "gconv4 lds attribute")) return 1;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((gconv4_kernel<EPI, MT>), grid, block, lds, s, *d);
+  return pdse_check_launch("gconv4");
+}
+
+// korder 3: LINEAR / GLU, one or two sources of a multiple of 16 channels, no load transform; validated by pdse_gconv_launch
+int pdse_gconv4_launch(const pdse_gconv_desc* d, hipStream_t s) {
+  const bool two = d->in1.C > 0;
+  // lane offsets are 32-bit BYTE offsets from a scalar channel base
+  const long long span0 = 4 * ((long long)d->B * d->in0.sb + 40ll * d->in0.sc), span1 = two ? 4 * ((long long)d->B * d->in1.sb + 40ll * d->in1.sc) : 0;
+  if (!(d->epi == PDSE_EPI_LINEAR || d->epi == PDSE_EPI_GLU) || (d->in0.C & 15) || (d->in1.C & 15) || d->in0.C == 0 || d->cin1 ||
+      d->xf_mode != 0 || d->padrow != nullptr || d->ntaps > 12 || span0 >= (1ll << 32) || span1 >= (1ll << 32) ||
+      (d->epi == PDSE_EPI_GLU && !d->w1)) {
+    pdse_set_error("gconv4: split-bf16 GEMM convolutions need LINEAR / GLU, channel counts in multiples of 16, <= 12 taps, "
+                   "no load transform / pad row, 32-bit gather offsets");
+    return 1;
+  }
+  const int mtiles = (d->Cout + 31) / 32;
+  if (d->epi == PDSE_EPI_GLU) return mtiles >= 2 ? launch4<PDSE_EPI_GLU, 2>(d, s, mtiles) : launch4<PDSE_EPI_GLU, 1>(d, s, mtiles);
+  if (mtiles >= 4) return launch4<PDSE_EPI_LINEAR, 4>(d, s, mtiles);
+  if (mtiles >= 2) return launch4<PDSE_EPI_LINEAR, 2>(d, s, mtiles);
+  return launch4<PDSE_EPI_LINEAR, 1>(d, s, mtiles);
+}

@@ -13,6 +13,7 @@ int pdse_check_hip(hipError_t e, const char* what);
 int pdse_gconv_launch(const pdse_gconv_desc* d, hipStream_t s);
 int pdse_gconv2_launch(const pdse_gconv_desc* d, hipStream_t s);  // korder 1, validated by pdse_gconv_launch
 int pdse_gconv3_launch(const pdse_gconv_desc* d, hipStream_t s);  // korder 2 (split-bf16 BIGLU), validated there too
+int pdse_gconv4_launch(const pdse_gconv_desc* d, hipStream_t s);  // korder 3 (split-bf16 GEMM-shaped LINEAR / GLU)
 int pdse_time_launch(const pdse_time_desc* d, hipStream_t s);
 int pdse_ew_launch(const pdse_ew_desc* d, hipStream_t s);
 int pdse_compand_launch(const pdse_compand_desc* d, hipStream_t s);

@@ -148,6 +148,21 @@ class PlanBase:
             f["nx_w"] = up16(np.stack([P.pack_s3_chain(tl["w"])[0] for tl in nx], 0))
         return f
 
+    def _gconv_weights_s3g(self, w, ntaps, c0, c1):
+        """korder 3 (csrc/gconv4.hip): LINEAR / GLU convolutions as split-bf16 GEMMs, weights streamed through LDS."""
+        ctx = self.ctx
+        up = lambda a: ctx.up(a).data_ptr()   # noqa: E731
+        up16 = lambda a: ctx.up(np.ascontiguousarray(a).view(np.int16), np.int16).data_ptr()   # noqa: E731
+        f = {"korder": 3, "ksteps": ntaps * (c0 + c1) // 2, "w0": up16(P.pack_s3_gemm(w["wk0"], ntaps, c0, c1))}
+        if w.get("wk1") is not None:
+            f["w1"] = up16(P.pack_s3_gemm(w["wk1"], ntaps, c0, c1))
+        for k in ("bias0", "bias1"):
+            if w.get(k) is not None:
+                f[k] = up(w[k])
+        if w.get("post") is not None:
+            f["post_scale"], f["post_shift"] = up(w["post"][0]), up(w["post"][1])
+        return f
+
     def _gconv_weights(self, w, ntaps, c0, c1, epi, cin1, pipelined_ok):
         """Pack and upload the weight side of one gather-GEMM launch; returns {descriptor field: value}.
         w: dict with wk0 [K, Cout] (k-major float64), optional wk1, wk2/wk3 (odd phase), bias0/bias1, post (scale, shift),
@@ -206,7 +221,7 @@ class PlanBase:
               bias1=None, bias1_sb=0, epi=L.EPI_LINEAR, act=L.ACT_NONE, act_slope=0.0,
               padrow=None, padrow_sb=0, padrow_off=0, cin1=False, resid=None, out,
               out_strides, out_off=0, out_cr=1, B, Tout, Fout, tag=TAG_NONE, bias0_off=0, phase1=None, nx=None,
-              bias1_off=0, bias_t0=None, label="gconv", s3=False):
+              bias1_off=0, bias_t0=None, label="gconv", s3=False, s3g=False, has_xf=False):
         """W: callable -> dict of the launch's weight-derived operands (see ``_gconv_weights``); evaluated only when the
         weight bank does not hold this launch yet.  bias0 / bias1 / padrow / bias_t0 here are per-plan DEVICE tensors
         (time-conditioned biases); constant biases travel inside W.
@@ -236,8 +251,13 @@ class PlanBase:
         # split-bf16 instantiations (csrc/gconv3.hip): 32-channel blocks with 4 or 6 taps, the composed encoder stage 1
         s3 = bool(s3) and pipelined_ok and epi == L.EPI_BIGLU and (
             ((c0, c1) == (32, 0) and len(ttaps) in (4, 6)) or ((c0, c1, len(ttaps)) == (2, 2, 10) and phase1 is None))
-        site = "%s:%d:%d:%d:%d:%d:%d:%d" % (label, epi, len(ttaps), c0, c1, Cout, pipelined_ok, s3)
-        if s3:
+        # split-bf16 GEMM form (csrc/gconv4.hip): LINEAR / GLU, channel counts in multiples of 16, no load transform
+        s3g = (bool(s3g) and not s3 and pipelined_ok and epi in (L.EPI_LINEAR, L.EPI_GLU) and not cin1 and not has_xf
+               and c0 > 0 and c0 % 16 == 0 and c1 % 16 == 0 and len(ttaps) <= 12)
+        site = "%s:%d:%d:%d:%d:%d:%d:%d:%d" % (label, epi, len(ttaps), c0, c1, Cout, pipelined_ok, s3, s3g)
+        if s3g:
+            f = self.memo(site, lambda: self._gconv_weights_s3g(W(), len(ttaps), c0, c1))
+        elif s3:
             f = self.memo(site, lambda: self._gconv_weights_s3(W(), len(ttaps), c0 + c1))
         else:
             f = self.memo(site, lambda: self._gconv_weights(W(), len(ttaps), c0, c1, epi, cin1, pipelined_ok))
@@ -783,11 +803,12 @@ class EpsNetPlan(PlanBase):
 class GcrnPlan(PlanBase):
     fused_last = True       # last decoder stage + Linear(161,161) as one persistent launch (pdse_gcrnlast_desc)
     fused_glstm = True      # both LSTM layers + LayerNorm 1 as a layer wavefront, T + 2 launches (pdse_glstm_desc)
+    split_bf16 = True       # gated (transposed) convolutions and the LSTM input projection as split-bf16 GEMMs (csrc/gconv4.hip)
     ENC_C = [2, 16, 32, 64, 128, 256]
     ENC_F = [161, 80, 39, 19, 9, 4]
 
     def __init__(self, ctx, sd, B, T, plan=None):
-        super().__init__(ctx, plan, ns=(id(sd), self.fused_last, self.fused_glstm))
+        super().__init__(ctx, plan, ns=(id(sd), self.fused_last, self.fused_glstm, self.split_bf16))
         self.sd, self.B, self.T = sd, B, T
         a = ctx.alloc
         self.Bp = Bp = (B + 31) // 32 * 32
@@ -818,7 +839,7 @@ class GcrnPlan(PlanBase):
                        W=lambda p=p, wk_fn=wk_fn: dict(wk0=wk_fn(self.w(p + "weight_ih_l0")),
                                                        bias0=self.w(p + "bias_ih_l0") + self.w(p + "bias_hh_l0")),
                        out=self.gx, out_strides=(1, Bp, 0, ost, osf), out_off=g * T * 2048 * Bp, B=B, Tout=Tout, Fout=Fout,
-                       tag=TAG_PRIOR, label=p + "ih")
+                       tag=TAG_PRIOR, label=p + "ih", s3g=self.split_bf16)
 
         def pack_whh():
             whh = np.empty((2, 64, 256, 64), np.float32)
@@ -849,7 +870,7 @@ class GcrnPlan(PlanBase):
                        W=lambda p=p, wk_fn=wk_fn: dict(wk0=wk_fn(self.w(p + "weight_ih_l0")),
                                                        bias0=self.w(p + "bias_ih_l0") + self.w(p + "bias_hh_l0")),
                        out=self.gx, out_strides=(1, Bp, 0, ost, osf), out_off=g * T * 2048 * Bp, B=B, Tout=Tout, Fout=Fout,
-                       tag=TAG_PRIOR, label=p + "ih")
+                       tag=TAG_PRIOR, label=p + "ih", s3g=self.split_bf16)
 
         def pack():
             up = lambda a: self.ctx.up(a).data_ptr()   # noqa: E731
@@ -899,7 +920,8 @@ class GcrnPlan(PlanBase):
                                                       wk1=P.conv_kmat(self.sd[p + ".conv2.weight"], kk),
                                                       bias0=self.w(p + ".conv1.bias"), bias1=self.w(p + ".conv2.bias"),
                                                       post=P.bn_fold(self.sd, "bn%d" % k)),
-                       out=self.e[k - 1], out_strides=nchw_out(co, T, Fout), B=B, Tout=T, Fout=Fout, tag=TAG_PRIOR, label=p)
+                       out=self.e[k - 1], out_strides=nchw_out(co, T, Fout), B=B, Tout=T, Fout=Fout, tag=TAG_PRIOR, label=p,
+                       s3g=self.split_bf16)
             src = self.src(self.e[k - 1], co, *nchw(co, T, Fout))
 
         # grouped LSTM (gcrn.py:22-40)
@@ -959,7 +981,7 @@ class GcrnPlan(PlanBase):
                                    wk1=P.convT_kmat(self.sd[p + ".conv2.weight"], kk), bias0=self.w(p + ".conv1.bias"),
                                    bias1=self.w(p + ".conv2.bias"), post=P.bn_fold(self.sd, "bn%d_t_%d" % (k, br))),
                                out=self.d[n], out_strides=(osb, osc, 0, ost, 2 * osf), out_off=phase, B=B, Tout=T,
-                               Fout=(Fout - phase + 1) // 2, tag=TAG_PRIOR, label="%s.ph%d" % (p, phase))
+                               Fout=(Fout - phase + 1) // 2, tag=TAG_PRIOR, label="%s.ph%d" % (p, phase), s3g=self.split_bf16)
                 Fin = Fout
                 if k > 1:
                     in0 = self.src(self.d[n], co, *nchw(co, T, Fout))
@@ -1051,10 +1073,11 @@ class AiaPlan(PlanBase):
 
     FH = 80  # bins after the stride-2 encoder conv
     fused_gru_input = True   # d_model 32: W_ih x inside the GRU kernel (csrc/aia.hip, gru_kernel<64, true>)
+    split_bf16 = True        # dilated dense blocks and the strided / sub-pixel convolutions as split-bf16 GEMMs (csrc/gconv4.hip)
 
     def __init__(self, ctx, sd, B, T, plan=None, d=32):
         """d: d_model of the transformer layers (32: AIA_Transformer(64, 64); 64: AIA_Transformer_merge(128, 64))."""
-        super().__init__(ctx, plan, ns=(id(sd), d, self.fused_gru_input))
+        super().__init__(ctx, plan, ns=(id(sd), d, self.fused_gru_input, self.split_bf16))
         self.sd, self.B, self.T, self.d = sd, B, T, d
         a = ctx.alloc
         FH = self.FH
@@ -1150,7 +1173,7 @@ class AiaPlan(PlanBase):
                        W=lambda i=i, kk=kk: dict(wk0=P.conv_kmat(self.sd["%s.conv%d.weight" % (p, i)], kk),
                                                  bias0=self.w("%s.conv%d.bias" % (p, i))), Cout=64,
                        out=tmp, out_strides=nchw_out(64, T, F_), B=B, Tout=T, Fout=F_, tag=TAG_PRIOR,
-                       label="%s.conv%d" % (p, i))
+                       label="%s.conv%d" % (p, i), s3g=self.split_bf16)
             self._rowln(tmp, D, 320 * T * F_, 64, F_, "%s.norm%d" % (p, i), "%s.prelu%d" % (p, i),
                         dst_off=(4 - i) * 64 * T * F_)
         return 0  # out4 sits in channel block 0
@@ -1237,7 +1260,7 @@ class AiaPlan(PlanBase):
         self.gconv(in0=self.src(self.D161, 64, *nchw(320, T, F0)), Tin=T, Fin=F0, taps=taps, sf_in=2,
                    W=lambda: dict(wk0=P.conv_kmat(sd[p + ".enc_conv1.weight"], kk), bias0=self.w(p + ".enc_conv1.bias")),
                    Cout=64, out=self.tmp80, out_strides=nchw_out(64, T, FH), B=B, Tout=T, Fout=FH, tag=TAG_PRIOR,
-                   label=p + ".enc_conv1")
+                   label=p + ".enc_conv1", s3g=self.split_bf16)
         self._rowln(self.tmp80, dst, 64 * T * FH, 64, FH, p + ".enc_norm1", p + ".enc_prelu1")
 
     def _aham(self, p, outs, dst):
@@ -1267,7 +1290,7 @@ class AiaPlan(PlanBase):
         self.gconv(in0=self.src(self.D80, 64, *nchw(320, T, FH)), Tin=T, Fin=FH, taps=taps, sf_in=1,
                    W=lambda: dict(wk0=P.conv_kmat(sd[de + ".dec_conv1.conv.weight"], kk), bias0=self.w(de + ".dec_conv1.conv.bias")),
                    Cout=128, out=self.dec_up, out_strides=(64 * T * F0, 1, T * F0, F0, 2), out_cr=64, out_off=1, B=B, Tout=T,
-                   Fout=FH, tag=TAG_PRIOR, label=de + ".dec_conv1")
+                   Fout=FH, tag=TAG_PRIOR, label=de + ".dec_conv1", s3g=self.split_bf16)
         self._rowln(self.dec_up, self.tmp161, 64 * T * F0, 64, F0, de + ".dec_norm1", de + ".dec_prelu1")
         self.gconv(in0=self.src(self.tmp161, 64, *nchw(64, T, F0)), Tin=T, Fin=F0, taps=[(0, 0)], sf_in=1,
                    W=lambda: dict(wk0=self.w(de + ".out_conv.weight")[:, :, 0, 0].T, bias0=self.w(de + ".out_conv.bias")), Cout=1,

@@ -335,3 +335,42 @@ def unpack_s3_chain(packed, mt, K):
             for j in range(8):
                 out[:, 32 * (s >> 1) + rho_bf16(s & 1, j, h)] = f[:, s, h, :, j].reshape(-1)
     return out
+
+
+def s3_gemm_krows(ntaps, c0, c1):
+    """Row order (k = tap*Cin + ci of the k-major weight matrix) of the K blocks of csrc/gconv4.hip: 16 consecutive
+    channels per block, blocks in the order (source, tap, channel block)."""
+    cin = c0 + c1
+    rows = []
+    for cbase, c in ((0, c0), (c0, c1)):
+        for tap in range(ntaps):
+            for cb in range(c // 16):
+                rows.extend(tap * cin + cbase + 16 * cb + np.arange(16))
+    return np.asarray(rows, np.int64)
+
+
+def pack_s3_gemm(wk, ntaps, c0, c1):
+    """wk [ntaps*(c0+c1), Cout] (k-major) -> uint16 [K blocks][ceil(Cout/32)][3 planes][64 lanes][8]."""
+    wk = np.asarray(wk, np.float64).astype(np.float32)
+    K, M = wk.shape
+    assert K == ntaps * (c0 + c1) and c0 % 16 == 0 and c1 % 16 == 0
+    mt = (M + 31) // 32
+    pad = np.zeros((K, mt * 32), np.float32)
+    pad[:, :M] = wk
+    ordered = pad[s3_gemm_krows(ntaps, c0, c1)]                           # [nkb*16, mt*32]
+    nkb = K // 16
+    frag = ordered.reshape(nkb, 2, 8, mt, 32).transpose(0, 3, 1, 4, 2)    # [kb, mt, h, row, j]
+    frag = frag.reshape(nkb, mt, 64, 8)
+    p = split_bf16x3(frag)
+    return np.ascontiguousarray(np.stack(p, 2))                           # [kb, mt, 3, 64, 8]
+
+
+def unpack_s3_gemm(packed, ntaps, c0, c1, M):
+    K = ntaps * (c0 + c1)
+    mt = (M + 31) // 32
+    packed = np.asarray(packed, np.uint16).reshape(K // 16, mt, 3, 2, 32, 8)      # [kb, mt, plane, h, row, j]
+    f = join_bf16x3([packed[:, :, i] for i in range(3)])                          # [kb, mt, h, row, j]
+    ordered = f.transpose(0, 2, 4, 1, 3).reshape(K, mt * 32)                       # k within block = 8h + j
+    out = np.zeros((K, mt * 32), np.float32)
+    out[s3_gemm_krows(ntaps, c0, c1)] = ordered
+    return out[:, :M]

@@ -89,6 +89,13 @@ def run_gconv(d, mem):
             out[rows[rows >= 0]] = wk[rows >= 0]
             assert np.all(wk[rows < 0] == 0)
             return out
+    elif d.korder == 3:   # split-bf16 GEMM-shaped convolution (csrc/gconv4.hip): weights streamed through LDS
+        assert d.epi in (L.EPI_LINEAR, L.EPI_GLU) and not d.cin1 and d.xf_mode == 0
+
+        def unpack(ptr):
+            n = d.ntaps * Cin // 16 * mtiles * 3 * 64 * 8
+            wk = P.unpack_s3_gemm(mem.arr(ptr, n, np.int16).view(np.uint16), d.ntaps, d.in0.C, d.in1.C, mtiles * 32)
+            return wk
     elif d.korder == 2:   # split-bf16 BIGLU block (csrc/gconv3.hip): exact 3-way bf16 splits in bf16 MFMA fragment order
         assert d.epi == L.EPI_BIGLU and Cin in (32, 4) and d.Cout == 32
 

@@ -62,17 +62,21 @@ def test_eps_net_plan_vs_oracle(weights, chained, split, monkeypatch):
     assert rel_l2(net.out, ref) < TOL
 
 
-@pytest.mark.parametrize("fused_glstm", [True, False])
-def test_gcrn_and_diffunet_prior_plans_vs_oracle(weights, fused_glstm, monkeypatch):
+@pytest.mark.parametrize("fused_glstm,split", [(True, True), (False, True), (True, False)])
+def test_gcrn_and_diffunet_prior_plans_vs_oracle(weights, fused_glstm, split, monkeypatch):
     """fused_glstm: both LSTM layers + LayerNorm 1 as one layer-wavefront operator (LayerNorm folded into the layer-2
-    input projection, permuted K order); False: two per-frame LSTM operators with the LayerNorm and projections between."""
+    input projection, permuted K order); False: two per-frame LSTM operators with the LayerNorm and projections between.
+    split: the gated convolutions / input projections packed for the split-bf16 GEMM kernel (korder 3)."""
     nets = pkg("nets")
     monkeypatch.setattr(nets.GcrnPlan, "fused_glstm", fused_glstm)
+    monkeypatch.setattr(nets.GcrnPlan, "split_bf16", split)
     B, T = 2, 10
     x = seeded((B, 2, T, 161), 5)
     ctx = nets.Ctx("cpu")
     net = nets.GcrnPlan(ctx, weights("GCRN"), B, T)
     net.build()
+    n3 = sum(1 for d, _ in net.descs if isinstance(d, pkg("_lib").GconvDesc) and d.korder == 3)
+    assert n3 == ((4 + 16 + (2 if fused_glstm else 4)) if split else 0)   # encoder 2-5, 2 x 4 x 2 decoder phases, projections
     net.x.copy_(x)
     emu.run(net.descs, ctx.all_tensors())
     taps = {}
