@@ -807,7 +807,9 @@ class GcrnPlan(PlanBase):
     ENC_C = [2, 16, 32, 64, 128, 256]
     ENC_F = [161, 80, 39, 19, 9, 4]
 
-    def __init__(self, ctx, sd, B, T, plan=None):
+    def __init__(self, ctx, sd, B, T, plan=None, split_bf16=None):
+        if split_bf16 is not None:
+            self.split_bf16 = bool(split_bf16)
         super().__init__(ctx, plan, ns=(id(sd), self.fused_last, self.fused_glstm, self.split_bf16))
         self.sd, self.B, self.T = sd, B, T
         a = ctx.alloc
@@ -1075,8 +1077,10 @@ class AiaPlan(PlanBase):
     fused_gru_input = True   # d_model 32: W_ih x inside the GRU kernel (csrc/aia.hip, gru_kernel<64, true>)
     split_bf16 = True        # dilated dense blocks and the strided / sub-pixel convolutions as split-bf16 GEMMs (csrc/gconv4.hip)
 
-    def __init__(self, ctx, sd, B, T, plan=None, d=32):
+    def __init__(self, ctx, sd, B, T, plan=None, d=32, split_bf16=None):
         """d: d_model of the transformer layers (32: AIA_Transformer(64, 64); 64: AIA_Transformer_merge(128, 64))."""
+        if split_bf16 is not None:
+            self.split_bf16 = bool(split_bf16)
         super().__init__(ctx, plan, ns=(id(sd), d, self.fused_gru_input, self.split_bf16))
         self.sd, self.B, self.T, self.d = sd, B, T, d
         a = ctx.alloc
@@ -1341,8 +1345,8 @@ class DualAiaPlan(AiaPlan):
     append), and IEEE addition commutes.  The golden vectors of the reference module confirm that the two output
     lists are bit-identical (tests/test_oracle_golden.py), so each layer is evaluated once."""
 
-    def __init__(self, ctx, sd, B, T, plan=None):
-        super().__init__(ctx, sd, B, T, plan, d=64)
+    def __init__(self, ctx, sd, B, T, plan=None, split_bf16=None):
+        super().__init__(ctx, sd, B, T, plan, d=64, split_bf16=split_bf16)
         a = ctx.alloc
         self.mag = a(B, 1, T, F0)
         self.x_mag_en = a(B, 64, T, self.FH)

@@ -39,7 +39,7 @@ class SamplerPipeline:
         :994-995); "feat": the noisy feature / 11 (the branch with neither flag set, :74-75, :972-974; no final add).
         bank: a ``nets.WeightBank`` shared with other pipelines built from the same state_dicts (packed weights are
         uploaded once, every further (B, T) only records descriptors).
-        split_bf16: the eps-net's (and a DiffUNet prior's) BIGLU blocks on the bf16 matrix cores with exact three-way
+        split_bf16: the eps-net's BIGLU blocks and the priors' GEMM-shaped convolutions on the bf16 matrix cores with exact three-way
         operand splits - fp32-level accuracy at 16/6 of the fp32 MFMA rate (csrc/gconv3.hip); None: on for fast sampling,
         off (exact fp32 MFMA) for the full 50-step schedule."""
         if L_ is not None:
@@ -73,13 +73,13 @@ class SamplerPipeline:
 
         self.stft = adopt(nets.StftPlan(ctx, B, L_, plan=self.plan)) if with_signal else None
         if prior_name == "GCRN":
-            self.prior = adopt(nets.GcrnPlan(ctx, prior_sd, B, T, plan=self.plan))
+            self.prior = adopt(nets.GcrnPlan(ctx, prior_sd, B, T, plan=self.plan, split_bf16=split_bf16))
         elif prior_name == "DiffUNet":
             self.prior = adopt(nets.EpsNetPlan(ctx, prior_sd, B, T, time_cond=False, plan=self.plan, split_bf16=split_bf16))
         elif prior_name == "aia_complex_trans_ri":
-            self.prior = adopt(nets.AiaPlan(ctx, prior_sd, B, T, plan=self.plan))
+            self.prior = adopt(nets.AiaPlan(ctx, prior_sd, B, T, plan=self.plan, split_bf16=split_bf16))
         elif prior_name == "dual_aia_trans_merge_crm":
-            self.prior = adopt(nets.DualAiaPlan(ctx, prior_sd, B, T, plan=self.plan))
+            self.prior = adopt(nets.DualAiaPlan(ctx, prior_sd, B, T, plan=self.plan, split_bf16=split_bf16))
         else:
             raise ValueError("prior %r not built (GCRN, DiffUNet, aia_complex_trans_ri, dual_aia_trans_merge_crm)" % prior_name)
         self.eps = adopt(nets.EpsNetPlan(ctx, ddpm_sd, B, T, time_cond=True, nsteps=S, plan=self.plan,

@@ -357,7 +357,10 @@ def test_split_bf16_networks_vs_goldens(L, weights, monkeypatch):
     x = seeded((B, 2, T, 161), g["seed_x"])
     xi = seeded((B, 2, T, 161), g["seed_init"]) * float(g["init_scale"])
     t = torch.from_numpy(g["t"]).to(DEV)
-    out32 = ops.DiffUNet1Op(weights("DiffUNet1"), DEV)(x.to(DEV), xi.to(DEV), t)
+    monkeypatch.setattr(nets.EpsNetPlan, "split_bf16", False)
+    op32 = ops.DiffUNet1Op(weights("DiffUNet1"), DEV)
+    out32 = op32(x.to(DEV), xi.to(DEV), t)
+    assert all(d.korder == 1 for d, _ in op32._plans[(B, T)].descs if isinstance(d, L.GconvDesc))
     monkeypatch.setattr(nets.EpsNetPlan, "split_bf16", True)
     op = ops.DiffUNet1Op(weights("DiffUNet1"), DEV)
     out = op(x.to(DEV), xi.to(DEV), t)
@@ -422,3 +425,27 @@ def test_split_bf16_full_size_b32(L, weights, R):
     print("split-bf16, 50 steps, T=401: vs fp32 CPU oracle %.2e | vs float64 evaluation %.2e | fp32 CPU oracle vs float64 %.2e"
           % (e_ref, e_exact, e_ref_exact))
     assert e_exact < 1e-4 and e_ref < 1e-4 + e_ref_exact
+
+
+def test_split_bf16_gcrn_prior_vs_fp32_kernels_and_goldens(L, weights, monkeypatch):
+    """GCRN's gated convolutions and LSTM input projection as split-bf16 GEMMs (csrc/gconv4.hip, the default) against the
+    goldens and against the exact-fp32 kernels; the pipeline flag reaches the prior (bench.py's fp32_exact pass)."""
+    nets, ops = pkg("nets"), pkg("ops")
+    g = golden("gcrn_small")
+    x = seeded((2, 2, 20, 161), g["seed_x"]).to(DEV)
+    op = ops.GCRNOp(weights("GCRN"), DEV)
+    out = op(x)
+    assert sum(1 for d, _ in op._plans[(2, 20)].descs if isinstance(d, L.GconvDesc) and d.korder == 3) == 22
+    monkeypatch.setattr(nets.GcrnPlan, "split_bf16", False)
+    op32 = ops.GCRNOp(weights("GCRN"), DEV)
+    out32 = op32(x)
+    assert all(d.korder != 3 for d, _ in op32._plans[(2, 20)].descs if isinstance(d, L.GconvDesc))
+    print("GCRN split-bf16 vs golden %.2e | fp32 kernels vs golden %.2e | split vs fp32 kernels %.2e" % (
+        rel_l2(out.cpu(), g["out"]), rel_l2(out32.cpu(), g["out"]), rel_l2(out.cpu(), out32.cpu())))
+    assert rel_l2(out.cpu(), g["out"]) < 2e-5 and rel_l2(out.cpu(), out32.cpu()) < 5e-6
+    monkeypatch.undo()
+    P = pkg("pipeline").SamplerPipeline
+    p32 = P(DEV, "GCRN", weights("GCRN"), weights("DiffUNet1"), 1, T=20, split_bf16=False)
+    assert all(d.korder in (0, 1) for d, _ in p32.descs if isinstance(d, L.GconvDesc))
+    pfull = P(DEV, "GCRN", weights("GCRN"), weights("DiffUNet1"), 1, T=20, fast_sampling=False)
+    assert not pfull.split_bf16 and all(d.korder in (0, 1) for d, _ in pfull.descs if isinstance(d, L.GconvDesc))
