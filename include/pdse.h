@@ -447,6 +447,32 @@ typedef struct pdse_tcm_desc {
   int32_t dil, B, T;
 } pdse_tcm_desc;
 
+/* The same residual block in split-bf16 arithmetic (csrc/tcm2.hip; exact three-way bf16 splits, six products, fp32
+ * accumulation).  The bottleneck tensor travels between launches transformed and split:
+ *   hs [B][2 main|mask][4 kb][2 kg][3 planes][T + 128][8] bf16 = the three bf16 planes of BN(PReLU(conv1(x))) for
+ *      each branch, channel 16*kb + 8*kg + j, frame t at index t + 64; the 64 frames on either side must stay zero
+ *      (the padding of the dilated convolution, dilation <= 32);
+ *   mode 0: x_out = conv2(BN(PReLU(gate(hs)))) + x;  hs_out = split(next block's transforms of conv1_next(x_out));
+ *           hs_out NULL: last block;     mode 1: hs_out from conv1_next(x) alone (the first block's conv1).
+ * Packed operands (prior-diffuse_amd/packing.py):
+ *   wbr [2 main|mask][2 mi][20 K blocks = tap*4 + kb][3][64 lanes][8]   pack_s3_gather per (branch, output tile)
+ *   wc2 [8 mt][4 kb][3][64][8]                                          pack_s3_gather per output tile
+ *   wn1 [2 mo][16 blocks][3][64][8]                                     pack_s3_chain (K order rho_bf16)
+ *   par [64][4 main bias, mask bias, BN scale, BN shift of the gate] | [256] conv2 bias | [64] next conv1 bias |
+ *       [64][4 next block's main scale, shift, mask scale, shift]       (832 floats, all present in either mode) */
+typedef struct pdse_tcm2_desc {
+  const float* x;
+  float* x_out;          /* may alias x */
+  const uint16_t* hs;
+  uint16_t* hs_out;      /* must not alias hs */
+  const uint16_t* wbr;
+  const uint16_t* wc2;
+  const uint16_t* wn1;
+  const float* par;
+  float slope2, slope_main_next, slope_mask_next;
+  int32_t dil, B, T, mode;
+} pdse_tcm2_desc;
+
 /* GroupNorm(1,C) statistics + the AIA layer update (dbaiat.py:142,147-148):
  *   out = base + k1 * gn(row) + k2 * gn(col);  stats scratch [B][4] (sum,sumsq of row | col). */
 typedef struct pdse_gncomb_desc {
@@ -500,7 +526,8 @@ enum pdse_op_kind {
   PDSE_OP_CRM = 18,
   PDSE_OP_GCRNLAST = 19,
   PDSE_OP_MASKLOSS = 20,
-  PDSE_OP_GLSTM = 21
+  PDSE_OP_GLSTM = 21,
+  PDSE_OP_TCM2 = 22
 };
 
 int pdse_abi_version(void);
@@ -531,6 +558,7 @@ int pdse_crm_f32(const pdse_crm_desc* d, pdse_stream_t s);
 int pdse_gcrnlast_f32(const pdse_gcrnlast_desc* d, pdse_stream_t s);
 int pdse_masked_mse_f32(const pdse_maskloss_desc* d, pdse_stream_t s);
 int pdse_glstm_f32(const pdse_glstm_desc* d, pdse_stream_t s);
+int pdse_tcm2_bf16x3(const pdse_tcm2_desc* d, pdse_stream_t s);
 
 /* plans: a recorded operator sequence replayed by one call (and capturable in a hipGraph) */
 typedef struct pdse_plan pdse_plan;

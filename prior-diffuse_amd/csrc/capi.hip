@@ -42,6 +42,7 @@ union pdse_any_desc {
   pdse_qsample_desc qsample;
   pdse_transpose_desc transpose;
   pdse_tcm_desc tcm;
+  pdse_tcm2_desc tcm2;
   pdse_crm_desc crm;
   pdse_gcrnlast_desc gcrnlast;
   pdse_maskloss_desc maskloss;
@@ -98,6 +99,7 @@ static int op_size(int kind) {
     case PDSE_OP_QSAMPLE: return (int)sizeof(pdse_qsample_desc);
     case PDSE_OP_TRANSPOSE: return (int)sizeof(pdse_transpose_desc);
     case PDSE_OP_TCM: return (int)sizeof(pdse_tcm_desc);
+    case PDSE_OP_TCM2: return (int)sizeof(pdse_tcm2_desc);
     case PDSE_OP_CRM: return (int)sizeof(pdse_crm_desc);
     case PDSE_OP_GCRNLAST: return (int)sizeof(pdse_gcrnlast_desc);
     case PDSE_OP_MASKLOSS: return (int)sizeof(pdse_maskloss_desc);
@@ -130,6 +132,7 @@ static int launch_op(const pdse_op& op, hipStream_t s) {
     case PDSE_OP_GCRNLAST: return pdse_gcrnlast_launch(&op.d.gcrnlast, s);
     case PDSE_OP_MASKLOSS: return pdse_maskloss_launch(&op.d.maskloss, s);
     case PDSE_OP_GLSTM: return pdse_glstm_launch(&op.d.glstm, s);
+    case PDSE_OP_TCM2: return pdse_tcm2_launch(&op.d.tcm2, s);
     default: pdse_set_error("plan: unknown op kind"); return 1;
   }
 }
@@ -162,6 +165,7 @@ int pdse_crm_f32(const pdse_crm_desc* d, pdse_stream_t s) { return pdse_crm_laun
 int pdse_gcrnlast_f32(const pdse_gcrnlast_desc* d, pdse_stream_t s) { return pdse_gcrnlast_launch(d, (hipStream_t)s); }
 int pdse_masked_mse_f32(const pdse_maskloss_desc* d, pdse_stream_t s) { return pdse_maskloss_launch(d, (hipStream_t)s); }
 int pdse_glstm_f32(const pdse_glstm_desc* d, pdse_stream_t s) { return pdse_glstm_launch(d, (hipStream_t)s); }
+int pdse_tcm2_bf16x3(const pdse_tcm2_desc* d, pdse_stream_t s) { return pdse_tcm2_launch(d, (hipStream_t)s); }
 
 int pdse_plan_create(pdse_plan** out) {
   if (!out) {

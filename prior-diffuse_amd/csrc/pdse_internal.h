@@ -35,4 +35,5 @@ int pdse_crm_launch(const pdse_crm_desc* d, hipStream_t s);
 int pdse_gcrnlast_launch(const pdse_gcrnlast_desc* d, hipStream_t s);
 int pdse_maskloss_launch(const pdse_maskloss_desc* d, hipStream_t s);
 int pdse_glstm_launch(const pdse_glstm_desc* d, hipStream_t s);
+int pdse_tcm2_launch(const pdse_tcm2_desc* d, hipStream_t s);
 #endif

@@ -1,0 +1,435 @@
+// tcm2.hip — the fused TCM residual block of tcm.hip (model/diff3.py:215-257) in split-bf16 arithmetic
+// (gconv_common.h: an fp32 value is the exact sum of three bf16, a product its six leading cross terms on the bf16
+// matrix cores with fp32 accumulation), restructured around what bounded the fp32 kernel: its waves spent 58 % of
+// their life in s_waitcnt (4 waves, each walking a long chain of weight loads with 4 groups in flight).
+//
+//   * 8 waves per workgroup;
+//   * the 64-channel bottleneck tensor h travels between launches ALREADY transformed and split: the producer (phase
+//     C of the previous block) applies both branches' PReLU + BatchNorm and stores the three bf16 planes in the
+//     B-operand order of v_mfma_f32_32x32x16_bf16, frames innermost:
+//         hs[B][2 branch][4 kb][2 kg][3 plane][T + 128][8]      (frame t at index t + 64; the margins stay zero)
+//     so a tap outside [0,T) is an address, not a select, a wave's load of one fragment plane is two runs of 512
+//     contiguous bytes, and the dilated gather costs no VALU work at all;
+//   * what bounds the block is the CU's read path from L2 (measured here: 32 B/clk per CU): a workgroup reads all of
+//     a block's weights (432 KB as bf16 planes) whatever its frame count, and the first version of this kernel (one
+//     output tile per wave, 32 frames per workgroup, h rows of 768 B gathered at 16 B per lane) pulled 960 KB + its
+//     line overfetch per CU through that path in phase A alone: 30,000 of its 52,000 cycles, the same 37 us per
+//     block as the fp32 kernel.  Hence: every operand fragment is loaded by exactly one wave of the workgroup, and a
+//     workgroup covers 64 frames (NT = 2) once 32-frame workgroups would outnumber the CUs;
+//   * A  wave (branch, kq): both output tiles of one branch over a quarter of K = 5 taps x 64 channels (5 K blocks;
+//        each A fragment feeds NT frame tiles, each B fragment both output tiles), operands two K blocks ahead in
+//        registers; the quarters meet in LDS in two steps (fixed order);
+//     G  gate -> PReLU -> BN by all 512 threads, split once, written as the B operand of conv2 (rows padded to 144 B);
+//     B  conv2: wave w = output channels 32w..32w+31 (+ bias + residual), x' stored;
+//     C  next block's conv1: that accumulator tile is split in registers and used as the B operand (K order
+//        rho_bf16, packing.pack_s3_chain); eight partial sums meet in LDS in a fixed order; the result is transformed
+//        for the NEXT block's two branches, split and stored as hs_out (512 contiguous bytes per 32 lanes).
+//   * MODE 1 is phase C alone on x (the conv1 of the first block of the stack).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "gconv_common.h"
+#include "pdse.h"
+#include "pdse_internal.h"
+
+#define REQ(cond, msg)     \
+  do {                     \
+    if (!(cond)) {         \
+      pdse_set_error(msg); \
+      return 1;            \
+    }                      \
+  } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int HS_PAD = 64;         // zero frames in front of frame 0 of hs (2 x the largest dilation), and behind frame T-1
+constexpr int GL_ROW = 144;        // bytes of one frame of one plane of the conv2 operand in LDS (128 + 16 pad)
+
+__device__ __forceinline__ float prelu2(float v, float slope) { return v > 0.f ? v : slope * v; }
+
+__device__ __forceinline__ f32x16 mfma6r(const uint4 (&a)[3], const uint4 (&b)[3], f32x16 acc) {
+  acc = mfma_bf16(a[0], b[2], acc);
+  acc = mfma_bf16(a[2], b[0], acc);
+  acc = mfma_bf16(a[1], b[1], acc);
+  acc = mfma_bf16(a[0], b[1], acc);
+  acc = mfma_bf16(a[1], b[0], acc);
+  acc = mfma_bf16(a[0], b[0], acc);
+  return acc;
+}
+
+// four values -> their three bf16 planes, 8 bytes each (element i in half i & 1 of dword i >> 1)
+__device__ __forceinline__ void split4(const float (&x)[4], uint2& p1, uint2& p2, uint2& p3) {
+  uint32_t q[3][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const float a = x[2 * i], b = x[2 * i + 1];
+    const uint32_t a1 = __float_as_uint(a) & 0xffff0000u, b1 = __float_as_uint(b) & 0xffff0000u;
+    const float ra = a - __uint_as_float(a1), rb = b - __uint_as_float(b1);
+    const uint32_t a2 = __float_as_uint(ra) & 0xffff0000u, b2 = __float_as_uint(rb) & 0xffff0000u;
+    const float sa = ra - __uint_as_float(a2), sb = rb - __uint_as_float(b2);
+    q[0][i] = (a1 >> 16) | b1;
+    q[1][i] = (a2 >> 16) | b2;
+    q[2][i] = (__float_as_uint(sa) >> 16) | (__float_as_uint(sb) & 0xffff0000u);
+  }
+  p1 = make_uint2(q[0][0], q[0][1]);
+  p2 = make_uint2(q[1][0], q[1][1]);
+  p3 = make_uint2(q[2][0], q[2][1]);
+}
+
+__device__ long long* g_trace = nullptr;   // PDSE_TCM2_TRACE=1 (diagnostic): [workgroup][wave][8] clock stamps
+#define STAMP(i)                                                                                       \
+  do {                                                                                                 \
+    if (trace && lane == 0) trace[((blockIdx.y * gridDim.x + blockIdx.x) * 8 * TW + wv) * 8 + (i)] = (i) == 0 ? wall_clock64() : clock64(); \
+  } while (0)
+
+// NT = frame tiles of 32 per wave, TW = teams of 8 waves per workgroup (workgroup = 32 NT TW frames of one utterance).
+// The teams of a workgroup run the same instruction stream on neighbouring frames between the same barriers, so
+// their weight requests reach the CU's L1 together.
+template <int MODE, int NT, int TW>
+__global__ __launch_bounds__(512 * TW, NT == 1 ? 4 : 2) void tcm2_kernel(const pdse_tcm2_desc d) {
+  // par: [64][4] main bias, mask bias, BN scale, BN shift of the gate | [256] conv2 bias | [64] next conv1 bias |
+  //      [64][4] next block's input transforms: main scale, shift, mask scale, shift
+  __shared__ __attribute__((aligned(16))) float par[832];
+  __shared__ float part_[TW * NT][4][64][33];                                    // A: [2 branch + kh]; C: partial sums of four waves
+  __shared__ __attribute__((aligned(16))) char gls_[TW * NT][3 * 32 * GL_ROW];   // conv2's B operand: [plane][frame][64 + 8 bf16]
+  const int tid = threadIdx.x & 511;                                             // within the team
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int team = wv >> 3, wave = wv & 7;
+  auto part = part_ + team * NT;
+  auto gls = gls_ + team * NT;
+  const int col = lane & 31, hh = lane >> 5;
+  const int b = blockIdx.y, t0 = (blockIdx.x * TW + team) * (32 * NT), T = d.T, TP = T + 2 * HS_PAD;
+  const bool chain = d.hs_out != nullptr;
+  long long* trace = g_trace;
+  STAMP(0);
+  STAMP(1);
+
+  // the parameter table is requested first and written to LDS behind the first batch of operand requests
+  const float par_a = d.par[tid], par_b = d.par[512 + (tid < 320 ? tid : 0)];
+  auto store_par = [&]() {
+    if (TW > 1 && team) return;
+    par[tid] = par_a;
+    if (tid < 320) par[512 + tid] = par_b;
+  };
+
+  bool tlive[NT];
+  int lrow[NT];        // lane offset of accumulator rows rho(r,h) in [256][T]
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const int t = t0 + 32 * n + col;
+    tlive[n] = t < T;
+    lrow[n] = 4 * hh * T + (tlive[n] ? t : T - 1);
+  }
+  f32x16 a2[NT];
+  if constexpr (MODE == 0) {
+    // -------------------------------------------------------------- A: dilated branches
+    const int br = wave & 1, kq = wave >> 1;
+    const size_t plane = (size_t)TP * 16;                      // bytes of one fragment plane of one (kb, kg)
+    const char* hbase = (const char*)d.hs + (size_t)(b * 2 + br) * 24 * plane;   // wave-uniform
+    int roff[NT][5];    // lane offsets of the five taps: this lane half's planes + frame (the margins are zeros)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int k = 0; k < 5; ++k)
+        roff[n][k] = hh * 3 * (int)plane + (tlive[n] ? t0 + 32 * n + col + (k - 2) * d.dil + HS_PAD : 0) * 16;
+    const uint4* WA = (const uint4*)d.wbr + ((size_t)(br * 2 * 20 + 5 * kq) * 3) * 64 + lane;   // [br][2 mi][20][3][64]
+    constexpr int D = 2;   // K blocks in flight (a slot is requested again as soon as its MFMAs have issued)
+    uint4 qa[D][2][3], qb[D][NT][3];
+    // workgroups walk their five K blocks in an order rotated by the frame tile index: neighbours in time do not ask L2
+    // for the same weight lines at the same moment (-6 % on phase A); a function of the frame tile only, so an
+    // utterance's result does not depend on its place in the batch
+    const int js = (int)(blockIdx.x % 5);
+    auto request = [&](int i) {
+      const int slot = i % D;
+      const int j = (i + js) % 5;
+      const int kbi = 5 * kq + j;                              // wave-uniform: tap = kbi >> 2, channel block = kbi & 3
+      const char* hq = hbase + (size_t)(kbi & 3) * 6 * plane;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) qa[slot][mi][p] = WA[(size_t)((mi * 20 + j) * 3 + p) * 64];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        int ro = roff[n][0];
+#pragma unroll
+        for (int k = 1; k < 5; ++k) ro = (kbi >> 2) == k ? roff[n][k] : ro;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) qb[slot][n][p] = *(const uint4*)(hq + p * plane + ro);
+      }
+    };
+#pragma unroll
+    for (int j = 0; j < D; ++j) request(j);
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][n][r] = 0.f;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[mi][n] = mfma6r(qa[j % D][mi], qb[j % D][n], acc[mi][n]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (j + D < 5) request(j + D);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    STAMP(2);
+    // conv2 weights and the residual: in flight across the gate phase
+    const uint4* W2 = (const uint4*)d.wc2 + ((size_t)wave * 4 * 3) * 64 + lane;
+    uint4 w2[4][3];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) w2[kb][p] = W2[(size_t)(kb * 3 + p) * 64];
+    const float* xb = d.x + ((size_t)b * 256 + 32 * wave) * T;
+    float xres[NT][16];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xres[n][r] = (xb + (size_t)((r & 3) + 8 * (r >> 2)) * T)[lrow[n]];
+    __builtin_amdgcn_sched_barrier(0);
+    store_par();
+    // K quarters 2, 3 -> LDS; quarters 0, 1 add theirs: part[n][2 br + (kq & 1)] = quarter (kq & 1) + quarter (kq & 1) + 2
+    if (kq >= 2) {
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) part[n][br * 2 + (kq & 1)][32 * mi + rho(r, hh)][col] = acc[mi][n][r];
+    }
+    __syncthreads();
+    if (kq < 2) {
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float* pr = &part[n][br * 2 + kq][32 * mi + rho(r, hh)][col];
+            *pr = acc[mi][n][r] + *pr;
+          }
+    }
+    __syncthreads();   // partial sums and the parameter table
+    STAMP(3);
+
+    // -------------------------------------------------------------- G: gate, PReLU, BN, split
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int f = tid & 31, cg = tid >> 5;
+      float v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = 4 * cg + i;
+        const f32x4 gp = *(const f32x4*)&par[4 * c];
+        const float m = (part[n][0][c][f] + part[n][1][c][f]) + gp[0];
+        const float k = (part[n][2][c][f] + part[n][3][c][f]) + gp[1];
+        v[i] = gp[2] * prelu2(m * sigmoid_f(k), d.slope2) + gp[3];
+      }
+      uint2 p1, p2, p3;
+      split4(v, p1, p2, p3);
+      char* g = gls[n] + f * GL_ROW + cg * 8;
+      *(uint2*)g = p1;
+      *(uint2*)(g + 32 * GL_ROW) = p2;
+      *(uint2*)(g + 64 * GL_ROW) = p3;
+    }
+    __syncthreads();
+    STAMP(4);
+
+    // -------------------------------------------------------------- B: conv2 + bias + residual
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a2[n][r] = 0.f;
+      const char* gb = gls[n] + col * GL_ROW + hh * 16;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        uint4 bp[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) bp[p] = *(const uint4*)(gb + p * 32 * GL_ROW + kb * 32);
+        a2[n] = mfma6r(w2[kb], bp, a2[n]);
+      }
+    }
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      const f32x4 bb = *(const f32x4*)&par[256 + 32 * wave + 8 * r4 + 4 * hh];   // rows (r&3) = 0..3 are consecutive
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a2[n][4 * r4 + i] += bb[i] + xres[n][4 * r4 + i];
+    }
+  } else {
+    const float* xb = d.x + ((size_t)b * 256 + 32 * wave) * T;
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a2[n][r] = (xb + (size_t)((r & 3) + 8 * (r >> 2)) * T)[lrow[n]];
+    store_par();
+  }
+
+  STAMP(5);
+  // next conv1's weights: requested before x' is stored
+  uint4 wn[2][2][3];
+  if (chain) {
+    const uint4* WN = (const uint4*)d.wn1 + ((size_t)(2 * wave) * 3) * 64 + lane;   // [2 mo][16 blocks][3][64]
+#pragma unroll
+    for (int mo = 0; mo < 2; ++mo)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) wn[mo][s][p] = WN[(size_t)((mo * 16 + s) * 3 + p) * 64];
+  }
+  if constexpr (MODE == 0) {
+    float* xo = d.x_out + ((size_t)b * 256 + 32 * wave) * T;
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+      if (tlive[n]) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) (xo + (size_t)((r & 3) + 8 * (r >> 2)) * T)[lrow[n]] = a2[n][r];
+      }
+  }
+  if (!chain) return;   // uniform over the grid
+
+  // ---------------------------------------------------------------- C: next block's conv1 on the accumulator tile
+  f32x16 a1[NT][2];
+#pragma unroll
+  for (int n = 0; n < NT; ++n)
+#pragma unroll
+    for (int mo = 0; mo < 2; ++mo)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a1[n][mo][r] = 0.f;
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      float xv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xv[j] = a2[n][8 * s + j];
+      uint4 bp[3];
+      split8(xv, bp[0], bp[1], bp[2]);
+      a1[n][0] = mfma6r(wn[0][s], bp, a1[n][0]);
+      a1[n][1] = mfma6r(wn[1][s], bp, a1[n][1]);
+    }
+  STAMP(6);
+  // part is free: every thread passed the barrier behind G
+  if (wave >= 4) {
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int mo = 0; mo < 2; ++mo)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part[n][wave - 4][32 * mo + rho(r, hh)][col] = a1[n][mo][r];
+  }
+  __syncthreads();
+  if (wave < 4) {
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int mo = 0; mo < 2; ++mo)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float* pr = &part[n][wave][32 * mo + rho(r, hh)][col];
+          *pr = a1[n][mo][r] + *pr;
+        }
+  }
+  __syncthreads();
+  // 8 channels (one fragment half) x one frame per thread: 16-byte stores, 512 contiguous bytes per 32 lanes
+  for (int item = tid; item < NT * 256; item += 512) {
+    const int n = item >> 8, cg = (item >> 5) & 7, f = item & 31;
+    const int t = t0 + 32 * n + f;
+    if (t < T) {
+      float vm[8], vk[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int c = 8 * cg + i;
+        const float s = ((part[n][0][c][f] + part[n][1][c][f]) + (part[n][2][c][f] + part[n][3][c][f])) + par[512 + c];
+        const f32x4 xp = *(const f32x4*)&par[576 + 4 * c];
+        vm[i] = xp[0] * prelu2(s, d.slope_main_next) + xp[1];
+        vk[i] = xp[2] * prelu2(s, d.slope_mask_next) + xp[3];
+      }
+      const size_t plane = (size_t)TP * 16;
+      char* ho = (char*)d.hs_out + ((size_t)(b * 2) * 24 + (size_t)cg * 3) * plane + (size_t)(t + HS_PAD) * 16;
+      uint4 p1, p2, p3;
+      split8(vm, p1, p2, p3);
+      *(uint4*)ho = p1;
+      *(uint4*)(ho + plane) = p2;
+      *(uint4*)(ho + 2 * plane) = p3;
+      split8(vk, p1, p2, p3);
+      ho += 24 * plane;
+      *(uint4*)ho = p1;
+      *(uint4*)(ho + plane) = p2;
+      *(uint4*)(ho + 2 * plane) = p3;
+    }
+  }
+  STAMP(7);
+}
+
+template <int NT, int TW>
+int launch_tcm2(const pdse_tcm2_desc* d, hipStream_t s) {
+  const dim3 grid((d->T + 32 * NT * TW - 1) / (32 * NT * TW), d->B);
+  static const bool tracing = getenv("PDSE_TCM2_TRACE") != nullptr;
+  static long long* tbuf = nullptr;
+  const size_t nst = (size_t)grid.x * grid.y * 64 * TW;
+  if (tracing) {
+    if (!tbuf) {
+      hipMalloc(&tbuf, 65536 * 64 * sizeof(long long));
+      hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &tbuf, sizeof(tbuf));
+    }
+    hipMemsetAsync(tbuf, 0, nst * sizeof(long long), s);
+  }
+  if (d->mode == 1) hipLaunchKernelGGL((tcm2_kernel<1, NT, TW>), grid, dim3(512 * TW), 0, s, *d);
+  else hipLaunchKernelGGL((tcm2_kernel<0, NT, TW>), grid, dim3(512 * TW), 0, s, *d);
+  if (tracing) {   // diagnostic: per-phase shader-clock averages over all waves, and the spread of start times (100 MHz clock)
+    hipStreamSynchronize(s);
+    long long* h = (long long*)malloc(nst * sizeof(long long));
+    hipMemcpy(h, tbuf, nst * sizeof(long long), hipMemcpyDeviceToHost);
+    double sum[8] = {0};
+    long long w0 = -1, w1 = 0;
+    const size_t nw = nst / 8;
+    for (size_t i = 0; i < nw; ++i) {
+      const long long* q = h + i * 8;
+      if (w0 < 0 || q[0] < w0) w0 = q[0];
+      if (q[0] > w1) w1 = q[0];
+      for (int k = 2; k < 8; ++k) sum[k] += q[k] ? (double)(q[k] - q[1]) : 0.0;
+    }
+    fprintf(stderr, "tcm2 trace mode %d NT %d TW %d dil %d: start spread %.2f us; cycles since wave start:", d->mode, NT, TW, d->dil, (w1 - w0) * 0.01);
+    for (int k = 2; k < 8; ++k) fprintf(stderr, " %.0f", sum[k] / nw);
+    fprintf(stderr, "\n");
+    free(h);
+  }
+  return pdse_check_launch("tcm2");
+}
+
+}  // namespace
+
+int pdse_tcm2_launch(const pdse_tcm2_desc* d, hipStream_t s) {
+  REQ(d && d->x && d->par, "tcm2: null pointer");
+  REQ(d->mode == 0 || d->mode == 1, "tcm2: mode is 0 (residual block) or 1 (input convolution only)");
+  REQ(d->B > 0 && d->B <= 65535 && d->T > 0 && d->dil > 0 && 2 * d->dil <= HS_PAD, "tcm2: bad sizes (dilation <= 32)");
+  REQ(!d->hs_out || d->wn1, "tcm2: the chained conv1 needs its weights");
+  if (d->mode == 1) {
+    REQ(d->hs_out, "tcm2: mode 1 writes hs_out");
+  } else {
+    REQ(d->hs && d->x_out && d->wbr && d->wc2, "tcm2: null pointer");
+    REQ(d->hs_out != d->hs, "tcm2: hs_out must not alias hs (other workgroups gather from hs)");
+  }
+  // workgroup shape 10 NT + TW.  Measured at B=32, T=401 (us per forward, 18 blocks): 11 -> 592, 21 (64 frames, two
+  // tiles per wave) -> 730, 12 (64 frames, two teams of 8 waves) -> 769: the shapes that halve the weight bytes per
+  // CU lose more to their longer dependent chains / simultaneous identical requests.  PDSE_TCM2_SHAPE: ablation.
+  static const int force = getenv("PDSE_TCM2_SHAPE") ? atoi(getenv("PDSE_TCM2_SHAPE")) : 0;
+  const int shape = force ? force : 11;
+  switch (shape) {
+    case 12: return launch_tcm2<1, 2>(d, s);
+    case 21: return launch_tcm2<2, 1>(d, s);
+    default: return launch_tcm2<1, 1>(d, s);
+  }
+}

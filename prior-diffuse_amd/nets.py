@@ -61,6 +61,12 @@ class Ctx:
         (self.bank.keep if self._banking else self.keep).append(t)
         return t
 
+    def alloc_u16(self, *shape):
+        """Zeroed 16-bit storage (bf16 planes travel as integers; torch has no uint16 arithmetic and needs none)."""
+        t = torch.zeros(*shape, dtype=torch.int16, device=self.device)
+        self.keep.append(t)
+        return t
+
     def all_tensors(self):
         """Everything a descriptor of this context may point at (tests replay descriptors on these)."""
         return list(self.keep) + list(self.bank.keep)
@@ -324,6 +330,7 @@ class EpsNetPlan(PlanBase):
     # BIGLU blocks on the bf16 matrix cores with exact 3-way operand splits (csrc/gconv3.hip): fp32-level accuracy
     # (same goldens, same tolerances) at 16/6 of the fp32 MFMA rate.  False: v_mfma_f32_32x32x2_f32 throughout.
     split_bf16 = True
+    split_tcm = True        # (with split_bf16 and fused_tcm) TCM blocks on the bf16 matrix cores too (csrc/tcm2.hip)
     NSLOT = 20  # 15 stages + en1 real-row bias + 4 composed encoder-stage-1 biases (l/r x frame >= 1 / frame 0)
 
     def __init__(self, ctx, sd, B, T, time_cond=True, nsteps=1, plan=None, table=None, with_pre=None, split_bf16=None):
@@ -333,7 +340,8 @@ class EpsNetPlan(PlanBase):
         if split_bf16 is not None:
             self.split_bf16 = bool(split_bf16)
         super().__init__(ctx, plan, ns=(id(sd), bool(time_cond), bool(with_pre), self.fused_tcm, self.chain_conv1,
-                                        self.compose_stage1, self.split_bf16, None if table is None else id(table)))
+                                        self.compose_stage1, self.split_bf16, self.split_tcm,
+                                        None if table is None else id(table)))
         self.sd, self.B, self.T, self.time_cond, self.nsteps = sd, B, T, time_cond, nsteps
         self.with_pre = with_pre
         a = ctx.alloc
@@ -348,6 +356,8 @@ class EpsNetPlan(PlanBase):
         self.en = [a(B, 64, T, f) for f in self.ENC_F[1:5]] + [a(B, 64, 4, T)]  # en5 stored [B,64,4,T]
         self.tcm_a, self.tcm_b = a(B, 256, T), a(B, 256, T)
         self.tcm_h, self.tcm_g = a(B, 64, T), a(B, 64, T)
+        # the same bottleneck tensor as the split-bf16 blocks exchange it (pdse_tcm2_desc.hs; its margins stay zero)
+        self.tcm_hs = [ctx.alloc_u16(*P.tcm2_hs_shape(B, T)) for _ in range(2)]
         self.dec = [a(B, 64, T, 79), a(B, 64, T, 79)]  # ping-pong decoder activations (largest F=79)
         if time_cond:
             self.tsteps = a(nsteps, B, zero=True)
@@ -670,6 +680,44 @@ class EpsNetPlan(PlanBase):
         d.dil, d.B, d.T = dil, self.B, self.T
         self.add(d, TAG_TCM)
 
+    def _residual_split(self, p, dil, xin, xout, hin, hout, p_next, mode=0):
+        """``_residual_fused`` in split-bf16 arithmetic (csrc/tcm2.hip): the bottleneck tensor travels as the split
+        planes of both branches' BN(PReLU(.)), so a block also carries the NEXT block's input transforms.
+        mode 1: only ``p_next``'s conv1 on ``xin`` (the first block of the stack)."""
+        def make():
+            up16 = lambda a: self.ctx.up(np.asarray(a).view(np.int16), np.int16).data_ptr()   # noqa: E731
+            par = np.zeros(832, np.float32)
+            f = dict(slope2=0.0, slope_main_next=0.0, slope_mask_next=0.0)
+            if mode == 0:
+                kmain, kmask = self._tcm_branch_mats(p)
+                s2, h2 = P.bn_fold(self.sd, p + ".conv2.1")
+                par[:256] = np.stack([self.w(p + ".mainbranch.2.bias"), self.w(p + ".maskbranch.2.bias"), s2, h2], 1).reshape(-1)
+                par[256:512] = self.w(p + ".conv2.2.bias")
+                f.update(wbr=up16(P.pack_tcm2_branch(kmain, kmask)),
+                         wc2=up16(P.pack_tcm2_conv2(self.w(p + ".conv2.2.weight")[:, :, 0].T)),
+                         slope2=float(self.w(p + ".conv2.0.weight")[0]))
+            if p_next is not None:
+                sm, hm = P.bn_fold(self.sd, p_next + ".mainbranch.1")
+                sk, hk = P.bn_fold(self.sd, p_next + ".maskbranch.1")
+                par[512:576] = self.w(p_next + ".conv1.bias")
+                par[576:] = np.stack([sm, hm, sk, hk], 1).reshape(-1)
+                f.update(wn1=up16(P.pack_s3_chain(self.w(p_next + ".conv1.weight")[:, :, 0])),
+                         slope_main_next=float(self.w(p_next + ".mainbranch.0.weight")[0]),
+                         slope_mask_next=float(self.w(p_next + ".maskbranch.0.weight")[0]))
+            f["par"] = self.ctx.up(par).data_ptr()
+            return f
+
+        d = L.Tcm2Desc()
+        for k, v in self.memo("%s.split%d" % (p if mode == 0 else p_next, mode), make).items():
+            setattr(d, k, v)
+        d.x = xin.data_ptr()
+        if mode == 0:
+            d.x_out, d.hs = xout.data_ptr(), hin.data_ptr()
+        if p_next is not None:
+            d.hs_out = hout.data_ptr()
+        d.dil, d.B, d.T, d.mode = dil, self.B, self.T, mode
+        self.add(d, TAG_TCM)
+
     def build_step(self, step=0, x=None, x_init=None, out=None):
         """Append one forward.  x / x_init / out default to the plan's own buffers.
 
@@ -752,6 +800,14 @@ class EpsNetPlan(PlanBase):
             for p, dil in names:
                 self._residual(p, dil, cur, nxt)
                 cur, nxt = nxt, (self.tcm_b if nxt is self.tcm_a else self.tcm_a)
+        elif self.split_bf16 and self.split_tcm:
+            hcur, hnxt = self.tcm_hs
+            self._residual_split(None, 1, cur, None, None, hcur, names[0][0], mode=1)
+            for n, (p, dil) in enumerate(names):
+                p_next = names[n + 1][0] if n + 1 < len(names) else None
+                self._residual_split(p, dil, cur, nxt, hcur, hnxt, p_next)
+                cur, nxt = nxt, (self.tcm_b if nxt is self.tcm_a else self.tcm_a)
+                hcur, hnxt = hnxt, hcur
         else:
             # one launch per block; each also produces the next block's conv1 output (h ping-pongs: halo reads)
             hcur, hnxt = self.tcm_h, self.tcm_g

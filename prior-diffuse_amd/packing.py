@@ -337,6 +337,58 @@ def unpack_s3_chain(packed, mt, K):
     return out
 
 
+# split-bf16 TCM residual block (csrc/tcm2.hip, include/pdse.h: pdse_tcm2_desc)
+TCM2_HS_PAD = 64           # zero frames on either side of hs (2 x the largest dilation)
+
+
+def tcm2_hs_shape(B, T):
+    """hs (uint16): [B][2 branch][4 kb][2 kg][3 planes][T + 2 pad][8], channel 16 kb + 8 kg + j, frame t at t + pad."""
+    return (B, 2, 4, 2, 3, T + 2 * TCM2_HS_PAD, 8)
+
+
+def pack_tcm2_branch(k_main, k_mask):
+    """k_* [320, 64] (row = tap*64 + channel) -> uint16 [2 main|mask][2 mi][20 blocks][3][64][8]."""
+    return np.ascontiguousarray(np.stack([np.stack([pack_s3_gather(np.asarray(k)[:, 32 * mi:32 * mi + 32], 5, 64)
+                                                    for mi in range(2)]) for k in (k_main, k_mask)]))
+
+
+def unpack_tcm2_branch(packed):
+    packed = np.asarray(packed, np.uint16).reshape(2, 2, 20, 3, 64, 8)
+    return [np.concatenate([unpack_s3_gather(packed[br, mi], 5, 64) for mi in range(2)], axis=1) for br in range(2)]
+
+
+def pack_tcm2_conv2(k2):
+    """k2 [64, 256] (row = gate channel) -> uint16 [8 mt][4 kb][3][64][8]."""
+    return np.ascontiguousarray(np.stack([pack_s3_gather(np.asarray(k2)[:, 32 * mt:32 * mt + 32], 1, 64) for mt in range(8)]))
+
+
+def unpack_tcm2_conv2(packed):
+    packed = np.asarray(packed, np.uint16).reshape(8, 4, 3, 64, 8)
+    return np.concatenate([unpack_s3_gather(packed[mt], 1, 64) for mt in range(8)], axis=1)
+
+
+def tcm2_split_h(v_main, v_mask):
+    """Transformed bottleneck tensors [B, 64, T] of the two branches -> hs uint16 (tcm2_hs_shape; margins zero)."""
+    B, C, T = v_main.shape
+    hs = np.zeros(tcm2_hs_shape(B, T), np.uint16)
+    for br, v in enumerate((v_main, v_mask)):
+        p = split_bf16x3(np.asarray(v, np.float32).reshape(B, 4, 2, 8, T).transpose(0, 1, 2, 4, 3))   # [B, kb, kg, T, j]
+        for i in range(3):
+            hs[:, br, :, :, i, TCM2_HS_PAD:TCM2_HS_PAD + T, :] = p[i]
+    return hs
+
+
+def tcm2_join_h(hs, B, T):
+    """Inverse of tcm2_split_h: (v_main, v_mask) float32 [B, 64, T]; asserts the zero margins."""
+    hs = np.asarray(hs, np.uint16).reshape(tcm2_hs_shape(B, T))
+    assert not hs[..., :TCM2_HS_PAD, :].any() and not hs[..., TCM2_HS_PAD + T:, :].any(), "hs: the margins must stay zero"
+    out = []
+    for br in range(2):
+        v = join_bf16x3([hs[:, br, :, :, i, TCM2_HS_PAD:TCM2_HS_PAD + T, :] for i in range(3)])    # [B, kb, kg, T, j]
+        out.append(np.ascontiguousarray(v.transpose(0, 1, 2, 4, 3).reshape(B, 64, T)))
+    return out
+
+
 def s3_gemm_krows(ntaps, c0, c1):
     """Row order (k = tap*Cin + ci of the k-major weight matrix) of the K blocks of csrc/gconv4.hip: 16 consecutive
     channels per block, blocks in the order (source, tap, channel block)."""

@@ -470,6 +470,39 @@ def run_tcm(d, mem):
     mem.arr(d.x_out, B * 256 * T)[:] = xo.astype(np.float32).reshape(-1)
 
 
+def run_tcm2(d, mem):
+    """pdse_tcm2_desc: the same block on split operands; h travels as the bf16 planes of both branches' transforms."""
+    B, T, dil = d.B, d.T, d.dil
+    par = mem.arr(d.par, 832)
+    u16 = lambda ptr, n: mem.arr(ptr, n, np.int16).view(np.uint16)   # noqa: E731
+    x = mem.arr(d.x, B * 256 * T).reshape(B, 256, T).astype(np.float64)
+    if d.mode == 0:
+        km = P.unpack_tcm2_branch(u16(d.wbr, 2 * 2 * 20 * 3 * 64 * 8))
+        v = P.tcm2_join_h(u16(d.hs, int(np.prod(P.tcm2_hs_shape(B, T)))), B, T)
+        pre = []
+        for which in range(2):
+            vp = np.zeros((B, 64, T + 4 * dil))
+            vp[:, :, 2 * dil:2 * dil + T] = v[which]
+            cols = np.concatenate([vp[:, :, k * dil:k * dil + T] for k in range(5)], axis=1)
+            pre.append(np.einsum("bkt,ko->bot", cols, km[which].astype(np.float64)))
+        gp = par[:256].reshape(64, 4)
+        g = (pre[0] + gp[:, 0][None, :, None]) * _sig(pre[1] + gp[:, 1][None, :, None])
+        g = np.where(g > 0, g, np.float32(d.slope2) * g) * gp[:, 2][None, :, None] + gp[:, 3][None, :, None]
+        g = g.astype(np.float32).astype(np.float64)             # the kernel splits the fp32 value
+        k2 = P.unpack_tcm2_conv2(u16(d.wc2, 8 * 4 * 3 * 64 * 8)).astype(np.float64)
+        xo = np.einsum("bkt,ko->bot", g, k2) + par[256:512][None, :, None] + x
+        mem.arr(d.x_out, B * 256 * T)[:] = xo.astype(np.float32).reshape(-1)
+    else:
+        xo = x
+    if d.hs_out:
+        w1 = P.unpack_s3_chain(u16(d.wn1, 2 * 16 * 3 * 64 * 8), 2, 256).astype(np.float64)
+        ho = (np.einsum("bkt,ok->bot", xo.astype(np.float32).astype(np.float64), w1) + par[512:576][None, :, None]).astype(np.float32)
+        xn = par[576:].reshape(64, 4)
+        vm = xn[:, 0][None, :, None] * np.where(ho > 0, ho, np.float32(d.slope_main_next) * ho) + xn[:, 1][None, :, None]
+        vk = xn[:, 2][None, :, None] * np.where(ho > 0, ho, np.float32(d.slope_mask_next) * ho) + xn[:, 3][None, :, None]
+        mem.arr(d.hs_out, int(np.prod(P.tcm2_hs_shape(B, T))), np.int16)[:] = P.tcm2_split_h(vm.astype(np.float32), vk.astype(np.float32)).view(np.int16).reshape(-1)
+
+
 def run_gcrnlast(d, mem):
     """pdse_gcrnlast_desc: gated ConvTranspose 32 -> 1 (1,3)/stride 2 + BN + ELU + Linear(161,161)."""
     B, T = d.B, d.T
@@ -493,7 +526,7 @@ def run_gcrnlast(d, mem):
     flat[idx] = res
 
 
-RUNNERS = {L.GcrnLastDesc: run_gcrnlast, L.TcmDesc: run_tcm, L.GconvDesc: run_gconv, L.TimeDesc: run_time, L.EwDesc: run_ew, L.CompandDesc: run_compand,
+RUNNERS = {L.GcrnLastDesc: run_gcrnlast, L.TcmDesc: run_tcm, L.Tcm2Desc: run_tcm2, L.GconvDesc: run_gconv, L.TimeDesc: run_time, L.EwDesc: run_ew, L.CompandDesc: run_compand,
            L.WavprepDesc: run_wavprep, L.OlaDesc: run_ola, L.SigmaDesc: run_sigma, L.LnDesc: run_ln,
            L.LstmDesc: run_lstm, L.GlstmDesc: run_glstm}
 

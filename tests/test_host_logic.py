@@ -46,6 +46,8 @@ def test_eps_net_plan_vs_oracle(weights, chained, split, monkeypatch):
     assert n_conv1 == (2 if chained else 16)          # chained: only decoder stage 5 x 2 (encoder stage 1 is composed)
     n_split = sum(1 for d, _ in net.descs if isinstance(d, pkg("_lib").GconvDesc) and d.korder == 2)
     assert n_split == (15 if split else 0)            # encoder stages 1-5 + 2 x 5 decoder stages
+    n_tcm2 = sum(1 for d, _ in net.descs if isinstance(d, pkg("_lib").Tcm2Desc))
+    assert n_tcm2 == (19 if split else 0)             # the first block's conv1 + 18 residual blocks (csrc/tcm2.hip)
     x, xi = seeded((B, 2, T, 161), 3), seeded((B, 2, T, 161), 4) * 0.3
     t = torch.tensor([4.086654, 22.992493])
     net.x.copy_(x)
@@ -60,6 +62,10 @@ def test_eps_net_plan_vs_oracle(weights, chained, split, monkeypatch):
         assert rel_l2(net.en[0], taps["en_list"][0]) < TOL
     assert rel_l2(net.en[4].permute(0, 1, 3, 2), taps["en_list"][4]) < TOL
     assert rel_l2(net.out, ref) < TOL
+    if split:                                          # the split bottleneck tensors keep their zero margins
+        Pk = pkg("packing")
+        for hs in net.tcm_hs:
+            Pk.tcm2_join_h(hs.numpy().view(np.uint16), B, T)
 
 
 @pytest.mark.parametrize("fused_glstm,split", [(True, True), (False, True), (True, False)])
@@ -136,7 +142,7 @@ def test_step_descriptors_are_cloned_not_repacked(weights):
     L = pkg("_lib")
     for a, b in zip(first, second):
         assert type(a) is type(b)
-        if isinstance(a, L.TcmDesc):                       # fused TCM blocks carry no time bias: identical clones
+        if isinstance(a, (L.TcmDesc, L.Tcm2Desc)):         # fused TCM blocks carry no time bias: identical clones
             assert bytes(a) == bytes(b)
             continue
         assert a.w0 == b.w0 and a.out == b.out

@@ -149,3 +149,24 @@ def test_masked_loss_and_q_sample_restatements():
     ab = torch.tensor(np.cumprod(1 - np.array(params.noise_schedule)).astype(np.float32))[t].view(2, 1, 1, 1)
     assert torch.equal(R.q_sample(lab, ini, t, noi, params.noise_schedule, "deltamu"),
                        ab ** 0.5 * lab + (1.0 - ab) ** 0.5 * (noi + ini))
+
+
+def test_split_tcm_operands_round_trip():
+    """csrc/tcm2.hip operands: weights as bf16 fragment planes, the bottleneck tensor as frames-innermost planes."""
+    P = pkg("packing")
+    rng = np.random.default_rng(5)
+    km, kk = (rng.standard_normal((320, 64)).astype(np.float32) for _ in range(2))
+    packed = P.pack_tcm2_branch(km, kk)
+    assert packed.shape == (2, 2, 20, 3, 64, 8) and packed.dtype == np.uint16
+    back = P.unpack_tcm2_branch(packed)
+    assert np.array_equal(back[0], km) and np.array_equal(back[1], kk)       # the three planes sum to the fp32 weight
+    k2 = rng.standard_normal((64, 256)).astype(np.float32)
+    assert np.array_equal(P.unpack_tcm2_conv2(P.pack_tcm2_conv2(k2)), k2)
+    a, b = (rng.standard_normal((3, 64, 9)).astype(np.float32) for _ in range(2))
+    hs = P.tcm2_split_h(a, b)
+    assert hs.shape == P.tcm2_hs_shape(3, 9) == (3, 2, 4, 2, 3, 9 + 128, 8)
+    x, y = P.tcm2_join_h(hs, 3, 9)
+    assert np.array_equal(x, a) and np.array_equal(y, b)
+    hs[0, 0, 0, 0, 0, 3, 0] = 1                                               # a write into the margin is caught
+    with pytest.raises(AssertionError):
+        P.tcm2_join_h(hs, 3, 9)

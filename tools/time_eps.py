@@ -35,6 +35,8 @@ def run(split, B=32, T=401):
         if isinstance(d, L.GconvDesc) and d.epi == L.EPI_BIGLU:
             print("  BIGLU korder %d taps %2d dual %d nx %d C2 %2d  %3d x %3d positions: %7.1f us" % (
                 d.korder, d.ntaps, 1 if d.w2 else 0, d.nx_n, d.C2, d.Tout, d.Fout, m * 1e3))
+        if isinstance(d, L.Tcm2Desc):
+            print("  TCM split mode %d dil %2d: %6.1f us" % (d.mode, d.dil, m * 1e3))
     tcm = sum(m for (d, tag), m in zip(net.descs, best) if tag == nets.TAG_TCM)
     print("  TCM %.1f us; whole forward %.3f ms" % (tcm * 1e3, tot))
 
