@@ -23,6 +23,7 @@
 //     split-bf16 tail image (accumulator tiles are re-split in registers and used as B operands, k order rho_bf16).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "pdse.h"
@@ -196,8 +197,12 @@ __global__ __launch_bounds__(1024, 4) void gconv3_in4_kernel(const pdse_gconv_de
 // PF: request every tap's activations before the K loop (16 NT registers); false: one tap in flight.
 // PERSIST: the workgroup walks rounds blockIdx.x, blockIdx.x + gridDim.x, ... of its batch item (image filled once); false:
 // one round per workgroup - the 16-wave form has no registers left for the loop-carried state (32 spills, 181 -> 200 us).
+__device__ long long* g_trace3 = nullptr;   // PDSE_S3_TRACE=1 (diagnostic): [workgroup][wave][8] clock sums of the persistent loop
+
 template <int NT, int P1MASK, bool NX, int WV, bool PF = (WV != 16), bool PERSIST = (WV != 16)>
 __global__ __launch_bounds__(64 * WV, WV / 4) void gconv3_kernel(const pdse_gconv_desc d) {
+  long long* const trace = g_trace3;
+  const long long c_start = trace ? clock64() : 0;
   constexpr int NB = 2 * NT, NT1 = popc3(P1MASK), NB1 = 2 * NT1;
   extern __shared__ uint4 img[];
   const int tid = threadIdx.x;
@@ -372,14 +377,18 @@ __global__ __launch_bounds__(64 * WV, WV / 4) void gconv3_kernel(const pdse_gcon
     pos_t ps;
     float raw[NT][16];
     int rd = blockIdx.x;
+    const long long c_fill = trace ? clock64() : 0;
+    long long c_k = 0, c_r = 0, c_e = 0, n_r = 0;
     if (rd < nrounds) {
       locate(rd, ps);
       request_all(ps, raw);
     }
     while (rd < nrounds) {
+      const long long c0 = trace ? clock64() : 0;
       zero_acc();
       __builtin_amdgcn_sched_barrier(0);   // every request of this round is out before its K loop starts
       kloop_all(ps.inb_mask, raw);
+      const long long c1 = trace ? clock64() : 0;
       const int t = ps.t, j = ps.j;
       const bool pvalid = ps.pvalid;
       rd += gridDim.x;
@@ -388,7 +397,24 @@ __global__ __launch_bounds__(64 * WV, WV / 4) void gconv3_kernel(const pdse_gcon
         request_all(ps, raw);
       }
       __builtin_amdgcn_sched_barrier(0);   // ... and the next round's before this round's tail
+      const long long c2 = trace ? clock64() : 0;
       epilogue(t, j, pvalid);
+      if (trace) {
+        const long long c3 = clock64();
+        c_k += c1 - c0;
+        c_r += c2 - c1;
+        c_e += c3 - c2;
+        ++n_r;
+      }
+    }
+    if (trace && lane == 0) {
+      long long* q = trace + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * WV + wave) * 8;
+      q[0] = c_fill - c_start;
+      q[1] = c_k;
+      q[2] = c_r;
+      q[3] = c_e;
+      q[4] = n_r;
+      q[5] = clock64() - c_start;
     }
   } else {
     auto round = [&](const int rd) {
@@ -423,6 +449,12 @@ static int launch3(const pdse_gconv_desc* d, hipStream_t s) {
   if (gx > rounds || !PERSIST) gx = rounds;
   if (gx < 1) gx = 1;
   const dim3 grid(gx, d->B, 1), block(64 * WV);
+  static const bool tracing = getenv("PDSE_S3_TRACE") != nullptr;
+  static long long* tbuf = nullptr;
+  if (tracing && !tbuf) {
+    hipMalloc(&tbuf, (size_t)1 << 22);
+    hipMemcpyToSymbol(HIP_SYMBOL(g_trace3), &tbuf, sizeof(tbuf));
+  }
   const size_t lds = (size_t)s3_blocks(NT, P1MASK, d->C2, d->nx_n) * 192 * sizeof(uint4) + S3_FLOATS * sizeof(float);
   if (lds > 160 * 1024) {
     pdse_set_error("gconv3: LDS image too large");
@@ -434,7 +466,20 @@ static int launch3(const pdse_gconv_desc* d, hipStream_t s) {
     if (pdse_check_hip(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "gconv3 lds attribute")) return 1;
     attr_done = true;
   }
+  if (tracing) hipMemsetAsync(tbuf, 0, (size_t)gx * d->B * WV * 64, s);
   hipLaunchKernelGGL((gconv3_kernel<NT, P1MASK, NX, WV, PF, PERSIST>), grid, block, lds, s, *d);
+  if (tracing && PERSIST && PF) {   // diagnostic: averages over all waves of the persistent loop's phases, in shader clocks
+    hipStreamSynchronize(s);
+    const size_t nw = (size_t)gx * d->B * WV;
+    long long* h = (long long*)malloc(nw * 64);
+    hipMemcpy(h, tbuf, nw * 64, hipMemcpyDeviceToHost);
+    double sum[6] = {0};
+    for (size_t i = 0; i < nw; ++i)
+      for (int k = 0; k < 6; ++k) sum[k] += (double)h[i * 8 + k];
+    fprintf(stderr, "gconv3 trace NT %d P1MASK %d NX %d C2 %d %dx%d: fill %.0f | per round: kloop %.0f request %.0f tail %.0f | rounds %.2f total %.0f\n",
+            NT, P1MASK, (int)NX, d->C2, d->Tout, d->Fout, sum[0] / nw, sum[1] / sum[4], sum[2] / sum[4], sum[3] / sum[4], sum[4] / nw, sum[5] / nw);
+    free(h);
+  }
   return pdse_check_launch("gconv3");
 }
 

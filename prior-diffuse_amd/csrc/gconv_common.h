@@ -111,19 +111,24 @@ __device__ __forceinline__ f32x16 mfma_bf16(const uint4& a, const uint4& b, cons
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.v, B.v, c, 0, 0, 0);
 }
 
-// x[0..7] -> three planes of 8 bf16 (element j in the low / high half of dword j >> 1), x == p1 + p2 + p3 exactly
+// x[0..7] -> three planes of 8 bf16 (element j in the low / high half of dword j >> 1), x == p1 + p2 + p3 exactly.
+// 11 VALU instructions per pair of values: two masked residuals each, and one v_perm_b32 per plane picks the high
+// halves of the pair (the bf16 of a truncation IS the high half, masked or not); 15 per pair with shift / or packing.
+// Two thirds of the VALU instructions of a block kernel's tail are this function, yet a quarter fewer of them moved
+// the tail by 5 % only (22.4k -> 21.1k cycles per round, PDSE_S3_TRACE): the tail is a serial chain of split ->
+// fragment read -> six dependent MFMAs, not an issue-bound stream.
 __device__ __forceinline__ void split8(const float (&x)[8], uint4& p1, uint4& p2, uint4& p3) {
   uint32_t q1[4], q2[4], q3[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const float a = x[2 * i], b = x[2 * i + 1];
-    const uint32_t a1 = __float_as_uint(a) & 0xffff0000u, b1 = __float_as_uint(b) & 0xffff0000u;
-    const float ra = a - __uint_as_float(a1), rb = b - __uint_as_float(b1);
-    const uint32_t a2 = __float_as_uint(ra) & 0xffff0000u, b2 = __float_as_uint(rb) & 0xffff0000u;
-    const float sa = ra - __uint_as_float(a2), sb = rb - __uint_as_float(b2);
-    q1[i] = (a1 >> 16) | b1;
-    q2[i] = (a2 >> 16) | b2;
-    q3[i] = (__float_as_uint(sa) >> 16) | (__float_as_uint(sb) & 0xffff0000u);
+    const float ra = a - __uint_as_float(__float_as_uint(a) & 0xffff0000u);
+    const float rb = b - __uint_as_float(__float_as_uint(b) & 0xffff0000u);
+    const float sa = ra - __uint_as_float(__float_as_uint(ra) & 0xffff0000u);
+    const float sb = rb - __uint_as_float(__float_as_uint(rb) & 0xffff0000u);
+    q1[i] = __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
+    q2[i] = __builtin_amdgcn_perm(__float_as_uint(rb), __float_as_uint(ra), 0x07060302u);
+    q3[i] = __builtin_amdgcn_perm(__float_as_uint(sb), __float_as_uint(sa), 0x07060302u);
   }
   p1 = make_uint4(q1[0], q1[1], q1[2], q1[3]);
   p2 = make_uint4(q2[0], q2[1], q2[2], q2[3]);
@@ -155,6 +160,23 @@ __device__ __forceinline__ f32x16 chain_s3(const uint4* w, const f32x16& X, f32x
     split8(x, b1, b2, b3);
     acc = mfma6(w + s * 192, b1, b2, b3, acc);
   }
+  return acc;
+}
+
+// The same with the operand split once and used for several output tiles: p[k-block][plane]
+__device__ __forceinline__ void split16(const f32x16& X, uint4 (&p)[2][3]) {
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = X[8 * s + j];
+    split8(x, p[s][0], p[s][1], p[s][2]);
+  }
+}
+
+__device__ __forceinline__ f32x16 chain_s3p(const uint4* w, const uint4 (&p)[2][3], f32x16 acc) {
+#pragma unroll
+  for (int s = 0; s < 2; ++s) acc = mfma6(w + s * 192, p[s][0], p[s][1], p[s][2], acc);
   return acc;
 }
 
@@ -415,6 +437,21 @@ __device__ __forceinline__ f32x16 nx_tile(const pdse_tail& tl, const int i, cons
   return Z;
 }
 
+struct nx_operand_f32 {
+  float Y[2][16];
+};
+__device__ __forceinline__ nx_operand_f32 nx_operand(const pdse_tail&, const float (&Y)[2][16]) {
+  nx_operand_f32 o;
+#pragma unroll
+  for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o.Y[m2][r] = Y[m2][r];
+  return o;
+}
+__device__ __forceinline__ f32x16 nx_tile(const pdse_tail& tl, const int i, const nx_operand_f32& o, const int lane) {
+  return nx_tile(tl, i, o.Y, lane);
+}
+
 // ---- the same tail on split-bf16 operands (overloads selected by the tail image type)
 template <typename Sink>
 __device__ __forceinline__ void biglu_tail_values(const pdse_gconv_desc& d, const pdse_tail_s3& tl, const f32x16& accL,
@@ -439,11 +476,13 @@ __device__ __forceinline__ void biglu_tail_values(const pdse_gconv_desc& d, cons
     v = v * tl.ps[0] + tl.pt[0];
     sink(0, 0, v > 0.f ? v : slope * v);
   } else {
+    uint4 gp[2][3];     // the gate is split once for both output tiles
+    split16(G, gp);
 #pragma unroll
     for (int m2 = 0; m2 < 2; ++m2) {
       const int c0 = 32 * m2 + 4 * h;
       f32x16 O = ld16(tl.bc2 + c0);
-      O = chain_s3(tl.wc2 + m2 * 384 + lane, G, O);
+      O = chain_s3p(tl.wc2 + m2 * 384 + lane, gp, O);
       const f32x16 vs = ld16(tl.ps + c0), vt = ld16(tl.pt + c0);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -474,6 +513,31 @@ __device__ __forceinline__ f32x16 nx_tile(const pdse_tail_s3& tl, const int i, c
   return nx_tile_acc(tl, i, Y, lane, Z);
 }
 
+// the block output split once for every chained tile of the launch (up to three: next stage's H, two skip halves)
+struct nx_operand_s3 {
+  uint4 p[2][2][3];
+};
+__device__ __forceinline__ nx_operand_s3 nx_operand(const pdse_tail_s3&, const float (&Y)[2][16]) {
+  nx_operand_s3 o;
+#pragma unroll
+  for (int m2 = 0; m2 < 2; ++m2) {
+    f32x16 X;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) X[r] = Y[m2][r];
+    split16(X, o.p[m2]);
+  }
+  return o;
+}
+__device__ __forceinline__ f32x16 nx_tile(const pdse_tail_s3& tl, const int i, const nx_operand_s3& o, const int lane) {
+  f32x16 Z;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) Z[r] = 0.f;
+  const uint4* w = tl.nxw + (size_t)i * 768 + lane;
+#pragma unroll
+  for (int m2 = 0; m2 < 2; ++m2) Z = chain_s3p(w + m2 * 384, o.p[m2], Z);
+  return Z;
+}
+
 // Single-phase BIGLU tail with chained next-stage 1x1 convolutions (pdse.h: nx_*); out_cr == 1, C2 == 64.
 template <typename TL>
 __device__ __forceinline__ void biglu_nx_epilogue(const pdse_gconv_desc& d, const TL& tl, const f32x16& a0,
@@ -487,10 +551,11 @@ __device__ __forceinline__ void biglu_nx_epilogue(const pdse_gconv_desc& d, cons
     Y[m2][r] = v;
     if (keep) obase[(int64_t)(32 * m2 + 4 * h) * cstep + (int64_t)PDSE_KR(r) * cstep] = v;
   }, t == 0);
+  const auto yop = nx_operand(tl, Y);
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     if (i >= d.nx_n) break;
-    const f32x16 Z = nx_tile(tl, i, Y, lane);
+    const f32x16 Z = nx_tile(tl, i, yop, lane);
     const int64_t sc = d.nx_sc[i];
     const int64_t rowbase = (int64_t)b * d.nx_sb[i] + (int64_t)j * d.nx_sf[i] + (int64_t)(4 * h) * sc;
     const int64_t off = rowbase + (int64_t)t * d.nx_st[i] + d.nx_off[i];
