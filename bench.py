@@ -259,7 +259,7 @@ def main():
     # split-bf16 mode: an fp32-equivalent FMA costs six bf16 MFMA products, so the roof of the algorithmic FLOP rate is the
     # dense bf16 peak / 6 (2.5 PF / 6); the TCM blocks inside the family still run on the fp32 matrix cores
     peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if args.split_bf16 else FP32_MFMA_PEAK_TFLOPS
-    roofline = {"bound": "mfma", "kernel": ("gconv3_kernel (split-bf16 BIGLU blocks) + tcm_block_kernel" if args.split_bf16 else
+    roofline = {"bound": "mfma", "kernel": ("gconv3_kernel (split-bf16 BIGLU blocks) + tcm2_kernel" if args.split_bf16 else
                                             "gconv2_kernel + tcm_block_kernel") + " (eps-net: BiConvGLU/BiConvTransGLU/TCM launches)",
                 "achieved": round(achieved, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
                 "peak_note": ("dense bf16 MFMA 2500 TFLOP/s / 6 products per fp32-equivalent multiply-add" if args.split_bf16

@@ -19,7 +19,7 @@ def load(path):
 
 
 def short(n):
-    m = re.match(r"void (gconv[23]?_kernel)<(.*)>\(", n)
+    m = re.match(r"void (?:\(anonymous namespace\)::)?(gconv[234]?_kernel|tcm2_kernel)<(.*)>\(", n)
     if m:
         return m.group(1).replace("_kernel", "") + "<" + m.group(2).replace("false", "F").replace("true", "T").replace(" ", "") + ">"
     return re.sub(r"\(.*", "", n)[:30]
@@ -50,7 +50,7 @@ i1 = [k for k, n in enumerate(names) if n.startswith("compand") and k > i0][0]
 rd = wr = 0.0
 n = 0
 for k in range(i0 + 1, i1):
-    if "gconv" in names[k] or "tcm_block" in names[k]:
+    if "gconv" in names[k] or "tcm_block" in names[k] or "tcm2_kernel" in names[k]:
         rd += f[ids[k]].get("FETCH_SIZE", 0) * 1024
         wr += w[idw[k]].get("WRITE_SIZE", 0) * 1024
         n += 1
