@@ -16,6 +16,7 @@
 //   * every (branch, tile) accumulator of the wave reuses the split B operand: 6 x branches x MT MFMAs per block.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "pdse.h"
@@ -49,15 +50,52 @@ __device__ __forceinline__ void g4_landed(float (&raw)[G4_CH][8]) {
     for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(raw[i][e]));
 }
 
+// A fragments are read from the ring with ds_read_b128 written as inline asm too: the compiler cannot tell the ring
+// buffer being read from the one an LDS-DMA in flight is filling, and put s_waitcnt vmcnt(0) in front of every K
+// block's ring reads - each chunk then waited for the NEXT chunk's DMA and gathers before its first MFMA.  The chunk
+// barrier orders the DMA of a buffer before its reads; the wait below orders the reads before their use.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // a register quad the inline asm can name (uint4 is a struct)
+__device__ __forceinline__ void g4_lds_read3(const unsigned addr, u32x4 (&a)[3]) {
+  asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:1024\n\tds_read_b128 %2, %3 offset:2048"
+               : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2])
+               : "v"(addr)
+               : "memory");
+}
+template <int N>
+__device__ __forceinline__ void g4_lds_wait(u32x4 (&a)[N][3]) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) asm volatile("" : "+v"(a[i][p]));
+}
+__device__ __forceinline__ f32x16 g4_mfma6(const u32x4 (&a)[3], const uint4& b1, const uint4& b2, const uint4& b3, f32x16 acc) {
+  const uint4 a1 = make_uint4(a[0][0], a[0][1], a[0][2], a[0][3]), a2 = make_uint4(a[1][0], a[1][1], a[1][2], a[1][3]),
+              a3 = make_uint4(a[2][0], a[2][1], a[2][2], a[2][3]);
+  acc = mfma_bf16(a1, b3, acc);
+  acc = mfma_bf16(a3, b1, acc);
+  acc = mfma_bf16(a2, b2, acc);
+  acc = mfma_bf16(a1, b2, acc);
+  acc = mfma_bf16(a2, b1, acc);
+  acc = mfma_bf16(a1, b1, acc);
+  return acc;
+}
+
 struct g4_chunk {
   int s, tap, cb0, n, kb0;   // source, tap, first 16-channel block, blocks in the chunk, first K block in the packed weights
 };
 
+__device__ long long* g_trace4 = nullptr;   // PDSE_G4_TRACE=1 (diagnostic): [workgroup][wave][8] clock sums
+
 template <int EPI, int MT>
 __global__ __launch_bounds__(512, 2) void gconv4_kernel(const pdse_gconv_desc d) {
+  long long* const trace = g_trace4;
+  const long long c_start = trace ? clock64() : 0;
+  long long c_req = 0, c_cmp = 0, c_bar = 0;
   constexpr bool DUAL = (EPI != PDSE_EPI_LINEAR);
   constexpr int NBR = DUAL ? 2 : 1, FR = NBR * MT;   // fragments (3 planes each) per K block and workgroup
   extern __shared__ uint4 ring[];                     // [2 buffers][G4_CH blocks][FR][192]
+  const unsigned ring_base = (unsigned)(uintptr_t)ring;   // LDS byte address (the low half of the flat address)
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int col = lane & 31, h = lane >> 5;
@@ -146,13 +184,18 @@ __global__ __launch_bounds__(512, 2) void gconv4_kernel(const pdse_gconv_desc d)
 #pragma unroll
           for (int e = 0; e < 8; ++e) x[e] = x[e] < 0.f ? fast_exp(x[e]) - 1.0f : x[e];
         }
+        // the block's fragments are requested first; the split runs under their LDS latency
+        u32x4 af[FR][3];
+        const unsigned wa = ring_base + (unsigned)((((buf * G4_CH + i) * FR) * 192 + lane) * 16);
+#pragma unroll
+        for (int f = 0; f < FR; ++f) g4_lds_read3(wa + f * (192 * 16), af[f]);
         uint4 b1, b2, b3;
         split8(x, b1, b2, b3);
-        const uint4* w = ring + ((buf * G4_CH + i) * FR) * 192 + lane;
+        g4_lds_wait(af);
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-          acc0[m] = mfma6(w + m * 192, b1, b2, b3, acc0[m]);
-          if constexpr (DUAL) acc1[m] = mfma6(w + (MT + m) * 192, b1, b2, b3, acc1[m]);
+          acc0[m] = g4_mfma6(af[m], b1, b2, b3, acc0[m]);
+          if constexpr (DUAL) acc1[m] = g4_mfma6(af[MT + m], b1, b2, b3, acc1[m]);
         }
       }
     }
@@ -165,15 +208,21 @@ __global__ __launch_bounds__(512, 2) void gconv4_kernel(const pdse_gconv_desc d)
   dma(cA, 0);
   __syncthreads();   // DMA and gather of chunk 0 have landed (the fence waits vmcnt(0) while LDS-DMA is in flight)
   g4_landed(rawA);
+  const long long c_pro = trace ? clock64() : 0;
   for (int ci = 0; ci < nch; ci += 2) {
     const bool hasB = ci + 1 < nch;
+    const long long k0 = trace ? clock64() : 0;
     if (hasB) {      // chunk ci+1: requests and DMA go out before chunk ci's matrix work
       cB = decode(ci + 1);
       gather(cB, rawB, inbB);
       dma(cB, 1);
     }
+    const long long k1 = trace ? clock64() : 0;
     compute(cA, rawA, inbA, 0);
+    const long long k2 = trace ? clock64() : 0;
     __syncthreads();   // buffer 1 complete; every wave is done reading buffer 0
+    const long long k3 = trace ? clock64() : 0;
+    c_req += k1 - k0, c_cmp += k2 - k1, c_bar += k3 - k2;
     if (!hasB) break;
     g4_landed(rawB);
     const bool hasA = ci + 2 < nch;
@@ -182,11 +231,26 @@ __global__ __launch_bounds__(512, 2) void gconv4_kernel(const pdse_gconv_desc d)
       gather(cA, rawA, inbA);
       dma(cA, 0);
     }
+    const long long k4 = trace ? clock64() : 0;
     compute(cB, rawB, inbB, 1);
+    const long long k5 = trace ? clock64() : 0;
     __syncthreads();
+    const long long k6 = trace ? clock64() : 0;
+    c_req += k4 - k3, c_cmp += k5 - k4, c_bar += k6 - k5;
     g4_landed(rawA);
   }
+  const long long c_loop = trace ? clock64() : 0;
   gconv_epilogue<EPI, MT>(d, tail_from_desc(d), acc0, acc1, b, t, j, pvalid, lane, h, mt0, mtiles);
+  if (trace && lane == 0) {
+    long long* q = trace + ((size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + wave) * 8;
+    q[0] = c_pro - c_start;
+    q[1] = c_req;
+    q[2] = c_cmp;
+    q[3] = c_bar;
+    q[4] = nch;
+    q[5] = clock64() - c_loop;
+    q[6] = clock64() - c_start;
+  }
 }
 
 template <int EPI, int MT>
@@ -201,7 +265,29 @@ static int launch4(const pdse_gconv_desc* d, hipStream_t s, const int mtiles) {
                        "gconv4 lds attribute")) return 1;
     attr_done = true;
   }
+  static const bool tracing = getenv("PDSE_G4_TRACE") != nullptr;
+  static long long* tbuf = nullptr;
+  const size_t nw = (size_t)grid.x * grid.y * grid.z * 8;
+  if (tracing) {
+    if (!tbuf) {
+      hipMalloc(&tbuf, (size_t)1 << 24);
+      hipMemcpyToSymbol(HIP_SYMBOL(g_trace4), &tbuf, sizeof(tbuf));
+    }
+    hipMemsetAsync(tbuf, 0, nw * 64, s);
+  }
   hipLaunchKernelGGL((gconv4_kernel<EPI, MT>), grid, block, lds, s, *d);
+  if (tracing && nw * 64 <= ((size_t)1 << 24)) {   // diagnostic: per-wave averages in shader clocks
+    hipStreamSynchronize(s);
+    long long* h = (long long*)malloc(nw * 64);
+    hipMemcpy(h, tbuf, nw * 64, hipMemcpyDeviceToHost);
+    double sum[7] = {0};
+    for (size_t i = 0; i < nw; ++i)
+      for (int k = 0; k < 7; ++k) sum[k] += (double)h[i * 8 + k];
+    fprintf(stderr, "gconv4 trace EPI %d MT %d taps %d cin %d+%d cout %d %dx%d grid %ux%ux%u: prologue %.0f | per chunk: request %.0f compute %.0f barrier %.0f | chunks %.1f | epilogue %.0f total %.0f\n",
+            EPI, MT, d->ntaps, d->in0.C, d->in1.C, d->Cout, d->Tout, d->Fout, grid.x, grid.y, grid.z, sum[0] / nw, sum[1] / sum[4], sum[2] / sum[4], sum[3] / sum[4],
+            sum[4] / nw, sum[5] / nw, sum[6] / nw);
+    free(h);
+  }
   return pdse_check_launch("gconv4");
 }
 

@@ -8,6 +8,7 @@
 // summed through LDS, then thread (unit, item) applies the cell update.  h is kept
 // transposed [H][Bp] (ping-pong) so the B operand is a coalesced 128-B row per k.
 #include <hip/hip_runtime.h>
+#include <stdio.h>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -125,6 +126,14 @@ __device__ __forceinline__ size_t hidx(const int u, const int b, const int Bp) {
   return (((size_t)(u >> 3) * 2 + (u & 1)) * Bp + b) * 4 + ((u & 7) >> 1);
 }
 
+__device__ long long* g_trace_l = nullptr;   // PDSE_GLSTM_TRACE=1 (diagnostic): [workgroup][wave][8] clock stamps of step T/2
+#define LSTAMP(i)                                                                                               \
+  do {                                                                                                          \
+    if (trace && lane == 0)                                                                                     \
+      trace[((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + wave) * 8 + (i)] =  \
+          (i) == 0 ? wall_clock64() : clock64();                                                                \
+  } while (0)
+
 __global__ __launch_bounds__(512) void glstm_wave_kernel(const pdse_glstm_desc d, const int s, const int stage_mask) {
   __shared__ float red[8][32][33];
   __shared__ float stat[16][32][2];
@@ -135,6 +144,9 @@ __global__ __launch_bounds__(512) void glstm_wave_kernel(const pdse_glstm_desc d
   const int stage = blockIdx.z / nbt, bt = blockIdx.z - stage * nbt;
   const int t = s - stage;
   if (t < 0 || t >= d.T || !((stage_mask >> stage) & 1)) return;
+  long long* const trace = (s == d.T / 2) ? g_trace_l : nullptr;
+  LSTAMP(0);
+  LSTAMP(1);
   const int H = d.H, Bp = d.Bp, G = d.G;
   const size_t hsz = (size_t)H * Bp;               // one group's state
   const int par = t & 1;
@@ -179,6 +191,10 @@ __global__ __launch_bounds__(512) void glstm_wave_kernel(const pdse_glstm_desc d
       bv[i] = B4[(size_t)i * 2 * Bp];
     }
     __builtin_amdgcn_sched_barrier(0);
+    if (trace) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      LSTAMP(2);
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].x, bv[i].x, acc, 0, 0, 0);
@@ -220,9 +236,11 @@ __global__ __launch_bounds__(512) void glstm_wave_kernel(const pdse_glstm_desc d
     stat[p][bb][0] = s1;
     stat[p][bb][1] = s2;
   }
+  LSTAMP(3);
 #pragma unroll
   for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * h][col] = acc[r];
   __syncthreads();
+  LSTAMP(4);
   const bool fin = threadIdx.x < 256;               // (unit, item) threads; every wave still reaches the barrier below
   float gate[4] = {0.f, 0.f, 0.f, 0.f};
   if (fin) {
@@ -271,6 +289,7 @@ __global__ __launch_bounds__(512) void glstm_wave_kernel(const pdse_glstm_desc d
       if (b < d.B) d.y[(int64_t)b * d.y_sb + (int64_t)t * d.y_st + (int64_t)hu * d.y_su + (int64_t)g * d.y_sg] = hv;
     }
   }
+  LSTAMP(5);
   if (stage != 0) return;
   __syncthreads();
   // LayerNorm partial sums over this workgroup's 8 units (the same summation order at every batch size)
@@ -300,6 +319,38 @@ int pdse_glstm_launch(const pdse_glstm_desc* d, hipStream_t s) {
   const dim3 grid(d->H / 8, d->G, 3 * (d->Bp / 32)), block(512);
   // PDSE_GLSTM_MASK (diagnostic, tools/time_glstm.py): run only some stages to time them apart - results are then wrong
   static const int mask = getenv("PDSE_GLSTM_MASK") ? atoi(getenv("PDSE_GLSTM_MASK")) : 7;
+  static const bool tracing = getenv("PDSE_GLSTM_TRACE") != nullptr;
+  static long long* tbuf = nullptr;
+  const size_t nw = (size_t)grid.x * grid.y * grid.z * 8;
+  if (tracing) {
+    if (!tbuf) {
+      hipMalloc(&tbuf, nw * 64);
+      hipMemcpyToSymbol(HIP_SYMBOL(g_trace_l), &tbuf, sizeof(tbuf));
+    }
+    hipMemsetAsync(tbuf, 0, nw * 64, s);
+  }
   for (int st = 0; st < d->T + 2; ++st) hipLaunchKernelGGL(glstm_wave_kernel, grid, block, 0, s, *d, st, mask);
+  if (tracing) {   // diagnostic: stamps of wavefront step T/2 - start spread (100 MHz clock) and shader clocks since the wave started
+    hipStreamSynchronize(s);
+    long long* h = (long long*)malloc(nw * 64);
+    hipMemcpy(h, tbuf, nw * 64, hipMemcpyDeviceToHost);
+    for (int stg = 0; stg < 3; ++stg) {
+      double sum[8] = {0};
+      long long w0 = -1, w1 = 0;
+      size_t n = 0;
+      const size_t per = nw / 3;
+      for (size_t i = stg * per; i < (stg + 1) * per; ++i) {
+        const long long* q = h + i * 8;
+        if (!q[0]) continue;
+        ++n;
+        if (w0 < 0 || q[0] < w0) w0 = q[0];
+        if (q[0] > w1) w1 = q[0];
+        for (int k = 2; k < 6; ++k) sum[k] += q[k] ? (double)(q[k] - q[1]) : 0.0;
+      }
+      if (n) fprintf(stderr, "glstm trace stage %d (%zu waves): start spread %.2f us; cycles since wave start: loads landed %.0f, mfma issued %.0f, after barrier %.0f, end %.0f\n",
+                     stg, n, (w1 - w0) * 0.01, sum[2] / n, sum[3] / n, sum[4] / n, sum[5] / n);
+    }
+    free(h);
+  }
   return pdse_check_launch("glstm");
 }
