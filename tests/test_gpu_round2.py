@@ -449,3 +449,50 @@ def test_split_bf16_gcrn_prior_vs_fp32_kernels_and_goldens(L, weights, monkeypat
     assert all(d.korder in (0, 1) for d, _ in p32.descs if isinstance(d, L.GconvDesc))
     pfull = P(DEV, "GCRN", weights("GCRN"), weights("DiffUNet1"), 1, T=20, fast_sampling=False)
     assert not pfull.split_bf16 and all(d.korder in (0, 1) for d, _ in pfull.descs if isinstance(d, L.GconvDesc))
+
+
+def test_split_tcm_blocks_match_fp32_kernel_and_validate_descriptors(L, weights):
+    """csrc/tcm2.hip against csrc/tcm.hip on the same eps-net: the TCM stack's output (the decoders' input) from the
+    split-bf16 blocks - pre-split bottleneck tensor, rotated K order - must equal the exact-fp32 blocks' to fp32 level,
+    the bottleneck tensor's zero margins must survive all 19 launches, and bad descriptors are refused."""
+    nets, P = pkg("nets"), pkg("packing")
+    sd = weights("DiffUNet1")
+    B, T = 3, 77                                      # three frame tiles, the last one ragged
+    x, xi = seeded((B, 2, T, 161), 41).to(DEV), (seeded((B, 2, T, 161), 42) * 0.3).to(DEV)
+    outs, tcm = {}, {}
+    for split in (False, True):
+        net = nets.EpsNetPlan(nets.Ctx(DEV), sd, B, T, time_cond=True, nsteps=1, split_bf16=split)
+        net.build_time()
+        net.build_step(0)
+        net.finish()
+        net.x.copy_(x)
+        net.x_init.copy_(xi)
+        net.tsteps.fill_(7.25)
+        net.plan.run()
+        torch.cuda.synchronize()
+        outs[split] = net.out.clone()
+        n_tcm2 = sum(1 for d, _ in net.descs if isinstance(d, L.Tcm2Desc))
+        assert n_tcm2 == (19 if split else 0)
+        last = [d for d, _ in net.descs if isinstance(d, (L.Tcm2Desc, L.TcmDesc))][-1]
+        tcm[split] = (net.tcm_a if last.x_out == net.tcm_a.data_ptr() else net.tcm_b).clone()
+        if split:
+            for hs in net.tcm_hs:                     # margins untouched (join asserts it), planes finite
+                vm, vk = P.tcm2_join_h(hs.cpu().numpy().view(np.uint16), B, T)
+                assert np.isfinite(vm).all() and np.isfinite(vk).all()
+            split_net = net
+    assert rel_l2(tcm[True].cpu(), tcm[False].cpu()) < 5e-6
+    assert rel_l2(outs[True].cpu(), outs[False].cpu()) < 2e-5
+    # descriptor validation
+    d = [d for d, _ in split_net.descs if isinstance(d, L.Tcm2Desc) and d.mode == 0][0]
+    bad = type(d).from_buffer_copy(d)
+    bad.dil = 33
+    with pytest.raises(L.PdseError, match="dilation"):
+        L.launch(bad)
+    bad = type(d).from_buffer_copy(d)
+    bad.hs_out = bad.hs
+    with pytest.raises(L.PdseError, match="alias"):
+        L.launch(bad)
+    bad = type(d).from_buffer_copy(d)
+    bad.mode = 2
+    with pytest.raises(L.PdseError, match="mode"):
+        L.launch(bad)
