@@ -199,6 +199,11 @@ typedef struct pdse_compand_desc {
   int64_t plane; /* T*F */
   int32_t B;
   int32_t mode; /* 0: mag**0.5 (compress), 1: mag**2 (decompress) */
+  /* F > 0: the output is written as out[b*out_sb + ri*out_sc + t*out_st + f] instead of the input's own layout (the
+   * ISTFT GEMM reads frame-major rows [B][T][2*168] whose 336 entries are its K dimension; the pad entries are never
+   * written).  F == 0: out has the layout of in. */
+  int64_t out_sb, out_sc, out_st;
+  int32_t F, pad_;
 } pdse_compand_desc;
 
 /* waveform front-end: c[b] = sqrt(sum x^2 / len_b); xpad = reflect_pad(x / c, 160)   (:922-923, stft center=True).

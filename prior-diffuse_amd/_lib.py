@@ -66,7 +66,8 @@ class EwDesc(C.Structure):
 
 
 class CompandDesc(C.Structure):
-    _fields_ = [("in_", _fp), ("out", _fp), ("plane", _i64), ("B", _i32), ("mode", _i32)]
+    _fields_ = [("in_", _fp), ("out", _fp), ("plane", _i64), ("B", _i32), ("mode", _i32),
+                ("out_sb", _i64), ("out_sc", _i64), ("out_st", _i64), ("F", _i32), ("pad_", _i32)]
 
 
 class WavprepDesc(C.Structure):

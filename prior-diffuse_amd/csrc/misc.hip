@@ -168,14 +168,22 @@ __global__ __launch_bounds__(256) void compand_kernel(const pdse_compand_desc d)
       sr = im / mag;
     }
     const float m2 = d.mode == 0 ? sqrtf(mag) : mag * mag;
-    d.out[ire] = m2 * cr;
-    d.out[iim] = m2 * sr;
+    if (d.F > 0) {
+      const int64_t t = q / d.F, f = q - t * d.F;
+      float* o = d.out + b * d.out_sb + t * d.out_st + f;
+      o[0] = m2 * cr;
+      o[d.out_sc] = m2 * sr;
+    } else {
+      d.out[ire] = m2 * cr;
+      d.out[iim] = m2 * sr;
+    }
   }
 }
 
 int pdse_compand_launch(const pdse_compand_desc* d, hipStream_t s) {
   REQ(d && d->in && d->out && d->B > 0 && d->plane > 0, "compand: bad descriptor");
   REQ(d->mode == 0 || d->mode == 1, "compand: mode must be 0 or 1");
+  REQ(d->F >= 0 && (d->F == 0 || d->plane % d->F == 0), "compand: plane must be a multiple of F");
   int64_t blocks = ((int64_t)d->B * d->plane + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(compand_kernel, dim3((unsigned)blocks), dim3(256), 0, s, *d);

@@ -1060,8 +1060,10 @@ class StftPlan(PlanBase):
     """wav [B,L] -> c [B], compressed spectrogram [B,2,T,161]
     (trainer/complex_ddpm_trainer.py:921-937)."""
 
-    def __init__(self, ctx, B, L_, plan=None, normalize=True):
-        super().__init__(ctx, plan, ns=("stft",))
+    def __init__(self, ctx, B, L_, plan=None, normalize=True, split_bf16=False):
+        """split_bf16: the framing GEMM on the bf16 matrix cores with exact three-way operand splits (csrc/gconv4.hip)."""
+        super().__init__(ctx, plan, ns=("stft", bool(split_bf16)))
+        self.split_bf16 = bool(split_bf16)
         if L_ <= 160:
             raise ValueError(f"utterance of {L_} samples: the centred STFT reflects 160 samples on each side (torch.stft "
                              "raises for the same input)")
@@ -1083,9 +1085,12 @@ class StftPlan(PlanBase):
         d.B, d.L, d.pad, d.normalize = B, L_, 160, 1 if self.normalize else 0
         self.add(d, TAG_SIGNAL)
         Lp = L_ + 320
-        self.gconv(in0=self.src(self.xpad, 1, Lp, 0, 0, 1), Tin=1, Fin=Lp, taps=[(0, n) for n in range(320)],
-                   sf_in=160, W=lambda: dict(wk0=P.stft_kmat(320)), Cout=2 * F0, cin1=True, out=feat, label="stft",
-                   out_strides=(2 * T * F0, T * F0, 1, 0, F0), out_cr=F0, B=B, Tout=1, Fout=T, tag=TAG_SIGNAL)
+        # a frame's 320 samples as 320 "channels" of stride 1 at position 160 j: one GEMM [B T, 320] x [320, 322] (as 320
+        # taps of one channel the gather loop ran 320 tap iterations of a 1-deep contraction: 294 us at B=32, 4 s)
+        self.gconv(in0=self.src(self.xpad, 320, Lp, 1, 0, 1), Tin=1, Fin=Lp, taps=[(0, 0)],
+                   sf_in=160, W=lambda: dict(wk0=P.stft_kmat(320)), Cout=2 * F0, out=feat, label="stft",
+                   out_strides=(2 * T * F0, T * F0, 1, 0, F0), out_cr=F0, B=B, Tout=1, Fout=T, tag=TAG_SIGNAL,
+                   s3g=self.split_bf16)
         c = L.CompandDesc()
         c.in_, c.out, c.plane, c.B, c.mode = feat.data_ptr(), feat.data_ptr(), T * F0, B, 0
         self.add(c, TAG_SIGNAL)
@@ -1096,11 +1101,13 @@ class IstftPlan(PlanBase):
     """compressed spectrogram [B,2,T,161] -> wav [B,L] * c
     (trainer/complex_ddpm_trainer.py:1004-1016)."""
 
-    def __init__(self, ctx, B, T, L_, plan=None):
-        super().__init__(ctx, plan, ns=("istft",))
+    def __init__(self, ctx, B, T, L_, plan=None, split_bf16=False):
+        super().__init__(ctx, plan, ns=("istft", bool(split_bf16)))
+        self.split_bf16 = bool(split_bf16)
         self.B, self.T, self.L = B, T, L_
         self.spec = ctx.alloc(B, 2, T, F0)
-        self.dec = ctx.alloc(B, 2, T, F0)
+        # decompressed spectrogram, frame-major rows [re 0..160, 7 zeros | im 0..160, 7 zeros]: the GEMM's K axis
+        self.dec = ctx.alloc(B, T, 2 * P.ISTFT_ROW, zero=True)
         self.frames = ctx.alloc(B, 320, T)
         self.wav = ctx.alloc(B, L_)
         self.win2 = self.upw("win2", lambda: P.hann_periodic(320) ** 2)
@@ -1110,10 +1117,12 @@ class IstftPlan(PlanBase):
         spec = self.spec if spec is None else spec
         cd = L.CompandDesc()
         cd.in_, cd.out, cd.plane, cd.B, cd.mode = spec.data_ptr(), self.dec.data_ptr(), T * F0, B, 1
+        K = 2 * P.ISTFT_ROW
+        cd.out_sb, cd.out_sc, cd.out_st, cd.F = T * K, P.ISTFT_ROW, K, F0
         self.add(cd, TAG_SIGNAL)
-        self.gconv(in0=self.src(self.dec, 2, *nchw(2, T, F0)), Tin=T, Fin=F0, taps=[(0, f) for f in range(F0)],
-                   sf_in=1, W=lambda: dict(wk0=P.istft_kmat(320)), Cout=320, out=self.frames, out_strides=(320 * T, T, 0, 1, 0),
-                   B=B, Tout=T, Fout=1, tag=TAG_SIGNAL, label="istft")
+        self.gconv(in0=self.src(self.dec, K, T * K, 1, K, 0), Tin=T, Fin=1, taps=[(0, 0)],
+                   sf_in=1, W=lambda: dict(wk0=P.istft_kmat_rows(320)), Cout=320, out=self.frames, out_strides=(320 * T, T, 0, 1, 0),
+                   B=B, Tout=T, Fout=1, tag=TAG_SIGNAL, label="istft", s3g=self.split_bf16)
         o = L.OlaDesc()
         o.frames, o.win2, o.c, o.out = (self.frames.data_ptr(), self.win2.data_ptr(), Ctx.ptr(c), self.wav.data_ptr())
         o.B, o.T, o.L, o.n_fft, o.hop = B, T, self.L, 320, 160

@@ -187,6 +187,20 @@ def istft_kmat(n_fft=320):
     return out
 
 
+ISTFT_ROW = 168   # F = 161 bins padded to a multiple of 8: K = 2 * 168 = 21 blocks of 16
+
+
+def istft_kmat_rows(n_fft=320):
+    """The same matrix with K ordered (ri, f) and each half padded to ISTFT_ROW rows of zeros: [2 * 168, n_fft] -
+    the K dimension of the ISTFT as ONE channel axis of the decompressed spectrogram stored [B][T][2 * 168]."""
+    F = n_fft // 2 + 1
+    k = istft_kmat(n_fft)
+    out = np.zeros((2 * ISTFT_ROW, n_fft))
+    out[:F] = k[0::2]
+    out[ISTFT_ROW:ISTFT_ROW + F] = k[1::2]
+    return out
+
+
 # ------------------------------------------------------------------------------------------
 # grouped LSTM, layer wavefront (csrc/lstm.hip: glstm_wave_kernel; include/pdse.h: pdse_glstm_desc)
 # ------------------------------------------------------------------------------------------

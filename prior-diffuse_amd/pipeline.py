@@ -71,7 +71,7 @@ class SamplerPipeline:
             pb.descs = self.descs
             return pb
 
-        self.stft = adopt(nets.StftPlan(ctx, B, L_, plan=self.plan)) if with_signal else None
+        self.stft = adopt(nets.StftPlan(ctx, B, L_, plan=self.plan, split_bf16=split_bf16)) if with_signal else None
         if prior_name == "GCRN":
             self.prior = adopt(nets.GcrnPlan(ctx, prior_sd, B, T, plan=self.plan, split_bf16=split_bf16))
         elif prior_name == "DiffUNet":
@@ -87,7 +87,7 @@ class SamplerPipeline:
         self.split_bf16 = self.eps.split_bf16
         self.deltamu = deltamu
         self.cond_feat = cond_feat = (cond == "feat") and not deltamu
-        self.istft = adopt(nets.IstftPlan(ctx, B, T, L_, plan=self.plan)) if with_signal else None
+        self.istft = adopt(nets.IstftPlan(ctx, B, T, L_, plan=self.plan, split_bf16=split_bf16)) if with_signal else None
 
         self.feat = self.prior.x                     # prior input = compressed spectrogram
         # X_init / 11: the eps-net's conditioning input only in the pirorgrad parameterisation

@@ -306,6 +306,13 @@ def run_compand(d, mem):
     cr, sr = np.where(mag > 0, x[:, 0] / safe, 1.0), np.where(mag > 0, x[:, 1] / safe, 0.0)
     m2 = np.sqrt(mag) if d.mode == 0 else mag * mag
     out = np.stack([m2 * cr, m2 * sr], axis=1).astype(np.float32)
+    if d.F > 0:                                    # strided output: out[b*out_sb + ri*out_sc + t*out_st + f]
+        T = d.plane // d.F
+        flat, off = mem.view(d.out)
+        idx = (off + np.arange(d.B)[:, None, None, None] * d.out_sb + np.arange(2)[None, :, None, None] * d.out_sc
+               + np.arange(T)[None, None, :, None] * d.out_st + np.arange(d.F)[None, None, None, :])
+        flat[idx] = out.reshape(d.B, 2, T, d.F)
+        return
     mem.arr(d.out, n)[:] = out.reshape(-1)
 
 
