@@ -24,9 +24,16 @@ runs = [p.plan.time_ops(0, n, st) for _ in range(5)][1:]
 med = [statistics.median(r[i] for r in runs) * 1e3 for i in range(n)]
 names = {nets.TAG_SIGNAL: "signal", nets.TAG_EW: "ew", nets.TAG_NONE: "none"}
 print("ops %d total %.2f ms" % (n, sum(med) / 1e3))
+seen = set()
 for i, (d, tag) in enumerate(p.descs):
-    if tag in names:
+    other = isinstance(d, L.GconvDesc) and d.korder in (0, 1) and tag not in names
+    if other:
+        key = (d.ntaps, d.in0.C + d.in1.C, d.Cout, d.Tout, d.Fout, d.korder, d.epi)
+        if key in seen:
+            continue
+        seen.add(key)
+    if tag in names or other or not isinstance(d, (L.GconvDesc, L.Tcm2Desc)):
         extra = ""
         if isinstance(d, L.GconvDesc):
             extra = "taps %d cin %d cout %d %dx%d korder %d" % (d.ntaps, d.in0.C + d.in1.C, d.Cout, d.Tout, d.Fout, d.korder)
-        print("%4d %-7s %-14s %8.1f us  %s" % (i, names[tag], type(d).__name__, med[i], extra))
+        print("%4d %-7s %-14s %8.1f us  %s" % (i, names.get(tag, "tag%d" % tag), type(d).__name__, med[i], extra))
