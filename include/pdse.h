@@ -301,7 +301,9 @@ typedef struct pdse_lstm_desc {
  * launches, each carrying layer 1 at frame s, the layer-2 input projection (LayerNorm 1 folded) at frame s-1 and
  * layer 2 at frame s-2 (csrc/lstm.hip).  Replaces two pdse_lstm_f32 calls, the LayerNorm(1024) between them and
  * the two layer-2 input-projection GEMMs.
- *   gx1   [G][T][4H][Bp]        layer-1 input projections + both biases (as pdse_lstm_desc.gx)
+ *   gx1   [G][T][Bp][4H]        layer-1 input projections + both biases, gate rows innermost: the projection GEMM's
+ *                                lanes are frames and its registers gate rows, so it stores 16 bytes per lane and
+ *                                instruction (batch innermost, as pdse_lstm_desc.gx: every 4-byte store its own line)
  *   whh1, whh2 [G][H/8][H/8][64][4]   recurrent weights: slice s = gate rows q*H + 8s + u (tile row q*8 + u), K in natural
  *                                order, four k-steps per 16-byte lane entry (packing.pack_a4)
  *   wih2  same shape             W_ih of layer 2 times diag(gamma_ln1); K order (g', kq, i, hh): k-group gq = 32 g' + kq'

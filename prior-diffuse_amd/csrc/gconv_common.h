@@ -9,6 +9,7 @@
 #include "pdse.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // row of accumulator register r on lane-half h (32x32 C/D layout, cdna_hip_programming.md §3)
 __device__ __forceinline__ int rho(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
@@ -254,6 +255,16 @@ __device__ __forceinline__ void gconv_epilogue_impl(const pdse_gconv_desc& d, co
                 float v = act_c<ACT>(y[r], d.act_slope);
                 if constexpr (RES) v += pr[(int64_t)PDSE_KR(r) * cstep];
                 po[(int64_t)PDSE_KR(r) * cstep] = v;
+              }
+            } else if (!RES && cstep == 1 && ((uintptr_t)po & 15) == 0) {
+              // channels innermost (the LSTM gate buffer): a lane's rows 4q..4q+3 are 16 contiguous bytes - four stores
+              // per tile instead of sixteen, each still touching one line per lane
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                f32x4 v4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v4[i] = value(4 * q + i);
+                *reinterpret_cast<f32x4*>(po + 8 * q) = v4;
               }
             } else {
 #pragma unroll

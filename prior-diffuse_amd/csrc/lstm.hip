@@ -137,6 +137,7 @@ __device__ long long* g_trace_l = nullptr;   // PDSE_GLSTM_TRACE=1 (diagnostic):
 __global__ __launch_bounds__(512) void glstm_wave_kernel(const pdse_glstm_desc d, const int s, const int stage_mask) {
   __shared__ float red[8][32][33];
   __shared__ float stat[16][32][2];
+  __shared__ __attribute__((aligned(16))) float gxs[4][32][8];   // stage A: this frame's gate pre-activations [gate][item][unit]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = lane & 31, h = lane >> 5;
   const int slice = blockIdx.x, g = blockIdx.y;
@@ -209,12 +210,16 @@ __global__ __launch_bounds__(512) void glstm_wave_kernel(const pdse_glstm_desc d
   const int b = bt * 32 + bb;
   const int hu = slice * 8 + u;
   float pre[4] = {0.f, 0.f, 0.f, 0.f};
+  float4 gx4 = make_float4(0.f, 0.f, 0.f, 0.f);
   float c_old = 0.f;
   const size_t ci = ((size_t)g * H + hu) * Bp + b;
   if (threadIdx.x < 256) {
     if (stage == 0) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) pre[q] = d.gx1[(((size_t)g * d.T + t) * (4 * H) + (size_t)q * H + hu) * Bp + b];
+      // gx1 [G][T][Bp][4H] (gate rows innermost, pdse.h): thread i fetches four consecutive units of one gate and item
+      // as ONE 16-byte load (one instruction per thread, 32 lines per wave instead of 4 x 32) and the values reach
+      // their (unit, item) threads through LDS behind the reduction barrier
+      const int lq = threadIdx.x >> 6, lb = (threadIdx.x >> 1) & 31, lu = (threadIdx.x & 1) * 4;
+      gx4 = *reinterpret_cast<const float4*>(d.gx1 + (((size_t)g * d.T + t) * Bp + bt * 32 + lb) * (4 * H) + (size_t)lq * H + slice * 8 + lu);
       if (t > 0) c_old = d.cst1[ci];
     } else if (stage == 2) {
 #pragma unroll
@@ -239,7 +244,15 @@ __global__ __launch_bounds__(512) void glstm_wave_kernel(const pdse_glstm_desc d
   LSTAMP(3);
 #pragma unroll
   for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * h][col] = acc[r];
+  if (stage == 0 && threadIdx.x < 256) {
+    const int lq = threadIdx.x >> 6, lb = (threadIdx.x >> 1) & 31, lu = (threadIdx.x & 1) * 4;
+    *reinterpret_cast<float4*>(&gxs[lq][lb][lu]) = gx4;
+  }
   __syncthreads();
+  if (stage == 0 && threadIdx.x < 256) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) pre[q] = gxs[q][bb][u];
+  }
   LSTAMP(4);
   const bool fin = threadIdx.x < 256;               // (unit, item) threads; every wave still reaches the barrier below
   float gate[4] = {0.f, 0.f, 0.f, 0.f};

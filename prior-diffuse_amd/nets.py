@@ -927,8 +927,8 @@ class GcrnPlan(PlanBase):
             self.gconv(in0=in0, Tin=Tin, Fin=Fin, taps=taps, sf_in=1, Cout=2048,
                        W=lambda p=p, wk_fn=wk_fn: dict(wk0=wk_fn(self.w(p + "weight_ih_l0")),
                                                        bias0=self.w(p + "bias_ih_l0") + self.w(p + "bias_hh_l0")),
-                       out=self.gx, out_strides=(1, Bp, 0, ost, osf), out_off=g * T * 2048 * Bp, B=B, Tout=Tout, Fout=Fout,
-                       tag=TAG_PRIOR, label=p + "ih", s3g=self.split_bf16)
+                       out=self.gx, out_strides=(2048, 1, 0, ost, osf), out_off=g * T * 2048 * Bp, B=B, Tout=Tout, Fout=Fout,
+                       tag=TAG_PRIOR, label=p + "ih", s3g=self.split_bf16)      # gx1 [G][T][Bp][4H] (pdse_glstm_desc)
 
         def pack():
             up = lambda a: self.ctx.up(a).data_ptr()   # noqa: E731

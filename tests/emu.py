@@ -404,7 +404,7 @@ def _unpack_lstm_slices(w, H, K):
 def run_glstm(d, mem):
     """pdse_glstm_desc: both LSTM layers + the folded LayerNorm, from the packed operands, frame by frame."""
     H, G, T, Bp, B = d.H, d.G, d.T, d.Bp, d.B
-    gx1 = mem.arr(d.gx1, G * T * 4 * H * Bp).reshape(G, T, 4 * H, Bp)
+    gx1 = mem.arr(d.gx1, G * T * 4 * H * Bp).reshape(G, T, Bp, 4 * H)
     n = G * (H // 8) * (H // 8) * 256
     W1 = [_unpack_lstm_slices(w, H, H) for w in mem.arr(d.whh1, n).reshape(G, -1)]
     W2 = [_unpack_lstm_slices(w, H, H) for w in mem.arr(d.whh2, n).reshape(G, -1)]
@@ -423,7 +423,7 @@ def run_glstm(d, mem):
     c2s = np.zeros((G, B, H), np.float32)
     for t in range(T):
         for g in range(G):
-            h1[g], c1[g] = cell(gx1[g, t, :, :B].T + h1[g] @ W1[g].T, c1[g])
+            h1[g], c1[g] = cell(gx1[g, t, :B, :] + h1[g] @ W1[g].T, c1[g])
         allh = np.stack([h1[0], h1[1]], -1).reshape(B, -1).astype(np.float64)       # feature 2u + g'
         mu, var = allh.mean(1), allh.var(1)
         rs = 1.0 / np.sqrt(var + d.eps)
