@@ -51,3 +51,28 @@ def weights():
         return cache[(arch, seed)]
 
     return get
+
+
+_ORACLE_RUNS = {}
+
+
+def oracle_sample_pair(R, weights, feat, x_T, fast, prior="GCRN"):
+    """(fp32 CPU oracle result, the same algorithm evaluated in float64) of ``R.sample`` on one input, memoised per
+    test session: the 50-step evaluations take ~70 s each on the GPU box's host cores and several tests assert against
+    the same input (seed 77, T = 401)."""
+    import hashlib
+
+    import torch
+
+    key = (prior, bool(fast), tuple(feat.shape), hashlib.sha1(feat.numpy().tobytes()).hexdigest(),
+           hashlib.sha1(x_T.numpy().tobytes()).hexdigest())
+    if key not in _ORACLE_RUNS:
+        params = pkg("params").params
+        w32 = (weights(prior), weights("DiffUNet1"))
+        w64 = tuple({k: v.double() for k, v in sd.items()} for sd in w32)
+        with torch.no_grad():
+            ref, _ = R.sample(prior, w32[0], w32[1], feat, x_T, params.noise_schedule, params.inference_noise_schedule, fast, False)
+            exact, _ = R.sample(prior, w64[0], w64[1], feat.double(), x_T.double(), params.noise_schedule,
+                                params.inference_noise_schedule, fast, False)
+        _ORACLE_RUNS[key] = (ref, exact)
+    return _ORACLE_RUNS[key]

@@ -15,7 +15,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden, pkg, rel_l2, seeded
+from conftest import golden, oracle_sample_pair, pkg, rel_l2, seeded
 
 pytestmark = pytest.mark.gpu
 
@@ -462,12 +462,7 @@ def test_full_50_step_schedule_at_t401(L, weights, R):
                                            fast_sampling=False)
     assert pipe.nsteps == 50 and np.array_equal(pipe.schedule[4], np.arange(50, dtype=np.float32))
     spec, init = pipe.sample(feat.to(DEV), x_T.to(DEV))
-    w64 = [{k: v.double() for k, v in weights(a).items()} for a in ("GCRN", "DiffUNet1")]
-    with torch.no_grad():
-        ref, _ = R.sample("GCRN", weights("GCRN"), weights("DiffUNet1"), feat, x_T, params.noise_schedule,
-                          params.inference_noise_schedule, False, False)
-        exact, _ = R.sample("GCRN", w64[0], w64[1], feat.double(), x_T.double(), params.noise_schedule,
-                            params.inference_noise_schedule, False, False)
+    ref, exact = oracle_sample_pair(R, weights, feat, x_T, False)
     e_ref, e_exact, e_ref_exact = rel_l2(spec.cpu(), ref), rel_l2(spec.cpu(), exact), rel_l2(ref, exact)
     print("50 steps, T=401: HIP vs fp32 CPU oracle %.2e | HIP vs float64 evaluation %.2e | fp32 CPU oracle vs float64 "
           "evaluation %.2e" % (e_ref, e_exact, e_ref_exact))
