@@ -355,7 +355,7 @@ def sigma_mask(init):
 
 
 def reverse_loop(ddpm_sd, init_scaled, x_T, alpha, beta, alpha_cum, sigmas, T, table=None,
-                 use_sigma=False, trace=None, deltamu=False, feat_scaled=None):
+                 use_sigma=False, trace=None, deltamu=False, feat_scaled=None, xT_plus_init=None):
     """Runs n = S-1 … 0 on ``audio = x_T`` with ``init_scaled = X_init / 11``.
     feat_scaled (noisy feature / 11): the branch with neither ``pirorgrad`` nor ``deltamu`` set — DiffUNet1 is
     conditioned on it instead of X_init (reference :972-974).
@@ -365,7 +365,9 @@ def reverse_loop(ddpm_sd, init_scaled, x_T, alpha, beta, alpha_cum, sigmas, T, t
     """
     if table is None:
         table = build_time_table(50)
-    audio = x_T + init_scaled if deltamu else x_T.clone()      # reference :947-950
+    if xT_plus_init is None:                                   # :946-949 tests ``self.deltamu`` alone: with pirorgrad AND
+        xT_plus_init = deltamu                                 # deltamu set, DiffUNet1 starts from noise + X_init/11
+    audio = x_T + init_scaled if xT_plus_init else x_T.clone()  # reference :947-950
     if use_sigma:
         mask = sigma_mask(init_scaled)
         audio = audio * (mask ** 0.5)
@@ -390,7 +392,7 @@ def reverse_loop(ddpm_sd, init_scaled, x_T, alpha, beta, alpha_cum, sigmas, T, t
 
 
 def sample(prior_name, prior_sd, ddpm_sd, feat, x_T, noise_schedule, inference_noise_schedule,
-           fast_sampling=True, use_sigma=False, trace=None, deltamu=False, cond="init"):
+           fast_sampling=True, use_sigma=False, trace=None, deltamu=False, cond="init", xT_plus_init=None):
     """feat [B,2,T,F] (compressed spectrogram) -> enhanced compressed spectrogram.
 
     reference: trainer/complex_ddpm_trainer.py:941-998.  cond "feat": neither pirorgrad nor deltamu (:972-974),
@@ -402,7 +404,8 @@ def sample(prior_name, prior_sd, ddpm_sd, feat, x_T, noise_schedule, inference_n
     init = init / C_SCALE
     feat_cond = cond == "feat" and not deltamu
     audio = reverse_loop(ddpm_sd, init, x_T, alpha, beta, alpha_cum, sigmas, T, use_sigma=use_sigma,
-                         trace=trace, deltamu=deltamu, feat_scaled=feat / C_SCALE if feat_cond else None)
+                         trace=trace, deltamu=deltamu, feat_scaled=feat / C_SCALE if feat_cond else None,
+                         xT_plus_init=xT_plus_init)
     if not (deltamu or feat_cond):   # ``if self.pirorgrad: audio += init_audio`` (reference :995-996)
         audio = audio + init
     audio = audio * C_SCALE

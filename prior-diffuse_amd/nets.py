@@ -37,6 +37,18 @@ class WeightBank:
     def __init__(self):
         self.items = {}
         self.keep = []      # every device tensor an entry refers to
+        self.owners = []    # the state_dicts (and tables) entries were derived from, kept alive: an ``id()`` cannot be recycled
+
+    def token(self, obj):
+        """Per-bank identity of a state_dict: its index in ``owners``.  The bank holds a reference, so a bank that
+        outlives a checkpoint can never hand that checkpoint's packed weights to a new dict at a recycled address."""
+        if obj is None:
+            return None
+        for i, o in enumerate(self.owners):
+            if o is obj:
+                return i
+        self.owners.append(obj)
+        return len(self.owners) - 1
 
     def nbytes(self):
         return sum(t.numel() * t.element_size() for t in self.keep if torch.is_tensor(t))
@@ -339,9 +351,9 @@ class EpsNetPlan(PlanBase):
         with_pre = time_cond if with_pre is None else with_pre
         if split_bf16 is not None:
             self.split_bf16 = bool(split_bf16)
-        super().__init__(ctx, plan, ns=(id(sd), bool(time_cond), bool(with_pre), self.fused_tcm, self.chain_conv1,
+        super().__init__(ctx, plan, ns=(ctx.bank.token(sd), bool(time_cond), bool(with_pre), self.fused_tcm, self.chain_conv1,
                                         self.compose_stage1, self.split_bf16, self.split_tcm,
-                                        None if table is None else id(table)))
+                                        ctx.bank.token(table)))
         self.sd, self.B, self.T, self.time_cond, self.nsteps = sd, B, T, time_cond, nsteps
         self.with_pre = with_pre
         a = ctx.alloc
@@ -866,7 +878,7 @@ class GcrnPlan(PlanBase):
     def __init__(self, ctx, sd, B, T, plan=None, split_bf16=None):
         if split_bf16 is not None:
             self.split_bf16 = bool(split_bf16)
-        super().__init__(ctx, plan, ns=(id(sd), self.fused_last, self.fused_glstm, self.split_bf16))
+        super().__init__(ctx, plan, ns=(ctx.bank.token(sd), self.fused_last, self.fused_glstm, self.split_bf16))
         self.sd, self.B, self.T = sd, B, T
         a = ctx.alloc
         self.Bp = Bp = (B + 31) // 32 * 32
@@ -1146,7 +1158,7 @@ class AiaPlan(PlanBase):
         """d: d_model of the transformer layers (32: AIA_Transformer(64, 64); 64: AIA_Transformer_merge(128, 64))."""
         if split_bf16 is not None:
             self.split_bf16 = bool(split_bf16)
-        super().__init__(ctx, plan, ns=(id(sd), d, self.fused_gru_input, self.split_bf16))
+        super().__init__(ctx, plan, ns=(ctx.bank.token(sd), d, self.fused_gru_input, self.split_bf16))
         self.sd, self.B, self.T, self.d = sd, B, T, d
         a = ctx.alloc
         FH = self.FH

@@ -32,11 +32,14 @@ def _expect(t, like, name):
 class SamplerPipeline:
     def __init__(self, device, prior_name, prior_sd, ddpm_sd, B, T=None, L_=None, fast_sampling=True,
                  use_sigma=False, params=default_params, with_signal=None, deltamu=False, cond="init", bank=None,
-                 split_bf16=None):
+                 split_bf16=None, xT_plus_init=None):
         """deltamu: the alternative parameterisation of utils/params.py:36 — ddpm_sd is a ``Nocon`` state_dict,
         x_T = noise + X_init/11 (:947-948), eps = Nocon(x, t) (:970-971), no final ``+ X_init`` (:995).
         cond (deltamu False): what conditions DiffUNet1 — "init": X_init/11 (pirorgrad, :967-969, + X_init at the end,
         :994-995); "feat": the noisy feature / 11 (the branch with neither flag set, :74-75, :972-974; no final add).
+        xT_plus_init: x_T = noise + X_init/11 (:946-949 tests ``self.deltamu`` on its own, while model selection :70-73
+        and the eps call :967-971 let ``pirorgrad`` win): default = deltamu; True with deltamu False is the reference's
+        behaviour when BOTH flags are set (DiffUNet1 conditioned on X_init, start from noise + X_init/11, final + X_init).
         bank: a ``nets.WeightBank`` shared with other pipelines built from the same state_dicts (packed weights are
         uploaded once, every further (B, T) only records descriptors).
         split_bf16: the eps-net's BIGLU blocks and the priors' GEMM-shaped convolutions on the bf16 matrix cores with exact three-way
@@ -86,6 +89,7 @@ class SamplerPipeline:
                                          with_pre=not deltamu, split_bf16=split_bf16))
         self.split_bf16 = self.eps.split_bf16
         self.deltamu = deltamu
+        self.xT_plus_init = xT_plus_init = bool(deltamu if xT_plus_init is None else xT_plus_init)
         self.cond_feat = cond_feat = (cond == "feat") and not deltamu
         self.istft = adopt(nets.IstftPlan(ctx, B, T, L_, plan=self.plan, split_bf16=split_bf16)) if with_signal else None
 
@@ -121,7 +125,7 @@ class SamplerPipeline:
             if cond_feat:
                 ew(L.EW_DIV, self.feat, out=self.eps.x_init, s0=PRIOR_SCALE_C)        # batch_feat /= c  (:943)
             src = self.xT_in
-            if deltamu:
+            if xT_plus_init:
                 ew(L.EW_ADD_MUL, self.xT_in, b=self.init, out=self.audio, s0=1.0)     # randn_like(init) + init  (:947-948)
                 src = self.audio
             if use_sigma:                                                             # audio * sqrt(mask(init))  (:951-956)
@@ -130,7 +134,7 @@ class SamplerPipeline:
                 d.maxbuf = ctx.alloc(B * 2).data_ptr()
                 d.plane, d.nplanes = T * F0, B * 2
                 self.eps.add(d, nets.TAG_EW)
-            elif not deltamu:
+            elif not xT_plus_init:
                 ew(L.EW_COPY, self.xT_in, out=self.audio)
             self.eps.build_time()
 

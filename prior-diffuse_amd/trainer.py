@@ -41,8 +41,11 @@ class ComplexDDPMTrainer(object):
         self.config = deepcopy(config)
         self.params = default_params if params is None else params    # :34 (override: synthetic runs / deltamu)
         self.pirorgrad = bool(self.params.pirorgrad)
-        # :70-75 / :967-974: pirorgrad wins over deltamu; neither flag = DiffUNet1 conditioned on the noisy feature
+        # :70-75 / :967-974: pirorgrad wins over deltamu for the model and the eps call; neither flag = DiffUNet1
+        # conditioned on the noisy feature.  The x_T prologue (:946-949) tests deltamu on its own: with both flags set
+        # the reference starts from randn + X_init/11 and still adds X_init at the end.
         self.deltamu = bool(self.params.deltamu) and not self.pirorgrad
+        self.xT_plus_init = bool(self.params.deltamu)
         self.cond = "init" if (self.pirorgrad or self.deltamu) else "feat"
         tr = self.config.train
         if (tr.fft_num, tr.win_size, tr.win_shift) != (320, 320, 160) or tr.feat_type != "sqrt":
@@ -77,7 +80,7 @@ class ComplexDDPMTrainer(object):
                 self.ddpm_sd = data[2]
         else:
             self.prior_sd = data
-        if getattr(self, "_pipes", None):      # new weights: every recorded plan and the packed copies are stale
+        if hasattr(self, "bank"):              # new weights: every recorded plan and the packed copies are stale
             self._pipes.clear()
             self.bank = nets.WeightBank()
             self.model = ops.PRIOR_OPS[self.prior_name](self.prior_sd, self.device, bank=self.bank)
@@ -101,7 +104,7 @@ class ComplexDDPMTrainer(object):
             pipe = self._pipes[key] = SamplerPipeline(
                 self.device, self.prior_name, self.prior_sd, self.ddpm_sd, B, T=T, L_=L_,
                 fast_sampling=self.params.fast_sampling, use_sigma=key[3], params=self.params, deltamu=self.deltamu,
-                cond=self.cond, bank=self.bank)
+                cond=self.cond, bank=self.bank, xT_plus_init=self.xT_plus_init)
         else:
             self._pipes.move_to_end(key)
         return pipe

@@ -53,26 +53,39 @@ def weights():
     return get
 
 
-_ORACLE_RUNS = {}
+def _cap_threads():
+    """The GPU box's host share is 16 cores of a much larger machine: torch's default thread count oversubscribes it
+    (round 2's suite ran 598-984 s on identical code).  bench.py applies the same cap."""
+    try:
+        import torch
+
+        torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    except Exception:       # noqa: BLE001 - a box without sched_getaffinity keeps torch's default
+        pass
 
 
-def oracle_sample_pair(R, weights, feat, x_T, fast, prior="GCRN"):
-    """(fp32 CPU oracle result, the same algorithm evaluated in float64) of ``R.sample`` on one input, memoised per
-    test session: the 50-step evaluations take ~70 s each on the GPU box's host cores and several tests assert against
-    the same input (seed 77, T = 401)."""
-    import hashlib
+_cap_threads()
 
-    import torch
 
-    key = (prior, bool(fast), tuple(feat.shape), hashlib.sha1(feat.numpy().tobytes()).hexdigest(),
-           hashlib.sha1(x_T.numpy().tobytes()).hexdigest())
-    if key not in _ORACLE_RUNS:
-        params = pkg("params").params
-        w32 = (weights(prior), weights("DiffUNet1"))
-        w64 = tuple({k: v.double() for k, v in sd.items()} for sd in w32)
-        with torch.no_grad():
-            ref, _ = R.sample(prior, w32[0], w32[1], feat, x_T, params.noise_schedule, params.inference_noise_schedule, fast, False)
-            exact, _ = R.sample(prior, w64[0], w64[1], feat.double(), x_T.double(), params.noise_schedule,
-                                params.inference_noise_schedule, fast, False)
-        _ORACLE_RUNS[key] = (ref, exact)
-    return _ORACLE_RUNS[key]
+def full_pair(name):
+    """(fp32 result, float64 result, X_init) of the REFERENCE's own sampling statements on the real modules at full size
+    (oracle/make_golden_full.py; tests/golden/full_*.npz).  Replaces round 2's on-the-box CPU oracle evaluations."""
+    g = golden(name)
+    return g["out"], g["out_f64"], g["init"]
+
+
+def assert_rows2_and_checksums(got, g, prefix, tol):
+    """T = 1001 fixtures keep every second frame plus float64 checksums of the whole tensor."""
+    got = np.asarray(got, dtype=np.float64)
+    assert rel_l2(got[:, :, ::2], g[prefix + "rows2"]) < tol
+    n, ssq = got.size, float(g[prefix + "sumsq"])
+    assert abs(float((got ** 2).sum()) - ssq) <= 2 * tol * ssq
+    assert abs(float(got.sum()) - float(g[prefix + "sum"])) <= tol * np.sqrt(n * ssq)
+
+
+_FIRST = ("golden", "full_size", "config3", "config4", "config5", "full_50", "bit_exact", "vs_reference")
+
+
+def pytest_collection_modifyitems(config, items):
+    """Parity against the reference's fixtures runs first, so a time limit cannot leave a parity row unreached."""
+    items.sort(key=lambda it: 0 if any(k in it.name for k in _FIRST) else 1)

@@ -15,7 +15,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden, oracle_sample_pair, pkg, rel_l2, seeded
+from conftest import assert_rows2_and_checksums, full_pair, golden, pkg, rel_l2, seeded
 
 pytestmark = pytest.mark.gpu
 
@@ -273,10 +273,9 @@ def test_batch_invariance_full_size(L, weights, R):
         assert torch.equal(i1[0], init[b]), b
         assert torch.equal(s1[0], spec[b]), b
     assert torch.isfinite(spec).all()
-    with torch.no_grad():
-        ref, _ = R.sample("GCRN", weights("GCRN"), weights("DiffUNet1"), feat[:1], x_T[:1], params.noise_schedule,
-                          params.inference_noise_schedule, True, False)
-    assert rel_l2(spec[0].cpu(), ref[0]) < 1e-4
+    ref, exact, ref_init = full_pair("full_gcrn_seed1234_t401_6step")      # the reference's own loop on its real modules
+    assert rel_l2(init[0].cpu(), ref_init[0]) < 2e-5
+    assert rel_l2(spec[0].cpu(), ref[0]) < 1e-4 and rel_l2(spec[0].cpu(), exact[0]) < 1e-4
 
 
 def test_trainer_surface(L, weights, tmp_path):
@@ -356,9 +355,7 @@ def test_aia_prior_golden_and_oracle(L, weights, R):
     assert rel_l2(out.cpu(), g["out"]) < 5e-5
     x = seeded((1, 2, 401, 161), 61)
     big = op(x.to(DEV)).cpu()
-    with torch.no_grad():
-        ref = R.aia_complex_trans_ri_forward(weights("aia_complex_trans_ri"), x)
-    assert rel_l2(big, ref) < 1e-4
+    assert rel_l2(big, golden("full_aia_seed61_t401")["out"]) < 1e-4       # the reference module at T = 401
 
 
 def test_dual_branch_aia_prior_golden_and_oracle(L, weights, R):
@@ -377,9 +374,7 @@ def test_dual_branch_aia_prior_golden_and_oracle(L, weights, R):
     assert rel_l2(out.cpu(), g["out"]) < 5e-5
     x = seeded((1, 2, 401, 161), 62)
     big = op(x.to(DEV)).cpu()
-    with torch.no_grad():
-        ref = R.dual_aia_trans_merge_crm_forward(weights("dual_aia_trans_merge_crm"), x)
-    assert rel_l2(big, ref) < 1e-4
+    assert rel_l2(big, golden("full_dual_aia_seed62_t401")["out"]) < 1e-4  # the reference module at T = 401
 
 
 @pytest.mark.parametrize("prior", ["aia_complex_trans_ri", "dual_aia_trans_merge_crm"])
@@ -455,14 +450,14 @@ def test_checkpoint_rules_and_cli_surface(L, weights, tmp_path, monkeypatch):
 
 def test_full_50_step_schedule_at_t401(L, weights, R):
     """BASELINE config 3 shape: full 50-step reverse schedule at T=401 (one utterance, fp32),
-    tolerance 1e-4 rel-L2 vs the CPU oracle; the step indices it walks are the bit-exact T array."""
+    tolerance 1e-4 rel-L2 vs the reference's own loop (fp32 and float64 fixtures); the step indices it walks are the bit-exact T array."""
     params = pkg("params").params
     feat, x_T = pkg("synth").synthetic_spectrogram(1, 401, seed=77)
     pipe = pkg("pipeline").SamplerPipeline(DEV, "GCRN", weights("GCRN"), weights("DiffUNet1"), 1, T=401,
                                            fast_sampling=False)
     assert pipe.nsteps == 50 and np.array_equal(pipe.schedule[4], np.arange(50, dtype=np.float32))
     spec, init = pipe.sample(feat.to(DEV), x_T.to(DEV))
-    ref, exact = oracle_sample_pair(R, weights, feat, x_T, False)
+    ref, exact, _ = full_pair("full_gcrn_seed77_t401_50step")
     e_ref, e_exact, e_ref_exact = rel_l2(spec.cpu(), ref), rel_l2(spec.cpu(), exact), rel_l2(ref, exact)
     print("50 steps, T=401: HIP vs fp32 CPU oracle %.2e | HIP vs float64 evaluation %.2e | fp32 CPU oracle vs float64 "
           "evaluation %.2e" % (e_ref, e_exact, e_ref_exact))
@@ -479,11 +474,9 @@ def test_long_utterance_t1001(L, weights, R):
     t = torch.tensor([22.992493])
     out = pkg("ops").DiffUNet1Op(weights("DiffUNet1"), DEV)(x.to(DEV), xi.to(DEV), t.to(DEV)).cpu()
     prior = pkg("ops").GCRNOp(weights("GCRN"), DEV)(x.to(DEV)).cpu()
-    with torch.no_grad():
-        ref = R.diffunet1_forward(weights("DiffUNet1"), x, xi, t)
-        ref_p = R.gcrn_forward(weights("GCRN"), x)
-    assert rel_l2(out, ref) < 2e-5
-    assert rel_l2(prior, ref_p) < 5e-5
+    g = golden("full_nets_seed91_t1001")                                   # the reference modules at T = 1001
+    assert_rows2_and_checksums(out, g, "eps_", 2e-5)
+    assert_rows2_and_checksums(prior, g, "gcrn_", 5e-5)
 
 
 def test_nocon_and_deltamu_sampling(L, weights):

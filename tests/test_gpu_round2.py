@@ -15,7 +15,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import ROOT, golden, oracle_sample_pair, pkg, rel_l2, seeded
+from conftest import ROOT, assert_rows2_and_checksums, full_pair, golden, pkg, rel_l2, seeded
 
 pytestmark = pytest.mark.gpu
 
@@ -48,13 +48,13 @@ def _trainer(weights, prior="GCRN", ddpm="DiffUNet1", sigma=False, params=None, 
         device=DEV, prior_state_dict=weights(prior), ddpm_state_dict=weights(ddpm), params=params)
 
 
-def _errors_vs_fp32_and_exact(R, weights, feat, x_T, got, fast, prior="GCRN"):
-    """rel-L2 of a HIP result against (a) the fp32 CPU oracle and (b) the same algorithm evaluated in float64, plus
-    (c) the fp32 oracle's own distance to (b).  Over 50 reverse steps the random eps-net amplifies rounding noise
+def _errors_vs_fp32_and_exact(fixture, got):
+    """rel-L2 of a HIP result against (a) the reference's fp32 CPU run and (b) the same statements evaluated in float64
+    (tests/golden/full_*.npz, oracle/make_golden_full.py), plus (c) the fp32 run's own distance to (b).  Over 50 reverse steps the random eps-net amplifies rounding noise
     (DESIGN.md §2): two correct fp32 implementations differ by about the sum of their distances to the exact answer, so
     the 1e-4 bound is asserted against the exact evaluation and, against the fp32 path, with that path's own noise
     added - both numbers are printed."""
-    ref, exact = oracle_sample_pair(R, weights, feat, x_T, fast, prior)
+    ref, exact, _ = full_pair(fixture)
     return rel_l2(got, ref), rel_l2(got, exact), rel_l2(ref, exact)
 
 
@@ -77,11 +77,9 @@ def test_config4_aia_prior_b32_t401(L, weights, R, prior):
         assert torch.equal(i1[0], init[b]), b
         assert torch.equal(s1[0], spec[b]), b
     assert torch.isfinite(spec).all()
-    with torch.no_grad():
-        ref, ref_init = R.sample(prior, weights(prior), weights("DiffUNet1"), feat[:1], x_T[:1], params.noise_schedule,
-                                 params.inference_noise_schedule, True, False)
-    assert rel_l2(init[0].cpu(), ref_init[0]) < 1e-4
-    assert rel_l2(spec[0].cpu(), ref[0]) < 1e-4
+    g = golden("full_%s_seed404_t401_6step" % prior)        # the reference's own loop on model/dbaiat.py + model/diff3.py
+    assert rel_l2(init[0].cpu(), g["init"][0]) < 1e-4
+    assert rel_l2(spec[0].cpu(), g["out"][0]) < 1e-4
 
 
 def test_config5_long_utterances_b16_t1001(L, weights, R):
@@ -101,11 +99,9 @@ def test_config5_long_utterances_b16_t1001(L, weights, R):
     for b in (0, 11):
         o1, s1 = one.enhance(wav[b:b + 1].to(DEV), x_T[b:b + 1].to(DEV))
         assert torch.equal(s1[0], spec[b]) and torch.equal(o1[0], out[b]), b
-    with torch.no_grad():
-        ref_w, ref_s = R.enhance("GCRN", weights("GCRN"), weights("DiffUNet1"), wav[:1], x_T[:1], params.noise_schedule,
-                                 params.inference_noise_schedule, True, False)
-    assert rel_l2(spec[0].cpu(), ref_s[0]) < 1e-4
-    assert rel_l2(out[0].cpu(), ref_w[0]) < 1e-4
+    g = golden("full_generate_wav_seed505_l160000")        # generate_wav's per-file statements executed from the reference's text
+    assert_rows2_and_checksums(spec[:1].cpu(), g, "spec_", 1e-4)
+    assert rel_l2(out[0].cpu(), g["wav"]) < 1e-4
 
 
 def test_config3_full_schedule_b32(L, weights, R):
@@ -125,7 +121,7 @@ def test_config3_full_schedule_b32(L, weights, R):
     for b in (0, 23):
         s1, _ = one.sample(feat[b:b + 1].to(DEV), x_T[b:b + 1].to(DEV))
         assert torch.equal(s1[0], spec[b]), b
-    e_ref, e_exact, e_ref_exact = _errors_vs_fp32_and_exact(R, weights, feat[:1], x_T[:1], spec[:1].cpu(), fast=False)
+    e_ref, e_exact, e_ref_exact = _errors_vs_fp32_and_exact("full_gcrn_seed77_t401_50step", spec[:1].cpu())
     print("config 3 (50 steps): HIP vs fp32 CPU oracle %.2e | HIP vs float64 evaluation %.2e | fp32 CPU oracle vs float64 "
           "evaluation %.2e" % (e_ref, e_exact, e_ref_exact))
     assert e_exact < 1e-4                                   # distance to the exact-arithmetic answer
@@ -264,8 +260,11 @@ def test_trainer_selects_the_conditioning_branch(L, weights):
     assert rel_l2(t.sample(feat, x_T).cpu(), g["out"]) < 1e-4
     prm2 = P.AttrDict(dict(P.params))
     prm2.deltamu = True                                     # both flags: the reference's if/elif takes pirorgrad (:70-73)
-    t2 = _trainer(weights, params=prm2)
-    assert t2.cond == "init" and not t2.deltamu
+    t2 = _trainer(weights, params=prm2)                     # ... for the model and the eps call; x_T still follows deltamu
+    assert t2.cond == "init" and not t2.deltamu and t2.xT_plus_init            # (:946-949): noise + X_init/11, final + X_init
+    gb = golden("sample_gcrn_fast_bothflags")               # the reference's own statements with both flags set
+    assert rel_l2(t2.sample(feat, x_T).cpu(), gb["out"]) < 1e-4
+    assert rel_l2(gb["out"], golden("sample_gcrn_fast")["out"]) > 1e-2         # a different result from pirorgrad alone
 
 
 def test_q_sample_branches_bit_exact(L, weights, R):
@@ -324,9 +323,7 @@ def test_aia_prior_long_sequence_t1001(L, weights, R):
     at a length that is neither a multiple of the chunk nor of four."""
     x = seeded((1, 2, 1001, 161), 93)
     got = pkg("ops").AiaOp(weights("aia_complex_trans_ri"), DEV)(x.to(DEV)).cpu()
-    with torch.no_grad():
-        ref = R.aia_complex_trans_ri_forward(weights("aia_complex_trans_ri"), x)
-    assert rel_l2(got, ref) < 1e-4
+    assert_rows2_and_checksums(got, golden("full_aia_seed93_t1001"), "", 1e-4)     # the reference module at T = 1001
     # attention core: qkv [B, 3E, T, F], sequence over frames (axis 1), E = 32, 4 heads of 8
     B, E, T, F_ = 2, 32, 1103, 3
     g = torch.Generator().manual_seed(8)
@@ -410,14 +407,14 @@ def test_split_bf16_full_size_b32(L, weights, R):
     for b in (0, 17, 31):
         s1, _ = one.sample(feat[b:b + 1].to(DEV), x_T[b:b + 1].to(DEV))
         assert torch.equal(s1[0], spec[b]), b
-    e_ref, e_exact, e_ref_exact = _errors_vs_fp32_and_exact(R, weights, feat[:1], x_T[:1], spec[:1].cpu(), fast=True)
+    e_ref, e_exact, e_ref_exact = _errors_vs_fp32_and_exact("full_gcrn_seed1234_t401_6step", spec[:1].cpu())
     print("split-bf16, 6 steps, B=32: vs fp32 CPU oracle %.2e | vs float64 evaluation %.2e | fp32 CPU oracle vs float64 %.2e"
           % (e_ref, e_exact, e_ref_exact))
     assert e_ref < 1e-4 and e_exact < 1e-4
     feat1, x_T1 = pkg("synth").synthetic_spectrogram(1, T, seed=77)
     full = P(DEV, "GCRN", weights("GCRN"), weights("DiffUNet1"), 1, T=T, fast_sampling=False, split_bf16=True, bank=bank)
     s50, _ = full.sample(feat1.to(DEV), x_T1.to(DEV))
-    e_ref, e_exact, e_ref_exact = _errors_vs_fp32_and_exact(R, weights, feat1, x_T1, s50.cpu(), fast=False)
+    e_ref, e_exact, e_ref_exact = _errors_vs_fp32_and_exact("full_gcrn_seed77_t401_50step", s50.cpu())
     print("split-bf16, 50 steps, T=401: vs fp32 CPU oracle %.2e | vs float64 evaluation %.2e | fp32 CPU oracle vs float64 %.2e"
           % (e_ref, e_exact, e_ref_exact))
     assert e_exact < 1e-4 and e_ref < 1e-4 + e_ref_exact
