@@ -4,8 +4,8 @@ O=gpurun_out/r2j; mkdir -p $O
 python bench.py > $O/bench_default.json 2> $O/bench_default.err; tail -c 600 $O/bench_default.json
 rocprofv3 --kernel-trace --stats -d $O/ks_default -o p --output-format csv -- python3 bench.py --no-cpu-baseline > $O/bench_default_prof.json 2> $O/ks_default.log
 rocprofv3 --kernel-trace --stats -d $O/ks_seq -o p --output-format csv -- python3 bench.py --no-cpu-baseline --inflight 1 --no-graph --steps 3 --warmup 1 > $O/bench_seq_prof.json 2> $O/ks_seq.log
-for c in FETCH_SIZE WRITE_SIZE; do rocprofv3 --pmc $c -d $O/pmc_$c -o p --output-format csv -- python3 bench.py --no-cpu-baseline --inflight 1 --no-graph --steps 1 --warmup 0 > /dev/null 2> $O/pmc_$c.log; done
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d $O/pmc_SQ -o p --output-format csv -- python3 bench.py --no-cpu-baseline --inflight 1 --no-graph --steps 1 --warmup 0 > /dev/null 2> $O/pmc_SQ.log
+for c in FETCH_SIZE WRITE_SIZE; do rocprofv3 --pmc $c -d $O/pmc_$c -o p --output-format csv -- python3 bench.py --no-cpu-baseline --no-fp32-compare --inflight 1 --no-graph --steps 1 --warmup 0 > /dev/null 2> $O/pmc_$c.log; done
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d $O/pmc_SQ -o p --output-format csv -- python3 bench.py --no-cpu-baseline --no-fp32-compare --inflight 1 --no-graph --steps 1 --warmup 0 > /dev/null 2> $O/pmc_SQ.log
 find $O -name "*.csv" | head -20
 for d in pmc_FETCH_SIZE pmc_WRITE_SIZE pmc_SQ; do f=$(find $O/$d -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp $f $O/$d/p_counter_collection.csv; done
 python tools/summarize_pmc.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_SQ $O/pmc_traffic.json > $O/pmc_traffic.log 2>&1; tail -3 $O/pmc_traffic.log

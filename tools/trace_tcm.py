@@ -1,5 +1,5 @@
 import importlib, os, sys, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as ge
 ge.build()
 nets = importlib.import_module("prior-diffuse_amd.nets")
