@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define PDSE_ABI_VERSION 3
+#define PDSE_ABI_VERSION 4
 
 typedef void* pdse_stream_t; /* hipStream_t */
 
@@ -511,6 +511,97 @@ typedef struct pdse_aham_desc {
   int32_t pad_;
 } pdse_aham_desc;
 
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * BiConvGLU / BiConvTransGLU block of the eps-net on PLANE tensors (csrc/bglu.hip; round 3).
+ * Replaces, per launch, one encoder / decoder stage of model/diff3.py (BiConvGLU :307-326, BiConvTransGLU :329-351,
+ * the BatchNorm2d + PReLU that follow it :122-141 / :172-203) together with the NEXT stage's 1x1 conv1 (and, in the
+ * encoder, the skip halves of both decoders' conv1) - the same mathematics as pdse_gconv_desc with epi BIGLU, korder 2.
+ *
+ * What changed against korder 2 (csrc/gconv3.hip):
+ *  - the 32-channel conv1 output H that the gather convolutions read travels between launches as its exact bf16
+ *    split planes in MFMA B-fragment order ("hp" tensors), written once by the producer's tail, so the K loop of the
+ *    consumer has no VALU work and gathers with 16-byte loads (round 2 split every activation again in each of the
+ *    4-6 taps that gather it);
+ *  - the workgroup is 4 waves, one per SIMD with the whole 512-register file, and its loop is software-pipelined: the
+ *    K loop of tile i+1 (matrix instructions only) is issued interleaved with the tail of tile i (vector
+ *    instructions mostly) in ONE basic block - on gfx950 a vector instruction only hides behind a matrix instruction
+ *    of the same wave's stream;
+ *  - BatchNorm is folded into conv2 (W' = diag(s) Wc2, b' = s bc2 + t), -log2(e) into l_conv / r_conv
+ *    (sigmoid(m) = rcp(1 + exp2(m'))), the gather biases seed the accumulators: all on the host, in float64.
+ *
+ * hp tensor (uint16 = bf16 bit patterns), np planes (3: exact split, fp32-equivalent; 1: plain bf16):
+ *     hp[b][tp][g][plane][fp][e],   tp in [0, Tp), g in [0, 4), fp in [0, Fp), e in [0, 8)
+ *   holds channel c = 16 (g >> 1) + 8 (e >> 2) + 4 (g & 1) + (e & 3) of frame t = tp - t0, bin f = fp - f0: group
+ *   g = 2 q + h is what lane half h feeds to K block q, and (q, h, e) is the accumulator register order of the
+ *   producer (register 8 q + e of lane half h), so a producer lane stores its 16 channels as 2 x np 16-byte pieces.
+ *   Margins (tp < t0, fp < f0, fp >= f0 + F) stay zero (decoders: the transposed convolution's out-of-range taps are
+ *   addresses, not branches); encoder tensors hold the explicit pad frame (t = -1) at tp = 0.  OUTPUT tensors of a launch
+ *   (nx_hp, nx_out[]) must be allocated with B + 1 items: item B takes the stores of lanes without a position.
+ *
+ * Packed weights (uint16, [blocks][np][64 lanes][8]): block = 16 consecutive k, lane (row = lane & 31, h = lane >> 5),
+ *   element e.  Gather weights w0..w3: block tap*2 + q, k -> channel as above (packing.pack_bglu_gather);
+ *   wlc / wrc / wc2 / nx_w: packing.pack_s3_chain (accumulator-register k order), pre-scaled as described.
+ *   Encoder stage 1 (x0.ptr != NULL): K = 10 taps x 4 channels of the fp32 inputs (x, x_init), split in the kernel,
+ *   three blocks (packing.pack_s3_gather(.., 3, 16)).
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct pdse_bglu_desc {
+  const uint16_t* hp;      /* input planes, or NULL for encoder stage 1 */
+  int64_t hp_sb;           /* batch stride, uint16 units */
+  int32_t hp_Tp, hp_Fp, hp_t0, hp_f0;
+  pdse_src x0, x1;         /* encoder stage 1: two fp32 sources of two channels each (x, x_init) */
+  int32_t Tin, Fin;        /* logical input extent (stage 1 bounds checks) */
+  int32_t ntaps, sf_in;
+  int32_t tap_dt[10], tap_df[10];
+  int32_t p1mask, Fout1;   /* dual phase (transposed conv): taps of the odd output bins, number of valid odd bins */
+  int32_t B, Tout, Fout, np;
+  const uint16_t* w0;      /* gather weights L, R (even phase); w2, w3: odd phase or NULL */
+  const uint16_t* w1;
+  const uint16_t* w2;
+  const uint16_t* w3;
+  const uint16_t* wlc;     /* [2][np][64][8], scaled by -log2 e */
+  const uint16_t* wrc;
+  const uint16_t* wc2;     /* [2 tiles][2][np][64][8], BatchNorm folded (C2 == 64) */
+  const float* wc2v;       /* [32] (C2 == 1) */
+  const uint16_t* nx_w;    /* [nx_n][4][np][64][8] */
+  const float* bias0;      /* [B or 1][32] gather biases */
+  const float* bias1;
+  const float* bias0_t0;   /* output frame 0 (NULL: as bias0) */
+  const float* bias1_t0;
+  int64_t bias_sb;
+  const float* blc;        /* [32], scaled by -log2 e */
+  const float* brc;
+  const float* bc2;        /* [C2], BatchNorm folded */
+  float slope;             /* PReLU slope of the block output (1: none); must be <= 1: PReLU(v) = max(v, slope v) */
+  int32_t C2;              /* 64 or 1 */
+  float* out;              /* C2 == 1: one channel; C2 == 64 and nx_n == 0: the 64-channel block output */
+  int64_t out_sb, out_sc, out_st, out_sf, out_off;   /* dual phase: out_sf = stride of 2 bins */
+  int32_t pad0_, nx_n;
+  /* chained tile 0 (next stage's conv1): written as planes */
+  uint16_t* nx_hp;
+  int64_t nx_hp_sb;
+  int32_t nx_Tp, nx_Fp, nx_t0, nx_f0;
+  int32_t nx_row0;         /* 1: lanes of output frame 0 also write the tile's bias to frame -1 (encoder pad frame) */
+  int32_t nx_pad_;
+  const float* nx_add;     /* fp32 addend at (b, c, t, bin) or NULL (decoders: the encoder's skip half) */
+  int64_t add_sb, add_sc, add_st, add_sf;
+  /* chained tiles 1, 2 (encoder: the decoders' skip halves): fp32 */
+  float* nx_out[2];
+  int64_t nx_sb[2], nx_sc[2], nx_st[2], nx_sf[2];
+  const float* nx_bias[3]; /* [B or 1][32] per tile */
+  int64_t nx_bias_sb[3];
+} pdse_bglu_desc;
+
+/* fp32 [B, 32, T, F] -> hp planes (the standalone conv1 of the first decoder stage) */
+typedef struct pdse_planes_desc {
+  const float* in;
+  int64_t in_sb, in_sc, in_st, in_sf;
+  uint16_t* hp;
+  int64_t hp_sb;
+  int32_t hp_Tp, hp_Fp, hp_t0, hp_f0;
+  int32_t B, T, F, np;
+} pdse_planes_desc;
+
 enum pdse_op_kind {
   PDSE_OP_GCONV = 0,
   PDSE_OP_TIME = 1,
@@ -534,7 +625,9 @@ enum pdse_op_kind {
   PDSE_OP_GCRNLAST = 19,
   PDSE_OP_MASKLOSS = 20,
   PDSE_OP_GLSTM = 21,
-  PDSE_OP_TCM2 = 22
+  PDSE_OP_TCM2 = 22,
+  PDSE_OP_BGLU = 23,
+  PDSE_OP_PLANES = 24
 };
 
 int pdse_abi_version(void);
@@ -566,6 +659,8 @@ int pdse_gcrnlast_f32(const pdse_gcrnlast_desc* d, pdse_stream_t s);
 int pdse_masked_mse_f32(const pdse_maskloss_desc* d, pdse_stream_t s);
 int pdse_glstm_f32(const pdse_glstm_desc* d, pdse_stream_t s);
 int pdse_tcm2_bf16x3(const pdse_tcm2_desc* d, pdse_stream_t s);
+int pdse_bglu_planes(const pdse_bglu_desc* d, pdse_stream_t s);
+int pdse_split_planes(const pdse_planes_desc* d, pdse_stream_t s);
 
 /* plans: a recorded operator sequence replayed by one call (and capturable in a hipGraph) */
 typedef struct pdse_plan pdse_plan;

@@ -9,14 +9,14 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PDSE_LIB") or os.path.join(_HERE, "libpdse.so")   # PDSE_LIB: diagnostic builds only
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 ACT_NONE, ACT_PRELU, ACT_ELU, ACT_SIGMOID = 0, 1, 2, 3
 EPI_LINEAR, EPI_GLU, EPI_BIGLU = 0, 1, 2
 EW_DIV, EW_UPDATE, EW_UPDATE_FINAL, EW_COPY, EW_ADD_MUL = 0, 1, 2, 3, 4
 (OP_GCONV, OP_TIME, OP_EW, OP_COMPAND, OP_WAVPREP, OP_OLA, OP_SIGMA, OP_LN, OP_LSTM,
  OP_ROWLN, OP_CHLN, OP_ATTN, OP_GRU, OP_GNCOMB, OP_AHAM, OP_QSAMPLE, OP_TRANSPOSE, OP_TCM, OP_CRM, OP_GCRNLAST,
- OP_MASKLOSS, OP_GLSTM, OP_TCM2) = range(23)
+ OP_MASKLOSS, OP_GLSTM, OP_TCM2, OP_BGLU, OP_PLANES) = range(25)
 MASKLOSS_BLOCKS = 32
 
 _fp = C.c_void_p  # device pointers travel as integers
@@ -162,6 +162,30 @@ class Tcm2Desc(C.Structure):
                 ("dil", _i32), ("B", _i32), ("T", _i32), ("mode", _i32)]
 
 
+class BgluDesc(C.Structure):
+    """BiConv(Trans)GLU block on plane tensors (include/pdse.h: pdse_bglu_desc, csrc/bglu.hip)."""
+    _fields_ = [("hp", _fp), ("hp_sb", _i64), ("hp_Tp", _i32), ("hp_Fp", _i32), ("hp_t0", _i32), ("hp_f0", _i32),
+                ("x0", Src), ("x1", Src), ("Tin", _i32), ("Fin", _i32), ("ntaps", _i32), ("sf_in", _i32),
+                ("tap_dt", _i32 * 10), ("tap_df", _i32 * 10), ("p1mask", _i32), ("Fout1", _i32),
+                ("B", _i32), ("Tout", _i32), ("Fout", _i32), ("np", _i32),
+                ("w0", _fp), ("w1", _fp), ("w2", _fp), ("w3", _fp), ("wlc", _fp), ("wrc", _fp), ("wc2", _fp), ("wc2v", _fp),
+                ("nx_w", _fp), ("bias0", _fp), ("bias1", _fp), ("bias0_t0", _fp), ("bias1_t0", _fp), ("bias_sb", _i64),
+                ("blc", _fp), ("brc", _fp), ("bc2", _fp), ("slope", _f32), ("C2", _i32),
+                ("out", _fp), ("out_sb", _i64), ("out_sc", _i64), ("out_st", _i64), ("out_sf", _i64), ("out_off", _i64),
+                ("pad0_", _i32), ("nx_n", _i32),
+                ("nx_hp", _fp), ("nx_hp_sb", _i64), ("nx_Tp", _i32), ("nx_Fp", _i32), ("nx_t0", _i32), ("nx_f0", _i32),
+                ("nx_row0", _i32), ("nx_pad_", _i32),
+                ("nx_add", _fp), ("add_sb", _i64), ("add_sc", _i64), ("add_st", _i64), ("add_sf", _i64),
+                ("nx_out", _fp * 2), ("nx_sb", _i64 * 2), ("nx_sc", _i64 * 2), ("nx_st", _i64 * 2), ("nx_sf", _i64 * 2),
+                ("nx_bias", _fp * 3), ("nx_bias_sb", _i64 * 3)]
+
+
+class PlanesDesc(C.Structure):
+    _fields_ = [("in_", _fp), ("in_sb", _i64), ("in_sc", _i64), ("in_st", _i64), ("in_sf", _i64),
+                ("hp", _fp), ("hp_sb", _i64), ("hp_Tp", _i32), ("hp_Fp", _i32), ("hp_t0", _i32), ("hp_f0", _i32),
+                ("B", _i32), ("T", _i32), ("F", _i32), ("np", _i32)]
+
+
 class CrmDesc(C.Structure):
     _fields_ = [("x", _fp), ("o", _fp), ("ri", _fp), ("out", _fp), ("a1", _f32), ("b1", _f32), ("a2", _f32), ("b2", _f32),
                 ("a3", _f32), ("b3", _f32), ("plane", _i32), ("B", _i32), ("mode", _i32), ("pad_", _i32)]
@@ -172,7 +196,7 @@ class GcrnLastDesc(C.Structure):
                 ("out_sb", _i64), ("b1", _f32), ("b2", _f32), ("bn_scale", _f32), ("bn_shift", _f32), ("B", _i32), ("T", _i32)]
 
 
-DESC_TYPES = {OP_TCM2: Tcm2Desc, OP_GLSTM: GlstmDesc, OP_MASKLOSS: MasklossDesc, OP_GCRNLAST: GcrnLastDesc, OP_CRM: CrmDesc, OP_TCM: TcmDesc, OP_TRANSPOSE: TransposeDesc, OP_QSAMPLE: QsampleDesc, OP_ROWLN: RowlnDesc, OP_CHLN: ChlnDesc, OP_ATTN: AttnDesc, OP_GRU: GruDesc, OP_GNCOMB: GncombDesc,
+DESC_TYPES = {OP_BGLU: BgluDesc, OP_PLANES: PlanesDesc, OP_TCM2: Tcm2Desc, OP_GLSTM: GlstmDesc, OP_MASKLOSS: MasklossDesc, OP_GCRNLAST: GcrnLastDesc, OP_CRM: CrmDesc, OP_TCM: TcmDesc, OP_TRANSPOSE: TransposeDesc, OP_QSAMPLE: QsampleDesc, OP_ROWLN: RowlnDesc, OP_CHLN: ChlnDesc, OP_ATTN: AttnDesc, OP_GRU: GruDesc, OP_GNCOMB: GncombDesc,
               OP_AHAM: AhamDesc, OP_GCONV: GconvDesc, OP_TIME: TimeDesc, OP_EW: EwDesc, OP_COMPAND: CompandDesc,
               OP_WAVPREP: WavprepDesc, OP_OLA: OlaDesc, OP_SIGMA: SigmaDesc, OP_LN: LnDesc,
               OP_LSTM: LstmDesc}
@@ -184,7 +208,7 @@ EXPORTS = [
     "pdse_ola_f32", "pdse_sigma_mask_f32", "pdse_layernorm_f32", "pdse_lstm_f32",
     "pdse_rowln_prelu_f32", "pdse_chln_f32", "pdse_attention_f32", "pdse_bigru_f32", "pdse_gn_combine_f32",
     "pdse_aham_f32", "pdse_qsample_f32", "pdse_transpose_f32", "pdse_tcm_f32", "pdse_crm_f32", "pdse_gcrnlast_f32",
-    "pdse_masked_mse_f32", "pdse_glstm_f32", "pdse_tcm2_bf16x3",
+    "pdse_masked_mse_f32", "pdse_glstm_f32", "pdse_tcm2_bf16x3", "pdse_bglu_planes", "pdse_split_planes",
     "pdse_plan_create", "pdse_plan_add", "pdse_plan_size", "pdse_plan_set_device", "pdse_plan_clear", "pdse_plan_run",
     "pdse_plan_run_range",
     "pdse_plan_build_graph", "pdse_plan_launch_graph", "pdse_plan_time_ops", "pdse_plan_time_tag",
@@ -198,7 +222,7 @@ _DIRECT = {OP_GCONV: "pdse_gconv_f32", OP_TIME: "pdse_time_embed_f32", OP_EW: "p
            OP_GRU: "pdse_bigru_f32", OP_GNCOMB: "pdse_gn_combine_f32", OP_AHAM: "pdse_aham_f32",
            OP_QSAMPLE: "pdse_qsample_f32", OP_TRANSPOSE: "pdse_transpose_f32", OP_TCM: "pdse_tcm_f32", OP_CRM: "pdse_crm_f32", OP_GCRNLAST: "pdse_gcrnlast_f32",
            OP_MASKLOSS: "pdse_masked_mse_f32", OP_GLSTM: "pdse_glstm_f32",
-           OP_TCM2: "pdse_tcm2_bf16x3"}
+           OP_TCM2: "pdse_tcm2_bf16x3", OP_BGLU: "pdse_bglu_planes", OP_PLANES: "pdse_split_planes"}
 
 
 class PdseError(RuntimeError):

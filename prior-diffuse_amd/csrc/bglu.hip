@@ -1,0 +1,775 @@
+// bglu.hip - BiConvGLU / BiConvTransGLU blocks of the eps-net on PLANE tensors (include/pdse.h: pdse_bglu_desc).
+// Reference semantics: model/diff3.py:307-326 (BiConvGLU), :329-351 (BiConvTransGLU), the BatchNorm2d + PReLU behind
+// every stage (:122-141, :172-203) and the next stage's 1x1 conv1 (:146-149, :343-345).
+//
+// Round 3 redesign of csrc/gconv3.hip, from measurements of that kernel (profiles/r03_*):
+//   * one tile of 32 positions cost 288 bf16 MFMAs (9.2k matrix-pipe cycles) and ~2450 vector instructions (9.8k issue
+//     cycles), and the time per tile on a SIMD was their SUM plus ~5k of waits, scalar work and ~70 exec-mask branches:
+//     vector instructions of one wave do not hide behind matrix instructions of the other wave of the SIMD, only behind
+//     matrix instructions of their own stream (MI355X_MICROARCH.md: <= 5 vector instructions per 32x32x16 gap);
+//   * so the loop is software-pipelined by hand: ONE wave per SIMD (4-wave workgroups, 512 registers), and every
+//     iteration issues the K loop of tile i+1 - matrix instructions and LDS reads only, because the input arrives as
+//     the producer's bf16 split planes - together with the tail of tile i - vector instructions mostly - in one
+//     basic block (no exec-mask branches: out-of-range taps are zero margins, lanes beyond the last position compute
+//     on position 0 and only the final stores are predicated);
+//   * vector work removed from the tail: BatchNorm folded into conv2, -log2 e into l_conv / r_conv, biases seed the
+//     accumulators from LDS, PReLU is mul + max.
+// NP = 3: exact three-way bf16 split of every operand, six products per multiply-add (fp32-equivalent);
+// NP = 1: plain bf16 operands, one product (the opt-in bf16 mode; its own tolerance).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "pdse.h"
+#include "pdse_internal.h"
+
+#include "gconv_common.h"
+
+namespace {
+
+#ifdef BGLU_DIAG   // diagnostic build only (tools/time_bglu.py --diag): shader-clock and 100 MHz stamps around the loop
+__device__ unsigned long long g_bglu_diag[4];
+#endif
+
+constexpr int popc(int m) { return m ? (m & 1) + popc(m >> 1) : 0; }
+constexpr int rank_of(int m, int tap) { return popc(m & ((1 << tap) - 1)); }
+
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l,
+                                   16, 0, 0);
+}
+
+// acc += A B: A = NP fragment planes at w[0], w[64], .. (this lane's entry), B = NP planes of the activation
+template <int NP>
+__device__ __forceinline__ f32x16 mm(const uint4* w, const uint4 (&b)[NP], f32x16 acc) {
+  if constexpr (NP == 3) {
+    const uint4 a1 = w[0], a2 = w[64], a3 = w[128];
+    acc = mfma_bf16(a1, b[2], acc);   // smallest terms first
+    acc = mfma_bf16(a3, b[0], acc);
+    acc = mfma_bf16(a2, b[1], acc);
+    acc = mfma_bf16(a1, b[1], acc);
+    acc = mfma_bf16(a2, b[0], acc);
+    acc = mfma_bf16(a1, b[0], acc);
+  } else {
+    acc = mfma_bf16(w[0], b[0], acc);
+  }
+  return acc;
+}
+
+// the same with the A fragments already in registers (read from LDS one slot ahead)
+template <int NP>
+__device__ __forceinline__ f32x16 mmf(const uint4 (&a)[NP], const uint4 (&b)[NP], f32x16 acc) {
+  if constexpr (NP == 3) {
+    acc = mfma_bf16(a[0], b[2], acc);
+    acc = mfma_bf16(a[2], b[0], acc);
+    acc = mfma_bf16(a[1], b[1], acc);
+    acc = mfma_bf16(a[0], b[1], acc);
+    acc = mfma_bf16(a[1], b[0], acc);
+    acc = mfma_bf16(a[0], b[0], acc);
+  } else {
+    acc = mfma_bf16(a[0], b[0], acc);
+  }
+  return acc;
+}
+
+// round-to-nearest-even bf16 of two floats, packed (hipcc: v_cvt_pk_bf16_f32)
+__device__ __forceinline__ uint32_t pack_bf16(const float a, const float b) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  const f32x2 v = {a, b};
+  union { bf16x2 h; uint32_t u; } c;
+  c.h = __builtin_convertvector(v, bf16x2);
+  return c.u;
+}
+
+template <int NP>
+__device__ __forceinline__ void split8p(const float (&x)[8], uint4 (&p)[NP]) {
+#if defined(BGLU_DIAG) && defined(BGLU_NO_SPLIT)   // timing ablation: no split arithmetic (results wrong)
+  p[0] = make_uint4(__float_as_uint(x[0]), __float_as_uint(x[1]), __float_as_uint(x[2]), __float_as_uint(x[3]));
+  if constexpr (NP == 3) {
+    p[1] = make_uint4(__float_as_uint(x[4]), __float_as_uint(x[5]), __float_as_uint(x[6]), __float_as_uint(x[7]));
+    p[2] = p[0];
+  }
+  return;
+#endif
+  if constexpr (NP == 3) {
+    split8(x, p[0], p[1], p[2]);
+  } else {
+    p[0] = make_uint4(pack_bf16(x[0], x[1]), pack_bf16(x[2], x[3]), pack_bf16(x[4], x[5]), pack_bf16(x[6], x[7]));
+  }
+}
+
+// a 32-channel accumulator tile as the B operand of the next contraction: two K blocks of 8 registers
+template <int NP>
+__device__ __forceinline__ void split16p(const f32x16& X, uint4 (&p)[2][NP]) {
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = X[8 * s + j];
+    split8p<NP>(x, p[s]);
+  }
+}
+
+template <int NP>
+__device__ __forceinline__ f32x16 chain(const uint4* w, const uint4 (&p)[2][NP], f32x16 acc) {
+#pragma unroll
+  for (int s = 0; s < 2; ++s) acc = mm<NP>(w + s * NP * 64, p[s], acc);
+  return acc;
+}
+
+__device__ __forceinline__ float sigm2(const float m) {   // sigmoid of a pre-activation that is already scaled by -log2 e
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(m));
+}
+
+__device__ __forceinline__ float vmax(const float a, const float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+#define BGLU_FLOATS 512
+// float operands behind the fragment areas: bl 0, br 32, bl0 64, br0 96, blc 128, brc 160, bc2 192 (64), nxb 256 (96), wc2v 352
+enum { F_BL = 0, F_BR = 32, F_BL0 = 64, F_BR0 = 96, F_BLC = 128, F_BRC = 160, F_BC2 = 192, F_NXB = 256, F_WC2V = 352 };
+
+template <int NT, int P1MASK, int C2, int NXN, bool IN4, int NP>
+struct bglu_cfg {
+  static constexpr int WV = 4;
+  static constexpr int NB = IN4 ? 3 : 2 * NT;
+  static constexpr int NT1 = popc(P1MASK), NB1 = 2 * NT1;
+  static constexpr bool DUAL = P1MASK != 0;
+  static constexpr int BS = NP * 64;   // uint4 per fragment block
+  static constexpr int o_gL = 0, o_gR = NB * BS, o_gL1 = 2 * NB * BS, o_gR1 = o_gL1 + NB1 * BS, o_lc = o_gR1 + NB1 * BS,
+                       o_rc = o_lc + 2 * BS, o_c2 = o_rc + 2 * BS, o_nx = o_c2 + (C2 == 64 ? 4 * BS : 0),
+                       o_f = o_nx + NXN * 4 * BS;
+  static constexpr size_t lds_bytes = (size_t)o_f * sizeof(uint4) + BGLU_FLOATS * sizeof(float);
+};
+
+template <int NT, int P1MASK, int C2, int NXN, bool IN4, int NP>
+__global__ __launch_bounds__(256, 1) void bglu_kernel(const pdse_bglu_desc d) {
+  using CF = bglu_cfg<NT, P1MASK, C2, NXN, IN4, NP>;
+  constexpr int WV = CF::WV, NB = CF::NB, NB1 = CF::NB1, BS = CF::BS;
+  constexpr bool DUAL = CF::DUAL;
+  extern __shared__ uint4 img[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, h = lane >> 5;
+  const int b = blockIdx.y;
+  const int P = d.Tout * d.Fout;
+
+  // ---- the LDS image: every weight fragment of the launch by LDS-DMA (1 KB per wave instruction), then the floats
+  {
+    const uint4* const srcs[8] = {reinterpret_cast<const uint4*>(d.w0), reinterpret_cast<const uint4*>(d.w1),
+                                  reinterpret_cast<const uint4*>(d.w2), reinterpret_cast<const uint4*>(d.w3),
+                                  reinterpret_cast<const uint4*>(d.wlc), reinterpret_cast<const uint4*>(d.wrc),
+                                  reinterpret_cast<const uint4*>(d.wc2), reinterpret_cast<const uint4*>(d.nx_w)};
+    const int cnt[8] = {NB * NP, NB * NP, NB1 * NP, NB1 * NP, 2 * NP, 2 * NP, C2 == 64 ? 4 * NP : 0, NXN * 4 * NP};
+    constexpr int total = CF::o_f >> 6;
+    for (int c = __builtin_amdgcn_readfirstlane(wave); c < total; c += WV) {
+      int cc = c;
+      const uint4* src = nullptr;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (src == nullptr) {
+          if (cc < cnt[k]) src = srcs[k] + cc * 64;
+          else cc -= cnt[k];
+        }
+      }
+      glds16(src + lane, img + c * 64);
+    }
+    float* const fo = reinterpret_cast<float*>(img + CF::o_f);
+    for (int s = tid; s < BGLU_FLOATS; s += 64 * WV) {
+      const int k = s & 31;
+      float v = 0.f;
+      if (s < 32) v = d.bias0[(int64_t)b * d.bias_sb + k];
+      else if (s < 64) v = d.bias1[(int64_t)b * d.bias_sb + k];
+      else if (s < 96) v = (d.bias0_t0 ? d.bias0_t0 : d.bias0)[(int64_t)b * d.bias_sb + k];
+      else if (s < 128) v = (d.bias1_t0 ? d.bias1_t0 : d.bias1)[(int64_t)b * d.bias_sb + k];
+      else if (s < 160) v = d.blc[k];
+      else if (s < 192) v = d.brc[k];
+      else if (s < 256) v = (s - 192) < C2 ? d.bc2[s - 192] : 0.f;
+      else if (s < 352) {
+        const int i = (s - 256) >> 5;
+        v = (i < NXN && d.nx_bias[i]) ? d.nx_bias[i][(int64_t)b * d.nx_bias_sb[i] + k] : 0.f;
+      } else if (s < 384) v = (C2 == 1) ? d.wc2v[k] : 0.f;
+      fo[s] = v;
+    }
+  }
+  __syncthreads();
+  const float* const fop = reinterpret_cast<const float*>(img + CF::o_f);
+  const int ntiles = (P + 31) >> 5;
+  const int nrounds = (ntiles + WV - 1) / WV;
+
+  // ---- per-tile lane state
+  struct pos_t {
+    int t, j;
+    bool valid;
+    uint32_t vin;   // lane part of the input address: BYTE offset into the item's hp (planes) / unused (IN4)
+  };
+  const int Fp = d.hp_Fp;
+  auto locate = [&](const int rd, pos_t& ps) {
+    const int p = (rd * WV + wave) * 32 + col;
+    ps.valid = p < P;
+    ps.t = ps.valid ? p / d.Fout : 0;
+    ps.j = ps.valid ? p - ps.t * d.Fout : 0;
+    ps.vin = (uint32_t)(ps.t * (4 * NP * Fp) + h * (NP * Fp) + ps.j * d.sf_in) << 4;
+  };
+  // Address of (tap, K block q, plane pl) of a lane = wave-uniform base (scalar registers) + the lane's 32-bit BYTE offset:
+  // the global_load saddr form.  (As uniform pointer + 32-bit index of 16-byte elements the byte offset does not provably
+  // fit 32 bits, hipcc then keeps a 64-bit address per load in vector registers - 72 of them - and spills; a spill reload
+  // is a scratch load followed by s_waitcnt vmcnt(0), which drains every prefetched plane: 20k instead of 10k cycles.)
+  const char* const hpb = IN4 ? nullptr : reinterpret_cast<const char*>(d.hp + (int64_t)b * d.hp_sb);
+  auto ubase = [&](const int tap, const int q, const int pl) -> const char* {
+    return hpb + ((int64_t)(((d.tap_dt[tap] + d.hp_t0) * 4 + 2 * q) * (NP * Fp) + pl * Fp + d.tap_df[tap] + d.hp_f0) << 4);
+  };
+  // input operands of one tile: planes [tap][q][plane] (or, stage 1, the raw fp32 gathers [slot][4])
+  struct in_t {
+    uint4 pl[IN4 ? 1 : NT][2][NP];
+    float raw[IN4 ? 6 : 1][4];
+    unsigned live;
+  };
+  auto request_tap = [&](const pos_t& ps, in_t& in, const int tap) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl) in.pl[tap][q][pl] = *reinterpret_cast<const uint4*>(ubase(tap, q, pl) + (size_t)ps.vin);
+  };
+  auto request_in4 = [&](const pos_t& ps, in_t& in) {
+    // slot s = 2q + w: tap 4q + 2h + w of the ten (2,5) taps, channels (x 0, x 1, x_init 0, x_init 1); taps >= 10: zero
+    in.live = 0;
+#pragma unroll
+    for (int s_ = 0; s_ < 6; ++s_) {
+      const int ta = 4 * (s_ >> 1) + (s_ & 1), tb = ta + 2;
+      const bool has_b = tb < 10, has_a = ta < 10;
+      const int dt = h ? (has_b ? d.tap_dt[tb < 10 ? tb : 0] : 0) : (has_a ? d.tap_dt[ta < 10 ? ta : 0] : 0);
+      const int df = h ? (has_b ? d.tap_df[tb < 10 ? tb : 0] : 0) : (has_a ? d.tap_df[ta < 10 ? ta : 0] : 0);
+      const bool has = h ? has_b : has_a;
+      const int tin = ps.t + dt, fin = ps.j * d.sf_in + df;
+      const bool inb = has && ps.valid && fin >= 0 && fin < d.Fin && tin >= 0 && tin < d.Tin;
+      if (inb) in.live |= 1u << s_;
+      const unsigned o0 = inb ? (unsigned)((int64_t)b * d.x0.sb + (int64_t)tin * d.x0.st + (int64_t)fin * d.x0.sf) : 0u;
+      const unsigned o1 = inb ? (unsigned)((int64_t)b * d.x1.sb + (int64_t)tin * d.x1.st + (int64_t)fin * d.x1.sf) : 0u;
+      in.raw[s_][0] = d.x0.ptr[o0];
+      in.raw[s_][1] = (d.x0.ptr + d.x0.sc)[o0];
+      in.raw[s_][2] = d.x1.ptr[o1];
+      in.raw[s_][3] = (d.x1.ptr + d.x1.sc)[o1];
+    }
+  };
+  auto request_all = [&](const pos_t& ps, in_t& in) {
+    if constexpr (IN4) {
+      request_in4(ps, in);
+    } else {
+#pragma unroll
+      for (int tap = 0; tap < NT; ++tap) request_tap(ps, in, tap);
+    }
+  };
+
+  struct acc_t {
+    f32x16 L, R, L1, R1;
+  };
+  // accumulators start from the gather biases (frame 0 of the composed stage 1 has its own)
+  auto seed = [&](const pos_t& ps, acc_t& a) {
+    const bool f0 = ps.t == 0;
+    a.L = ld16(fop + (f0 ? F_BL0 : F_BL) + 4 * h);
+    a.R = ld16(fop + (f0 ? F_BR0 : F_BR) + 4 * h);
+    if constexpr (DUAL) {
+      a.L1 = a.L;
+      a.R1 = a.R;
+    }
+  };
+  auto kblock = [&](acc_t& a, const uint4 (&bp)[NP], const int tap, const int q) {
+    const int blk = (tap * 2 + q) * BS + lane;
+    a.L = mm<NP>(img + CF::o_gL + blk, bp, a.L);
+    a.R = mm<NP>(img + CF::o_gR + blk, bp, a.R);
+    if constexpr (DUAL) {
+      if ((P1MASK >> tap) & 1) {
+        const int blk1 = (rank_of(P1MASK, tap) * 2 + q) * BS + lane;
+        a.L1 = mm<NP>(img + CF::o_gL1 + blk1, bp, a.L1);
+        a.R1 = mm<NP>(img + CF::o_gR1 + blk1, bp, a.R1);
+      }
+    }
+  };
+  auto kloop_in4 = [&](acc_t& a, const in_t& in) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      float x[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = ((in.live >> (2 * q + (e >> 2))) & 1u) ? in.raw[2 * q + (e >> 2)][e & 3] : 0.f;
+      uint4 bp[NP];
+      split8p<NP>(x, bp);
+      const int blk = q * BS + lane;
+      a.L = mm<NP>(img + CF::o_gL + blk, bp, a.L);
+      a.R = mm<NP>(img + CF::o_gR + blk, bp, a.R);
+    }
+  };
+
+  // ---- stores.  Plane and skip-half stores are UNCONDITIONAL (lanes without a position write to the dump item B of the
+  // target tensor, which is allocated with B + 1 items), so they leave the tail as soon as their values exist and the iteration stays one basic block; only
+  // the few fp32 stores of the stages without a dump frame (last decoder stage, encoder stage 5) are predicated.
+  uint4* const nxb_ = NXN > 0 ? reinterpret_cast<uint4*>(d.nx_hp + (int64_t)b * d.nx_hp_sb) : nullptr;
+  const int nFp = d.nx_Fp;
+  // dump targets: item B of the tensor (allocated with B + 1 items), reached through the same 32-bit lane offset
+  const unsigned dump_hp = NXN > 0 ? (unsigned)(((int64_t)(d.B - b) * d.nx_hp_sb) >> 3) : 0u;
+  auto store_planes = [&](const uint4 (&zp)[2][NP], const bool ok, const int t, const int bin) {
+    // (frame t, bin) of the next stage's hp: lane half h owns groups g = 2q + h
+    const unsigned o = ok ? (unsigned)(((t + d.nx_t0) * 4 + h) * (NP * nFp) + bin + d.nx_f0) : dump_hp + (unsigned)(h * (NP * nFp));
+    uint4* const base = nxb_ + o;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl) base[(2 * q * NP + pl) * nFp] = zp[q][pl];
+  };
+  auto store_skip = [&](const f32x16& z, const int i, const pos_t& ps) {   // fp32 [B + 1 (dump item), 32, T, F]
+    const unsigned o = ps.valid ? (unsigned)((int64_t)ps.t * d.nx_st[i] + (int64_t)ps.j * d.nx_sf[i] + (int64_t)(4 * h) * d.nx_sc[i])
+                                : (unsigned)((int64_t)(d.B - b) * d.nx_sb[i] + (int64_t)(4 * h) * d.nx_sc[i]);
+    float* const zb = d.nx_out[i] + (int64_t)b * d.nx_sb[i];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) (zb + (int64_t)PDSE_KR(r) * d.nx_sc[i])[o] = z[r];
+  };
+  auto stores_masked = [&](const pos_t& ps, const auto& o0, const auto& o1) {
+    if (!ps.valid) return;
+    const int t = ps.t, j = ps.j;
+    const bool two = DUAL && j < d.Fout1;
+    float* const po = d.out + ((int64_t)b * d.out_sb + (int64_t)t * d.out_st + (int64_t)j * d.out_sf + d.out_off);
+    if constexpr (C2 == 1) {
+      if (h == 0) {
+        if constexpr (DUAL) {
+          const int64_t bin = d.out_sf >> 1;
+          if (two && bin == 1) store_pair(po, o0.v, o1.v);
+          else {
+            po[0] = o0.v;
+            if (two) po[bin] = o1.v;
+          }
+        } else {
+          po[0] = o0.v;
+        }
+      }
+    } else if constexpr (NXN == 0) {   // no chained tile: the 64-channel block output itself (encoder stage 5 -> TCM)
+#pragma unroll
+      for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) po[(int64_t)(32 * m2 + 4 * h + PDSE_KR(r)) * d.out_sc] = (m2 ? o0.O1 : o0.O0)[r];
+    }
+  };
+
+  // ---- the tail of one output phase as separately schedulable pieces (vocabulary of csrc/bglu_sched.inc).
+  // PReLU slope <= 1 (validated at launch): PReLU(v) = max(v, slope v).
+  const float slope = d.slope;
+  struct ph_t {
+    f32x16 L, R, mL, mR, G, O0, O1, Z0, Z1, Z2;
+    uint4 lp[2][NP], rp[2][NP], gp[2][NP], yp[2][2][NP], zp[2][NP];
+    float v;
+  };
+  auto split_half = [&](const f32x16& X, const int s_, uint4 (&p)[NP]) {
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = X[8 * s_ + j];
+    split8p<NP>(x, p);
+  };
+  // addend of chained tile 0 (decoders: the encoder's skip half of this conv1; its bias is part of it).  Lanes without a
+  // valid position (or without an odd bin) read a position that exists.
+  auto zseed = [&](const pos_t& ps, const int ph, f32x16& z) {
+    const bool two = ph == 0 || ps.j < d.Fout1;
+    const int bin = 2 * ps.j + (two ? ph : 0);
+    const unsigned o = (unsigned)((int64_t)b * d.add_sb + (int64_t)ps.t * d.add_st + (int64_t)bin * d.add_sf + (int64_t)(4 * h) * d.add_sc);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = (d.nx_add + (int64_t)PDSE_KR(r) * d.add_sc)[o];
+  };
+
+#define FRAG(buf, ptr)                                         \
+  {                                                            \
+    _Pragma("unroll") for (int pl_ = 0; pl_ < NP; ++pl_) fr[buf][pl_] = (ptr)[64 * pl_]; \
+  }
+#if defined(BGLU_DIAG) && defined(BGLU_NO_MM)   // timing ablation: no matrix instructions in the loop (results wrong)
+#define MM(buf, acc_, bp_) acc_[0] += __uint_as_float(fr[buf][0].x ^ bp_[0].x)
+#else
+#define MM(buf, acc_, bp_) acc_ = mmf<NP>(fr[buf], bp_, acc_)
+#endif
+#define GL(tap, q) (img + CF::o_gL + ((tap) * 2 + (q)) * BS + lane)
+#define GR(tap, q) (img + CF::o_gR + ((tap) * 2 + (q)) * BS + lane)
+#define GL1(rk, q) (img + CF::o_gL1 + ((rk) * 2 + (q)) * BS + lane)
+#define GR1(rk, q) (img + CF::o_gR1 + ((rk) * 2 + (q)) * BS + lane)
+#define GLI(q) (img + CF::o_gL + (q) * BS + lane)
+#define GRI(q) (img + CF::o_gR + (q) * BS + lane)
+#define LCW(s_) (img + CF::o_lc + (s_) * BS + lane)
+#define RCW(s_) (img + CF::o_rc + (s_) * BS + lane)
+#define C2W(m2, s_) (img + CF::o_c2 + ((m2) * 2 + (s_)) * BS + lane)
+#define NXW(i, m2, s_) (img + CF::o_nx + ((i) * 4 + (m2) * 2 + (s_)) * BS + lane)
+#define V_SL(S, s_)                                      \
+  {                                                      \
+    if ((s_) == 0) S.mL = ld16(fop + F_BLC + 4 * h);     \
+    split_half(S.L, s_, S.lp[s_]);                       \
+  }
+#define V_SR(S, s_)                                      \
+  {                                                      \
+    if ((s_) == 0) S.mR = ld16(fop + F_BRC + 4 * h);     \
+    split_half(S.R, s_, S.rp[s_]);                       \
+  }
+#define V_SG(S, lo, hi)                                                                                       \
+  {                                                                                                           \
+    _Pragma("unroll") for (int r = lo; r < hi; ++r) S.G[r] = S.L[r] * sigm2(S.mR[r]) + S.R[r] * sigm2(S.mL[r]); \
+  }
+#define V_SPG(S, s_)                                          \
+  {                                                           \
+    if ((s_) == 0) {                                          \
+      S.O0 = ld16(fop + F_BC2 + 4 * h);                       \
+      S.O1 = ld16(fop + F_BC2 + 32 + 4 * h);                  \
+    }                                                         \
+    split_half(S.G, s_, S.gp[s_]);                            \
+  }
+#define V_PR(S, m2)                                                                                        \
+  {                                                                                                        \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) S.O##m2[r] = vmax(S.O##m2[r], slope * S.O##m2[r]);       \
+  }
+#define V_SY(S, m2, s_)                                                     \
+  {                                                                         \
+    if ((m2) == 0 && (s_) == 0) {                                           \
+      if constexpr (!DUAL && NXN > 0) S.Z0 = ld16(fop + F_NXB + 4 * h);     \
+      if constexpr (NXN > 1) S.Z1 = ld16(fop + F_NXB + 32 + 4 * h);         \
+      if constexpr (NXN > 2) S.Z2 = ld16(fop + F_NXB + 64 + 4 * h);         \
+    }                                                                       \
+    split_half(S.O##m2, s_, S.yp[m2][s_]);                                  \
+  }
+#define V_SZ(S, s_) split_half(S.Z0, s_, S.zp[s_]);
+#define V_ST0(S, ph)                                                                                   \
+  {                                                                                                    \
+    if constexpr (DUAL) {                                                                              \
+      store_planes(S.zp, pc.valid && ((ph) == 0 || pc.j < d.Fout1), pc.t, 2 * pc.j + (ph));            \
+    } else {                                                                                           \
+      store_planes(S.zp, pc.valid, pc.t, pc.j);                                                        \
+      if (d.nx_row0) { /* uniform: the explicit pad frame of the next encoder stage = the folded bias */ \
+        uint4 bp_[2][NP];                                                                              \
+        split16p<NP>(ld16(fop + F_NXB + 4 * h), bp_);                                                  \
+        store_planes(bp_, pc.valid && pc.t == 0, -1, pc.j);                                            \
+      }                                                                                                \
+    }                                                                                                  \
+  }
+#define V_STSKIP(S, i) store_skip(S.Z##i, (i)-1, pc);
+#define V_DOT(S, ph)                                                              \
+  {                                                                               \
+    const f32x16 vw_ = ld16(fop + F_WC2V + 4 * h);                                \
+    float part_ = 0.f;                                                            \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) part_ += vw_[r] * S.G[r];      \
+    const float v_ = part_ + __shfl_xor(part_, 32) + fop[F_BC2];                  \
+    S.v = vmax(v_, slope * v_);                                                   \
+  }
+#define V_KEEP(S)
+#define V_KSPLIT(q)                                                                                                               \
+  {                                                                                                                               \
+    float x_[8];                                                                                                                  \
+    _Pragma("unroll") for (int e = 0; e < 8; ++e) x_[e] = ((in.live >> (2 * (q) + (e >> 2))) & 1u) ? in.raw[2 * (q) + (e >> 2)][e & 3] : 0.f; \
+    split8p<NP>(x_, kb[q]);                                                                                                       \
+  }
+#define REQ(tap) request_tap(pnn, in, tap);
+#define REQ_IN4() request_in4(pnn, in);
+#define FRAG_FENCE __builtin_amdgcn_sched_barrier(0);
+#if defined(BGLU_DIAG) && defined(BGLU_NO_V)
+#undef V_SL
+#undef V_SR
+#undef V_SG
+#undef V_SPG
+#undef V_PR
+#undef V_SY
+#undef V_SZ
+#undef V_ST0
+#undef V_STSKIP
+#undef V_DOT
+#undef V_KSPLIT
+#define V_SL(S, s_)
+#define V_SR(S, s_)
+#define V_SG(S, lo, hi)
+#define V_SPG(S, s_)
+#define V_PR(S, m2)
+#define V_SY(S, m2, s_)
+#define V_SZ(S, s_)
+#define V_ST0(S, ph)
+#define V_STSKIP(S, i)
+#define V_DOT(S, ph)
+#define V_KSPLIT(q)
+#endif
+#if defined(BGLU_DIAG) && defined(BGLU_NO_REQ)
+#undef REQ
+#undef REQ_IN4
+#define REQ(tap)
+#define REQ_IN4()
+#endif
+#if defined(BGLU_DIAG) && defined(BGLU_NO_FRAG)
+#undef FRAG
+#define FRAG(buf, ptr)
+#endif
+#define SLOT_BEGIN {
+  // one slot: the LDS reads of the next slot's fragments first, then each MFMA followed by the vector instructions
+  // that fit its shadow; nothing crosses the slot boundary
+#define SLOT_END(hasm, hasv)                                                       \
+  if constexpr (NP == 3) {                                                         \
+    _Pragma("unroll") for (int g_ = 0; g_ < 6; ++g_) {                             \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                           \
+      __builtin_amdgcn_sched_group_barrier(0x002, 9, 0);                           \
+    }                                                                              \
+  } else {                                                                         \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                             \
+  }                                                                                \
+  __builtin_amdgcn_sched_barrier(0);                                               \
+  }
+
+  // ---- the software pipeline over this workgroup's rounds r_k = blockIdx.x + k gridDim.x
+  const int stride = gridDim.x;
+  int rd = blockIdx.x;
+  if (rd >= nrounds) return;
+  pos_t pc, pn;
+  in_t in;
+  acc_t acc, accn;
+  locate(rd, pc);
+  request_all(pc, in);
+  seed(pc, acc);
+  if constexpr (IN4) {
+    kloop_in4(acc, in);
+  } else {
+#pragma unroll
+    for (int tap = 0; tap < NT; ++tap)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) kblock(acc, in.pl[tap][q], tap, q);
+  }
+  locate(rd + stride, pn);
+  request_all(pn, in);
+  constexpr int SCHED = IN4 ? 5 : (DUAL ? (C2 == 64 ? 1 : 2) : (NXN == 3 ? 3 : 4));
+#ifdef BGLU_DIAG
+  const unsigned long long dg_c0 = __builtin_amdgcn_s_memtime(), dg_r0 = __builtin_amdgcn_s_memrealtime();
+  unsigned dg_n = 0;
+#endif
+  while (true) {
+    // one iteration: tail of the current tile (vector instructions) beside the K loop of the next tile (matrix
+    // instructions), the requests of the tile after that behind each consumed tap - in the order of bglu_sched.inc
+    pos_t pnn;
+    locate(rd + 2 * stride, pnn);
+    ph_t SA, SB;
+    uint4 fr[2][NP];
+    uint4 kb[IN4 ? 3 : 1][NP];
+    SA.L = acc.L;
+    SA.R = acc.R;
+    if constexpr (DUAL) {
+      SB.L = acc.L1;
+      SB.R = acc.R1;
+      if constexpr (NXN > 0) {
+        zseed(pc, 0, SA.Z0);
+        zseed(pc, 1, SB.Z0);
+      }
+    }
+    seed(pn, accn);
+#if defined(BGLU_DIAG) && (defined(BGLU_NO_V) || defined(BGLU_NO_FRAG))
+    {   // timing ablations: every operand the skipped code would have produced is defined (from live values)
+      const uint4 u_ = make_uint4(__float_as_uint(acc.L[0]), __float_as_uint(acc.R[1]), lane, rd);
+      for (int a_ = 0; a_ < 2; ++a_)
+        for (int p_ = 0; p_ < NP; ++p_) {
+          SA.lp[a_][p_] = SA.rp[a_][p_] = SA.gp[a_][p_] = SA.zp[a_][p_] = SB.lp[a_][p_] = SB.rp[a_][p_] = SB.gp[a_][p_] = SB.zp[a_][p_] = u_;
+          SA.yp[0][a_][p_] = SA.yp[1][a_][p_] = SB.yp[0][a_][p_] = SB.yp[1][a_][p_] = u_;
+          fr[a_][p_] = u_;
+          if constexpr (IN4) kb[a_][p_] = kb[2][p_] = u_;
+        }
+      SA.mL = SA.mR = SA.G = SA.O0 = SA.O1 = SA.Z1 = SA.Z2 = SB.mL = SB.mR = SB.G = SB.O0 = SB.O1 = acc.L;
+      if constexpr (!DUAL) SA.Z0 = acc.R;
+      SA.v = SB.v = acc.L[3];
+    }
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (SCHED == 1) {
+#define BGLU_SCHED 1
+#include "bglu_sched.inc"
+#undef BGLU_SCHED
+    } else if constexpr (SCHED == 2) {
+#define BGLU_SCHED 2
+#include "bglu_sched.inc"
+#undef BGLU_SCHED
+    } else if constexpr (SCHED == 3) {
+#define BGLU_SCHED 3
+#include "bglu_sched.inc"
+#undef BGLU_SCHED
+    } else if constexpr (SCHED == 4) {
+#define BGLU_SCHED 4
+#include "bglu_sched.inc"
+#undef BGLU_SCHED
+    } else {
+#define BGLU_SCHED 5
+#include "bglu_sched.inc"
+#undef BGLU_SCHED
+    }
+    if constexpr (C2 == 1 || NXN == 0) stores_masked(pc, SA, SB);
+    rd += stride;
+#ifdef BGLU_DIAG
+    ++dg_n;
+    if (rd >= nrounds && lane == 0) {
+      atomicAdd(&g_bglu_diag[0], __builtin_amdgcn_s_memtime() - dg_c0);
+      atomicAdd(&g_bglu_diag[1], __builtin_amdgcn_s_memrealtime() - dg_r0);
+      atomicAdd(&g_bglu_diag[2], (unsigned long long)dg_n);
+      atomicAdd(&g_bglu_diag[3], 1ull);
+    }
+#endif
+    if (rd >= nrounds) break;
+    acc = accn;
+    pc = pn;
+    pn = pnn;
+  }
+}
+
+// fp32 [B, 32, T, F] -> planes (the first decoder stage's standalone conv1 output)
+template <int NP>
+__global__ __launch_bounds__(256) void planes_kernel(const pdse_planes_desc d) {
+  const int64_t n = (int64_t)d.B * d.T * d.F * 4;   // one thread per (b, t, g, f): 8 channels
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int f = (int)(i % d.F);
+  const int g = (int)((i / d.F) & 3);
+  const int64_t bt = i / ((int64_t)4 * d.F);
+  const int t = (int)(bt % d.T), b = (int)(bt / d.T);
+  const int q = g >> 1, h = g & 1;
+  float x[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = 16 * q + 8 * (e >> 2) + 4 * h + (e & 3);
+    x[e] = d.in[(int64_t)b * d.in_sb + (int64_t)c * d.in_sc + (int64_t)t * d.in_st + (int64_t)f * d.in_sf];
+  }
+  uint4 p[NP];
+  split8p<NP>(x, p);
+  uint4* const base = reinterpret_cast<uint4*>(d.hp + (int64_t)b * d.hp_sb) + ((int64_t)(t + d.hp_t0) * 4 + g) * (NP * d.hp_Fp) + f + d.hp_f0;
+#pragma unroll
+  for (int pl = 0; pl < NP; ++pl) base[pl * d.hp_Fp] = p[pl];
+}
+
+template <int NT, int P1MASK, int C2, int NXN, bool IN4, int NP>
+int launch(const pdse_bglu_desc* d, hipStream_t s) {
+  using CF = bglu_cfg<NT, P1MASK, C2, NXN, IN4, NP>;
+  const int P = d->Tout * d->Fout;
+  const int rounds = (((P + 31) >> 5) + CF::WV - 1) / CF::WV;
+  static const int wgs = getenv("PDSE_BGLU_WGS") ? atoi(getenv("PDSE_BGLU_WGS")) : 256;
+  int gx = (wgs + d->B - 1) / d->B;
+  if (gx > rounds) gx = rounds;
+  if (gx < 1) gx = 1;
+  if (CF::lds_bytes > 160 * 1024) {
+    pdse_set_error("bglu: LDS image too large");
+    return 1;
+  }
+  const void* fn = (const void*)bglu_kernel<NT, P1MASK, C2, NXN, IN4, NP>;
+  // the attribute is per (function, device): a plan may be bound to any device of the process (pdse_plan_set_device)
+  static unsigned long long attr_mask = 0;
+  int dev = 0;
+  if (pdse_check_hip(hipGetDevice(&dev), "bglu: device")) return 1;
+  if (dev >= 64 || !((attr_mask >> dev) & 1ull)) {
+    if (pdse_check_hip(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "bglu lds attribute")) return 1;
+    if (dev < 64) attr_mask |= 1ull << dev;
+  }
+#ifdef BGLU_DIAG
+  unsigned long long z[4] = {0, 0, 0, 0};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bglu_diag), z, sizeof(z));
+#endif
+  hipLaunchKernelGGL((bglu_kernel<NT, P1MASK, C2, NXN, IN4, NP>), dim3(gx, d->B, 1), dim3(64 * CF::WV), CF::lds_bytes, s, *d);
+#ifdef BGLU_DIAG
+  (void)hipStreamSynchronize(s);
+  (void)hipMemcpyFromSymbol(z, HIP_SYMBOL(g_bglu_diag), sizeof(z));
+  if (z[3]) fprintf(stderr, "bglu diag NT %d P1 %d C2 %d NXN %d NP %d: %.0f cycles per iteration, %.2f iterations per wave, clock %.0f MHz\n", NT, P1MASK, C2, NXN, NP,
+                    (double)z[0] / (double)z[2], (double)z[2] / (double)z[3], (double)z[0] / (double)z[1] * 100.0);
+#endif
+  return pdse_check_launch("bglu");
+}
+
+template <int NP>
+int dispatch(const pdse_bglu_desc* d, hipStream_t s) {
+  if (d->x0.ptr) {   // encoder stage 1
+    if (d->nx_n == 3) return launch<10, 0, 64, 3, true, NP>(d, s);
+  } else if (d->p1mask) {
+    if (d->ntaps == 4 && d->p1mask == 5 && d->C2 == 64 && d->nx_n == 1) return launch<4, 5, 64, 1, false, NP>(d, s);
+    if (d->ntaps == 6 && d->p1mask == 27 && d->C2 == 1 && d->nx_n == 0) return launch<6, 27, 1, 0, false, NP>(d, s);
+  } else {
+    if (d->ntaps == 6 && d->C2 == 64 && d->nx_n == 3) return launch<6, 0, 64, 3, false, NP>(d, s);
+    if (d->ntaps == 6 && d->C2 == 64 && d->nx_n == 0) return launch<6, 0, 64, 0, false, NP>(d, s);
+  }
+  pdse_set_error("bglu: no instantiation for this (taps, phases, C2, chained tiles)");
+  return 1;
+}
+
+}   // namespace
+
+int pdse_bglu_launch(const pdse_bglu_desc* d, hipStream_t s) {
+  if (!d || !d->w0 || !d->w1 || !d->wlc || !d->wrc || !d->bias0 || !d->bias1 || !d->blc || !d->brc || !d->bc2) {
+    pdse_set_error("bglu: null operand");
+    return 1;
+  }
+  if (!(d->slope <= 1.0f)) {
+    pdse_set_error("bglu: PReLU slope must be <= 1 (max form); use the korder 2 kernels otherwise");
+    return 1;
+  }
+  if (d->B < 1 || d->Tout < 1 || d->Fout < 1 || !(d->np == 3 || d->np == 1) || !(d->C2 == 64 || d->C2 == 1) || d->nx_n < 0 ||
+      d->nx_n > 3 || d->ntaps < 1 || d->ntaps > 10) {
+    pdse_set_error("bglu: bad geometry (np in {1, 3}, C2 in {64, 1}, nx_n <= 3, ntaps <= 10)");
+    return 1;
+  }
+  if (d->p1mask && d->Fout1 > d->Fout) {
+    pdse_set_error("bglu: Fout1 > Fout");
+    return 1;
+  }
+  if ((d->C2 == 64 && !d->wc2) || (d->C2 == 1 && (!d->wc2v || !d->out)) || (d->C2 == 64 && d->nx_n == 0 && !d->out) || (d->nx_n > 0 && (!d->nx_w || !d->nx_hp)) ||
+      (d->nx_n > 1 && !d->nx_out[0]) || (d->nx_n > 2 && !d->nx_out[1]) || (d->p1mask && (!d->w2 || !d->w3))) {
+    pdse_set_error("bglu: an operand of the selected form is missing");
+    return 1;
+  }
+  if (!d->x0.ptr) {
+    // plane input: every tap must stay inside the margins of hp, and the lane offsets must fit 32 bits
+    if (!d->hp || d->hp_Fp < 1) {
+      pdse_set_error("bglu: null hp");
+      return 1;
+    }
+    const long long frame = 4ll * d->np * d->hp_Fp;
+    if ((long long)d->hp_Tp * frame >= (1ll << 31)) {
+      pdse_set_error("bglu: hp item exceeds 32-bit lane offsets");
+      return 1;
+    }
+    for (int i = 0; i < d->ntaps; ++i) {
+      const int tlo = d->tap_dt[i] + d->hp_t0, thi = d->Tout - 1 + d->tap_dt[i] + d->hp_t0;
+      const int flo = d->tap_df[i] + d->hp_f0, fhi = (d->Fout - 1) * d->sf_in + d->tap_df[i] + d->hp_f0;
+      if (tlo < 0 || thi >= d->hp_Tp || flo < 0 || fhi >= d->hp_Fp) {
+        pdse_set_error("bglu: a tap leaves the margins of hp");
+        return 1;
+      }
+    }
+  } else if (!d->x1.ptr || d->ntaps != 10 || d->p1mask) {
+    pdse_set_error("bglu: encoder stage 1 needs two fp32 sources and the ten (2,5) taps");
+    return 1;
+  }
+  if (d->nx_n > 0) {
+    const long long frame = 4ll * d->np * d->nx_Fp;
+    int maxbin = d->Fout - 1;
+    if (d->p1mask) maxbin = 2 * (d->Fout - 1) > 2 * (d->Fout1 - 1) + 1 ? 2 * (d->Fout - 1) : 2 * (d->Fout1 - 1) + 1;
+    if (d->nx_t0 + d->Tout > d->nx_Tp || d->nx_t0 - (d->nx_row0 ? 1 : 0) < 0 || d->nx_f0 < 0 || maxbin + d->nx_f0 >= d->nx_Fp ||
+        (long long)d->nx_Tp * frame >= (1ll << 31) || (d->p1mask != 0) != (d->nx_add != nullptr) ||
+        (long long)(d->B + 1) * d->nx_hp_sb / 8 >= (1ll << 32)) {
+      pdse_set_error("bglu: the chained tile does not fit its hp tensor");
+      return 1;
+    }
+    if (d->nx_add && (long long)d->B * d->add_sb >= (1ll << 31)) {
+      pdse_set_error("bglu: addend exceeds 32-bit lane offsets");
+      return 1;
+    }
+    for (int i = 0; i + 1 < d->nx_n; ++i)
+      if ((long long)(d->B + 1) * d->nx_sb[i] >= (1ll << 32)) {
+        pdse_set_error("bglu: skip tensor exceeds 32-bit lane offsets");
+        return 1;
+      }
+  }
+  return d->np == 3 ? dispatch<3>(d, s) : dispatch<1>(d, s);
+}
+
+int pdse_planes_launch(const pdse_planes_desc* d, hipStream_t s) {
+  if (!d || !d->in || !d->hp || d->B < 1 || d->T < 1 || d->F < 1 || !(d->np == 3 || d->np == 1)) {
+    pdse_set_error("planes: bad argument");
+    return 1;
+  }
+  if (d->hp_t0 < 0 || d->hp_f0 < 0 || d->hp_t0 + d->T > d->hp_Tp || d->hp_f0 + d->F > d->hp_Fp) {
+    pdse_set_error("planes: the tensor does not fit hp");
+    return 1;
+  }
+  const int64_t n = (int64_t)d->B * d->T * d->F * 4;
+  const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  if (d->np == 3) hipLaunchKernelGGL(planes_kernel<3>, grid, block, 0, s, *d);
+  else hipLaunchKernelGGL(planes_kernel<1>, grid, block, 0, s, *d);
+  return pdse_check_launch("planes");
+}

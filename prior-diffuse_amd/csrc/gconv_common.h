@@ -119,6 +119,12 @@ __device__ __forceinline__ f32x16 mfma_bf16(const uint4& a, const uint4& b, cons
 // the tail by 5 % only (22.4k -> 21.1k cycles per round, PDSE_S3_TRACE): the tail is a serial chain of split ->
 // fragment read -> six dependent MFMAs, not an issue-bound stream.
 __device__ __forceinline__ void split8(const float (&x)[8], uint4& p1, uint4& p2, uint4& p3) {
+#ifdef PDSE_ABLATE_SPLIT   // diagnostic build only (wrong results): the cost of the splits
+  p1 = make_uint4(__float_as_uint(x[0]), __float_as_uint(x[1]), __float_as_uint(x[2]), __float_as_uint(x[3]));
+  p2 = make_uint4(__float_as_uint(x[4]), __float_as_uint(x[5]), __float_as_uint(x[6]), __float_as_uint(x[7]));
+  p3 = make_uint4(p1.x ^ p2.x, p1.y ^ p2.y, p1.z ^ p2.z, p1.w ^ p2.w);
+  return;
+#endif
   uint32_t q1[4], q2[4], q3[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {

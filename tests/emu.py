@@ -533,7 +533,152 @@ def run_gcrnlast(d, mem):
     flat[idx] = res
 
 
-RUNNERS = {L.GcrnLastDesc: run_gcrnlast, L.TcmDesc: run_tcm, L.Tcm2Desc: run_tcm2, L.GconvDesc: run_gconv, L.TimeDesc: run_time, L.EwDesc: run_ew, L.CompandDesc: run_compand,
+
+def _bf16_round(v):
+    """What a one-plane (plain bf16) operand keeps of a float array."""
+    return P.bf16_to_f32(P.bf16_rne(v)).reshape(np.shape(v))
+
+
+def run_planes(d, mem):
+    """pdse_planes_desc: fp32 [B, 32, T, F] -> hp planes."""
+    flat, off = mem.view(d.in_)
+    b, c, t, f = np.meshgrid(np.arange(d.B), np.arange(32), np.arange(d.T), np.arange(d.F), indexing="ij")
+    x = flat[off + b * d.in_sb + c * d.in_sc + t * d.in_st + f * d.in_sf]
+    hpf, hoff = mem.view(d.hp, np.int16)
+    hp = hpf.view(np.uint16)[hoff:hoff + d.B * d.hp_sb].reshape(d.B, d.hp_Tp, 4, d.np, d.hp_Fp, 8)
+    assert d.hp_t0 == P.HP_T0 and d.hp_f0 == P.HP_F0 and d.hp_Tp == d.T + P.HP_T0 and d.hp_Fp == d.F + 2 * P.HP_F0
+    hp[...] = P.hp_split(x, d.np)
+
+
+def run_bglu(d, mem):
+    """pdse_bglu_desc (include/pdse.h, csrc/bglu.hip): gather convolutions on a plane tensor (or, encoder stage 1, on the two
+    fp32 sources), the BIGLU tail with the host-side foldings the descriptor documents (sigmoid from pre-activations
+    scaled by -log2 e, BatchNorm inside conv2, PReLU as max(v, slope v)), chained tiles written as planes / fp32.
+    One-plane (bf16) launches round every matrix operand to bf16 where the kernel does."""
+    B, T, Fo, npl = d.B, d.Tout, d.Fout, d.np
+    rnd = _bf16_round if npl == 1 else (lambda v: v)
+    u16 = lambda ptr, n: mem.arr(ptr, n, np.int16).view(np.uint16)   # noqa: E731
+    blk = npl * 64 * 8
+    nt = d.ntaps
+    taps = [(d.tap_dt[i], d.tap_df[i]) for i in range(nt)]
+    bI, tI, jI = np.meshgrid(np.arange(B), np.arange(T), np.arange(Fo), indexing="ij")
+
+    def unp(ptr, nb):
+        return np.asarray(u16(ptr, nb * blk)).reshape(nb, npl, 64, 8)
+
+    if d.x0.ptr:
+        W0, W1 = P.unpack_bglu_in4(unp(d.w0, 3)), P.unpack_bglu_in4(unp(d.w1, 3))     # [40, 32], k = tap*4 + channel
+        accL = np.zeros((B, 32, T, Fo), np.float32)
+        accR = np.zeros_like(accL)
+        for ti, (dt, df) in enumerate(taps):
+            tin, fin = tI + dt, jI * d.sf_in + df
+            inb = (tin >= 0) & (tin < d.Tin) & (fin >= 0) & (fin < d.Fin)
+            tcl, fcl = np.clip(tin, 0, d.Tin - 1), np.clip(fin, 0, d.Fin - 1)
+            for si, S in enumerate((d.x0, d.x1)):
+                flat, off = mem.view(S.ptr)
+                for c in range(2):
+                    v = rnd(np.where(inb, flat[off + bI * S.sb + c * S.sc + tcl * S.st + fcl * S.sf], 0.0).astype(np.float32))
+                    k = ti * 4 + si * 2 + c
+                    accL += W0[k][None, :, None, None] * v[:, None]
+                    accR += W1[k][None, :, None, None] * v[:, None]
+        accs = [(accL, accR)]
+    else:
+        hpf, hoff = mem.view(d.hp, np.int16)
+        hp = hpf.view(np.uint16)[hoff:hoff + B * d.hp_sb].reshape(B, d.hp_Tp, 4, npl, d.hp_Fp, 8)
+        H = P.hp_join(hp, with_margins=True)                                                 # [B, 32, Tp, Fp]
+        W = [P.unpack_bglu_gather(unp(p_, 2 * nt), nt) for p_ in (d.w0, d.w1)]
+        ph_taps = [list(range(nt))]
+        if d.p1mask:
+            t1 = [i for i in range(nt) if (d.p1mask >> i) & 1]
+            W += [P.unpack_bglu_gather(unp(p_, 2 * len(t1)), len(t1)) for p_ in (d.w2, d.w3)]
+            ph_taps.append(t1)
+        accs = []
+        for ph, tl in enumerate(ph_taps):
+            aL = np.zeros((B, 32, T, Fo), np.float32)
+            aR = np.zeros_like(aL)
+            for r, ti in enumerate(tl):
+                dt, df = taps[ti]
+                tp, fp = tI + dt + d.hp_t0, jI * d.sf_in + df + d.hp_f0
+                assert tp.min() >= 0 and tp.max() < d.hp_Tp and fp.min() >= 0 and fp.max() < d.hp_Fp
+                v = H[bI, :, tp, fp].transpose(0, 3, 1, 2)                                  # [B, 32, T, Fo]
+                aL += np.einsum("km,bktf->bmtf", W[2 * ph][32 * r:32 * r + 32], v, optimize=True)
+                aR += np.einsum("km,bktf->bmtf", W[2 * ph + 1][32 * r:32 * r + 32], v, optimize=True)
+            accs.append((aL, aR))
+
+    def vec(ptr, sb, n):
+        flat, off = mem.view(ptr)
+        return flat[off + np.arange(B)[:, None] * sb + np.arange(n)[None, :]][:, :, None, None]
+
+    bl, br = vec(d.bias0, d.bias_sb, 32), vec(d.bias1, d.bias_sb, 32)
+    Wlc = P.unpack_bglu_chain(unp(d.wlc, 2)[None], 32, 32)
+    Wrc = P.unpack_bglu_chain(unp(d.wrc, 2)[None], 32, 32)
+    blc, brc = mem.arr(d.blc, 32)[None, :, None, None], mem.arr(d.brc, 32)[None, :, None, None]
+    if d.C2 == 64:
+        Wc2 = P.unpack_bglu_chain(np.asarray(u16(d.wc2, 4 * blk)).reshape(2, 2, npl, 64, 8), 64, 32)
+        bc2 = mem.arr(d.bc2, 64)[None, :, None, None]
+    Wn = []
+    if d.nx_n:
+        nxw = np.asarray(u16(d.nx_w, d.nx_n * 4 * blk)).reshape(d.nx_n, 1, 4, npl, 64, 8)
+        Wn = [P.unpack_bglu_chain(nxw[i], 32, 64) for i in range(d.nx_n)]
+    slope = np.float32(d.slope)
+    assert slope <= 1.0
+    for ph, (aL, aR) in enumerate(accs):
+        Lh, Rh = aL + bl, aR + br
+        if d.bias0_t0:
+            Lh[:, :, 0] = (aL + vec(d.bias0_t0, d.bias_sb, 32))[:, :, 0]
+            Rh[:, :, 0] = (aR + vec(d.bias1_t0, d.bias_sb, 32))[:, :, 0]
+        mL = np.einsum("oc,bctf->botf", Wlc, rnd(Lh)) + blc          # pre-activations x (-log2 e)
+        mR = np.einsum("oc,bctf->botf", Wrc, rnd(Rh)) + brc
+        G = (Lh / (1.0 + np.exp2(mR)) + Rh / (1.0 + np.exp2(mL))).astype(np.float32)
+        jmax = Fo if ph == 0 else d.Fout1
+        if d.C2 == 1:
+            v = np.einsum("c,bctf->btf", mem.arr(d.wc2v, 32), G) + mem.arr(d.bc2, 1)[0]
+            y = np.maximum(v, slope * v).astype(np.float32)
+            flat, off = mem.view(d.out)
+            bin_ = d.out_sf // 2 if d.p1mask else 0
+            idx = off + bI[..., 0:1] * 0 + bI * d.out_sb + tI * d.out_st + jI * d.out_sf + d.out_off + ph * bin_
+            flat[idx[..., :jmax]] = y[..., :jmax]
+            continue
+        O = np.einsum("oc,bctf->botf", Wc2, rnd(G)) + bc2
+        Y = np.maximum(O, slope * O).astype(np.float32)
+        if d.nx_n == 0:
+            flat, off = mem.view(d.out)
+            co = np.arange(64)[None, :, None, None]
+            idx = off + bI[:, None] * d.out_sb + co * d.out_sc + tI[:, None] * d.out_st + jI[:, None] * d.out_sf + d.out_off
+            flat[np.broadcast_to(idx, Y.shape)] = Y
+            continue
+        for i in range(d.nx_n):
+            Z = np.einsum("oc,bctf->botf", Wn[i], rnd(Y)) + (vec(d.nx_bias[i], d.nx_bias_sb[i], 32) if d.nx_bias[i] else 0.0)
+            co = np.arange(32)[None, :, None, None]
+            if i == 0:
+                bins = (2 * jI + ph) if d.p1mask else jI
+                if d.nx_add:
+                    flat, off = mem.view(d.nx_add)
+                    idx = off + bI[:, None] * d.add_sb + co * d.add_sc + tI[:, None] * d.add_st + bins[:, None] * d.add_sf
+                    idx = np.where(np.broadcast_to((jI < jmax)[:, None], Z.shape), np.broadcast_to(idx, Z.shape), off)
+                    Z = Z + flat[idx]
+                Z = Z.astype(np.float32)
+                hpf, hoff = mem.view(d.nx_hp, np.int16)
+                nhp = hpf.view(np.uint16)[hoff:hoff + B * d.nx_hp_sb].reshape(B, d.nx_Tp, 4, npl, d.nx_Fp, 8)
+                new = P.hp_split(np.zeros((B, 32, d.nx_Tp - d.nx_t0, d.nx_Fp - 2 * d.nx_f0), np.float32), npl)   # shape helper
+                assert new.shape == nhp.shape and d.nx_t0 == P.HP_T0 and d.nx_f0 == P.HP_F0
+                for bb in range(B):
+                    for tt in range(T):
+                        cols = np.arange(jmax)
+                        fb = (2 * cols + ph) if d.p1mask else cols
+                        piece = P.hp_split(Z[bb:bb + 1, :, tt:tt + 1, :jmax], npl)[0, P.HP_T0, :, :, P.HP_F0:P.HP_F0 + jmax, :]
+                        nhp[bb, tt + d.nx_t0, :, :, fb + d.nx_f0, :] = piece.transpose(2, 0, 1, 3)
+                if d.nx_row0:
+                    bz = np.broadcast_to(vec(d.nx_bias[0], d.nx_bias_sb[0], 32), (B, 32, 1, Fo)).astype(np.float32)
+                    nhp[:, d.nx_t0 - 1, :, :, d.nx_f0:d.nx_f0 + Fo, :] = P.hp_split(bz, npl)[:, P.HP_T0, :, :, P.HP_F0:P.HP_F0 + Fo, :]
+            else:
+                flat, off = mem.view(d.nx_out[i - 1])
+                k_ = i - 1
+                idx = off + bI[:, None] * d.nx_sb[k_] + co * d.nx_sc[k_] + tI[:, None] * d.nx_st[k_] + jI[:, None] * d.nx_sf[k_]
+                flat[np.broadcast_to(idx, Z.shape)] = Z.astype(np.float32)
+
+
+RUNNERS = {L.BgluDesc: run_bglu, L.PlanesDesc: run_planes, L.GcrnLastDesc: run_gcrnlast, L.TcmDesc: run_tcm, L.Tcm2Desc: run_tcm2, L.GconvDesc: run_gconv, L.TimeDesc: run_time, L.EwDesc: run_ew, L.CompandDesc: run_compand,
            L.WavprepDesc: run_wavprep, L.OlaDesc: run_ola, L.SigmaDesc: run_sigma, L.LnDesc: run_ln,
            L.LstmDesc: run_lstm, L.GlstmDesc: run_glstm}
 

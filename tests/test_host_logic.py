@@ -28,14 +28,16 @@ def test_pack_roundtrip():
     assert sorted(P.RHO.reshape(-1).tolist()) == list(range(32))
 
 
-@pytest.mark.parametrize("chained,split", [(True, False), (False, False), (True, True)])
-def test_eps_net_plan_vs_oracle(weights, chained, split, monkeypatch):
+@pytest.mark.parametrize("chained,split,plane_h", [(True, False, False), (False, False, False), (True, True, False),
+                                                  (True, True, "auto"), (True, True, True)])
+def test_eps_net_plan_vs_oracle(weights, chained, split, plane_h, monkeypatch):
     """chained: every stage's conv1 rides on the previous stage's tail and the encoder/decoder block outputs are never
     stored (only en[4], the TCM input, is); unchained: the per-stage launches with all intermediates in memory.
     split: the BIGLU blocks' weights as exact three-way bf16 splits in bf16 MFMA fragment order (korder 2)."""
     nets = pkg("nets")
     monkeypatch.setattr(nets.EpsNetPlan, "chain_conv1", chained)
     monkeypatch.setattr(nets.EpsNetPlan, "split_bf16", split)
+    monkeypatch.setattr(nets.EpsNetPlan, "plane_h", plane_h)      # csrc/bglu.hip: conv1 outputs as bf16 split planes
     B, T = 2, 12
     sd = weights("DiffUNet1")
     ctx = nets.Ctx("cpu")
@@ -43,9 +45,11 @@ def test_eps_net_plan_vs_oracle(weights, chained, split, monkeypatch):
     net.build_time()
     net.build_step(0)
     n_conv1 = sum(1 for _, tag in net.descs if tag == nets.TAG_EPS_CONV1)
-    assert n_conv1 == (2 if chained else 16)          # chained: only decoder stage 5 x 2 (encoder stage 1 is composed)
+    n_planes = {False: 0, "auto": 5, True: 15}[plane_h]   # stages on plane tensors: the encoder / every stage
+    assert n_conv1 == (2 if chained else 16) + (2 if plane_h is True else 0)   # chained: only decoder stage 5 x 2 (+ its split into planes)
     n_split = sum(1 for d, _ in net.descs if isinstance(d, pkg("_lib").GconvDesc) and d.korder == 2)
-    assert n_split == (15 if split else 0)            # encoder stages 1-5 + 2 x 5 decoder stages
+    assert n_split == (15 - n_planes if split else 0)     # encoder stages 1-5 + 2 x 5 decoder stages
+    assert sum(1 for d, _ in net.descs if isinstance(d, pkg("_lib").BgluDesc)) == n_planes
     n_tcm2 = sum(1 for d, _ in net.descs if isinstance(d, pkg("_lib").Tcm2Desc))
     assert n_tcm2 == (19 if split else 0)             # the first block's conv1 + 18 residual blocks (csrc/tcm2.hip)
     x, xi = seeded((B, 2, T, 161), 3), seeded((B, 2, T, 161), 4) * 0.3

@@ -15,8 +15,9 @@ synth = importlib.import_module("prior-diffuse_amd.synth")
 L = importlib.import_module("prior-diffuse_amd._lib")
 
 
-def run(split, B=32, T=401):
-    net = nets.EpsNetPlan(nets.Ctx("cuda:0"), synth.make_state_dict("DiffUNet1"), B, T, time_cond=True, nsteps=1, split_bf16=split)
+def run(split, B=32, T=401, plane_h=None, planes=None):
+    net = nets.EpsNetPlan(nets.Ctx("cuda:0"), synth.make_state_dict("DiffUNet1"), B, T, time_cond=True, nsteps=1, split_bf16=split,
+                          plane_h=plane_h, planes=planes)
     net.build_time()
     net.build_step(0)
     net.finish()
@@ -29,12 +30,15 @@ def run(split, B=32, T=401):
         ms = net.plan.time_ops(0, len(net.descs), st)
         best = ms if best is None else [min(a, b) for a, b in zip(best, ms)]
     tot = 0.0
-    print("---- split_bf16 =", split)
+    print("---- split_bf16 =", split, "plane_h =", net.plane_h, "planes =", net.planes)
     for (d, tag), m in zip(net.descs, best):
         tot += m
         if isinstance(d, L.GconvDesc) and d.epi == L.EPI_BIGLU:
             print("  BIGLU korder %d taps %2d dual %d nx %d C2 %2d  %3d x %3d positions: %7.1f us" % (
                 d.korder, d.ntaps, 1 if d.w2 else 0, d.nx_n, d.C2, d.Tout, d.Fout, m * 1e3))
+        if isinstance(d, L.BgluDesc):
+            print("  BGLU planes %d taps %2d dual %d nx %d C2 %2d  %3d x %3d positions: %7.1f us" % (
+                d.np, d.ntaps, 1 if d.p1mask else 0, d.nx_n, d.C2, d.Tout, d.Fout, m * 1e3))
         if isinstance(d, L.Tcm2Desc):
             print("  TCM split mode %d dil %2d: %6.1f us" % (d.mode, d.dil, m * 1e3))
     tcm = sum(m for (d, tag), m in zip(net.descs, best) if tag == nets.TAG_TCM)
@@ -43,4 +47,7 @@ def run(split, B=32, T=401):
 
 if __name__ == "__main__":
     run(False)
+    run(True, plane_h=False)
     run(True)
+    run(True, plane_h=True)
+    run(True, planes=1)
