@@ -119,6 +119,31 @@ __device__ __forceinline__ f32x16 chain(const uint4* w, const uint4 (&p)[2][NP],
   return acc;
 }
 
+// Raw buffer access: address = resource base (4 scalar registers) + 32-bit lane byte offset + scalar byte offset, so no
+// 64-bit per-lane address lives in vector registers (with flat pointers hipcc kept one 64-bit address per load of a tile -
+// 72 registers - and spilled; every spill reload is a scratch load + s_waitcnt vmcnt(0), which drains all prefetches), and
+// reads beyond the resource return zero instead of faulting.
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+#define PDSE_RSRC_FLAGS 0x00020000
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, const uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, (int)bytes, PDSE_RSRC_FLAGS);
+}
+__device__ __forceinline__ uint4 bload16(const __amdgpu_buffer_rsrc_t r, const uint32_t voff, const int soff) {
+  const v4i_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, 0);
+  return make_uint4((uint32_t)v.x, (uint32_t)v.y, (uint32_t)v.z, (uint32_t)v.w);
+}
+__device__ __forceinline__ float bload4(const __amdgpu_buffer_rsrc_t r, const uint32_t voff, const int soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, soff, 0));
+}
+__device__ __forceinline__ void bstore16(const uint4& x, const __amdgpu_buffer_rsrc_t r, const uint32_t voff, const int soff) {
+  v4i_t v;
+  v.x = (int)x.x; v.y = (int)x.y; v.z = (int)x.z; v.w = (int)x.w;
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff, soff, 0);
+}
+__device__ __forceinline__ void bstore4(const float x, const __amdgpu_buffer_rsrc_t r, const uint32_t voff, const int soff) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, x), r, (int)voff, soff, 0);
+}
+
 __device__ __forceinline__ float sigm2(const float m) {   // sigmoid of a pre-activation that is already scaled by -log2 e
   return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(m));
 }
@@ -133,9 +158,9 @@ __device__ __forceinline__ float vmax(const float a, const float b) {
 // float operands behind the fragment areas: bl 0, br 32, bl0 64, br0 96, blc 128, brc 160, bc2 192 (64), nxb 256 (96), wc2v 352
 enum { F_BL = 0, F_BR = 32, F_BL0 = 64, F_BR0 = 96, F_BLC = 128, F_BRC = 160, F_BC2 = 192, F_NXB = 256, F_WC2V = 352 };
 
-template <int NT, int P1MASK, int C2, int NXN, bool IN4, int NP>
+template <int NT, int P1MASK, int C2, int NXN, bool IN4, int NP, bool PIPE>
 struct bglu_cfg {
-  static constexpr int WV = 4;
+  static constexpr int WV = PIPE ? 4 : 8;
   static constexpr int NB = IN4 ? 3 : 2 * NT;
   static constexpr int NT1 = popc(P1MASK), NB1 = 2 * NT1;
   static constexpr bool DUAL = P1MASK != 0;
@@ -146,9 +171,12 @@ struct bglu_cfg {
   static constexpr size_t lds_bytes = (size_t)o_f * sizeof(uint4) + BGLU_FLOATS * sizeof(float);
 };
 
-template <int NT, int P1MASK, int C2, int NXN, bool IN4, int NP>
-__global__ __launch_bounds__(256, 1) void bglu_kernel(const pdse_bglu_desc d) {
-  using CF = bglu_cfg<NT, P1MASK, C2, NXN, IN4, NP>;
+// PIPE true: 4 waves (one per SIMD, 512 registers), the K loop of tile i+1 interleaved with the tail of tile i.
+// PIPE false: 8 waves (two per SIMD, 256 registers), K loop and tail of the same tile one after the other - a wave issues at
+// most one instruction per four cycles, so two waves per SIMD double the issue rate and cover each other's stalls.
+template <int NT, int P1MASK, int C2, int NXN, bool IN4, int NP, bool PIPE>
+__global__ __launch_bounds__(PIPE ? 256 : 512, PIPE ? 1 : 2) void bglu_kernel(const pdse_bglu_desc d) {
+  using CF = bglu_cfg<NT, P1MASK, C2, NXN, IN4, NP, PIPE>;
   constexpr int WV = CF::WV, NB = CF::NB, NB1 = CF::NB1, BS = CF::BS;
   constexpr bool DUAL = CF::DUAL;
   extern __shared__ uint4 img[];
@@ -211,18 +239,19 @@ __global__ __launch_bounds__(256, 1) void bglu_kernel(const pdse_bglu_desc d) {
   auto locate = [&](const int rd, pos_t& ps) {
     const int p = (rd * WV + wave) * 32 + col;
     ps.valid = p < P;
-    ps.t = ps.valid ? p / d.Fout : 0;
-    ps.j = ps.valid ? p - ps.t * d.Fout : 0;
+    const int pp = ps.valid ? p : 0;   // branch-free: lanes without a position work on position 0
+    ps.t = pp / d.Fout;
+    ps.j = pp - ps.t * d.Fout;
     ps.vin = (uint32_t)(ps.t * (4 * NP * Fp) + h * (NP * Fp) + ps.j * d.sf_in) << 4;
   };
-  // Address of (tap, K block q, plane pl) of a lane = wave-uniform base (scalar registers) + the lane's 32-bit BYTE offset:
-  // the global_load saddr form.  (As uniform pointer + 32-bit index of 16-byte elements the byte offset does not provably
-  // fit 32 bits, hipcc then keeps a 64-bit address per load in vector registers - 72 of them - and spills; a spill reload
-  // is a scratch load followed by s_waitcnt vmcnt(0), which drains every prefetched plane: 20k instead of 10k cycles.)
-  const char* const hpb = IN4 ? nullptr : reinterpret_cast<const char*>(d.hp + (int64_t)b * d.hp_sb);
-  auto ubase = [&](const int tap, const int q, const int pl) -> const char* {
-    return hpb + ((int64_t)(((d.tap_dt[tap] + d.hp_t0) * 4 + 2 * q) * (NP * Fp) + pl * Fp + d.tap_df[tap] + d.hp_f0) << 4);
+  // (tap, K block q, plane pl) of a lane = buffer resource of this item's hp + the lane's byte offset (pos_t::vin) + a
+  // wave-uniform byte offset in a scalar register
+  const __amdgpu_buffer_rsrc_t r_in = IN4 ? make_rsrc(nullptr, 0)
+                                          : make_rsrc(d.hp + (int64_t)b * d.hp_sb, (uint32_t)d.hp_Tp * 4u * NP * (uint32_t)Fp * 16u);
+  auto soff_in = [&](const int tap, const int q, const int pl) -> int {
+    return (((d.tap_dt[tap] + d.hp_t0) * 4 + 2 * q) * (NP * Fp) + pl * Fp + d.tap_df[tap] + d.hp_f0) << 4;
   };
+  const __amdgpu_buffer_rsrc_t r_x0 = IN4 ? make_rsrc(d.x0.ptr, 0xfffffffcu) : r_in, r_x1 = IN4 ? make_rsrc(d.x1.ptr, 0xfffffffcu) : r_in;
   // input operands of one tile: planes [tap][q][plane] (or, stage 1, the raw fp32 gathers [slot][4])
   struct in_t {
     uint4 pl[IN4 ? 1 : NT][2][NP];
@@ -233,7 +262,7 @@ __global__ __launch_bounds__(256, 1) void bglu_kernel(const pdse_bglu_desc d) {
 #pragma unroll
     for (int q = 0; q < 2; ++q)
 #pragma unroll
-      for (int pl = 0; pl < NP; ++pl) in.pl[tap][q][pl] = *reinterpret_cast<const uint4*>(ubase(tap, q, pl) + (size_t)ps.vin);
+      for (int pl = 0; pl < NP; ++pl) in.pl[tap][q][pl] = bload16(r_in, ps.vin, soff_in(tap, q, pl));
   };
   auto request_in4 = [&](const pos_t& ps, in_t& in) {
     // slot s = 2q + w: tap 4q + 2h + w of the ten (2,5) taps, channels (x 0, x 1, x_init 0, x_init 1); taps >= 10: zero
@@ -248,12 +277,12 @@ __global__ __launch_bounds__(256, 1) void bglu_kernel(const pdse_bglu_desc d) {
       const int tin = ps.t + dt, fin = ps.j * d.sf_in + df;
       const bool inb = has && ps.valid && fin >= 0 && fin < d.Fin && tin >= 0 && tin < d.Tin;
       if (inb) in.live |= 1u << s_;
-      const unsigned o0 = inb ? (unsigned)((int64_t)b * d.x0.sb + (int64_t)tin * d.x0.st + (int64_t)fin * d.x0.sf) : 0u;
-      const unsigned o1 = inb ? (unsigned)((int64_t)b * d.x1.sb + (int64_t)tin * d.x1.st + (int64_t)fin * d.x1.sf) : 0u;
-      in.raw[s_][0] = d.x0.ptr[o0];
-      in.raw[s_][1] = (d.x0.ptr + d.x0.sc)[o0];
-      in.raw[s_][2] = d.x1.ptr[o1];
-      in.raw[s_][3] = (d.x1.ptr + d.x1.sc)[o1];
+      const uint32_t o0 = inb ? (unsigned)((int64_t)b * d.x0.sb + (int64_t)tin * d.x0.st + (int64_t)fin * d.x0.sf) : 0u;
+      const uint32_t o1 = inb ? (unsigned)((int64_t)b * d.x1.sb + (int64_t)tin * d.x1.st + (int64_t)fin * d.x1.sf) : 0u;
+      in.raw[s_][0] = bload4(r_x0, o0 << 2, 0);
+      in.raw[s_][1] = bload4(r_x0, o0 << 2, (int)(d.x0.sc << 2));
+      in.raw[s_][2] = bload4(r_x1, o1 << 2, 0);
+      in.raw[s_][3] = bload4(r_x1, o1 << 2, (int)(d.x1.sc << 2));
     }
   };
   auto request_all = [&](const pos_t& ps, in_t& in) {
@@ -307,25 +336,26 @@ __global__ __launch_bounds__(256, 1) void bglu_kernel(const pdse_bglu_desc d) {
   // ---- stores.  Plane and skip-half stores are UNCONDITIONAL (lanes without a position write to the dump item B of the
   // target tensor, which is allocated with B + 1 items), so they leave the tail as soon as their values exist and the iteration stays one basic block; only
   // the few fp32 stores of the stages without a dump frame (last decoder stage, encoder stage 5) are predicated.
-  uint4* const nxb_ = NXN > 0 ? reinterpret_cast<uint4*>(d.nx_hp + (int64_t)b * d.nx_hp_sb) : nullptr;
   const int nFp = d.nx_Fp;
-  // dump targets: item B of the tensor (allocated with B + 1 items), reached through the same 32-bit lane offset
-  const unsigned dump_hp = NXN > 0 ? (unsigned)(((int64_t)(d.B - b) * d.nx_hp_sb) >> 3) : 0u;
+  // dump targets: item B of the tensor (allocated with B + 1 items); all offsets are bytes from the start of the tensor
+  const uint32_t item_hp = NXN > 0 ? (uint32_t)(d.nx_hp_sb * 2) : 0u;
+  const __amdgpu_buffer_rsrc_t r_nx = make_rsrc(NXN > 0 ? d.nx_hp : nullptr, NXN > 0 ? (uint32_t)(d.B + 1) * item_hp : 0u);
   auto store_planes = [&](const uint4 (&zp)[2][NP], const bool ok, const int t, const int bin) {
     // (frame t, bin) of the next stage's hp: lane half h owns groups g = 2q + h
-    const unsigned o = ok ? (unsigned)(((t + d.nx_t0) * 4 + h) * (NP * nFp) + bin + d.nx_f0) : dump_hp + (unsigned)(h * (NP * nFp));
-    uint4* const base = nxb_ + o;
+    const uint32_t o = ok ? (uint32_t)b * item_hp + ((uint32_t)(((t + d.nx_t0) * 4 + h) * (NP * nFp) + bin + d.nx_f0) << 4)
+                          : (uint32_t)d.B * item_hp + ((uint32_t)(h * (NP * nFp)) << 4);
 #pragma unroll
     for (int q = 0; q < 2; ++q)
 #pragma unroll
-      for (int pl = 0; pl < NP; ++pl) base[(2 * q * NP + pl) * nFp] = zp[q][pl];
+      for (int pl = 0; pl < NP; ++pl) bstore16(zp[q][pl], r_nx, o, ((2 * q * NP + pl) * nFp) << 4);
   };
+  const __amdgpu_buffer_rsrc_t r_sk0 = make_rsrc(NXN > 1 ? d.nx_out[0] : nullptr, NXN > 1 ? (uint32_t)((d.B + 1) * d.nx_sb[0] * 4) : 0u);
+  const __amdgpu_buffer_rsrc_t r_sk1 = make_rsrc(NXN > 2 ? d.nx_out[1] : nullptr, NXN > 2 ? (uint32_t)((d.B + 1) * d.nx_sb[1] * 4) : 0u);
   auto store_skip = [&](const f32x16& z, const int i, const pos_t& ps) {   // fp32 [B + 1 (dump item), 32, T, F]
-    const unsigned o = ps.valid ? (unsigned)((int64_t)ps.t * d.nx_st[i] + (int64_t)ps.j * d.nx_sf[i] + (int64_t)(4 * h) * d.nx_sc[i])
-                                : (unsigned)((int64_t)(d.B - b) * d.nx_sb[i] + (int64_t)(4 * h) * d.nx_sc[i]);
-    float* const zb = d.nx_out[i] + (int64_t)b * d.nx_sb[i];
+    const uint32_t o = (uint32_t)(((int64_t)(ps.valid ? b : d.B) * d.nx_sb[i] + (ps.valid ? (int64_t)ps.t * d.nx_st[i] + (int64_t)ps.j * d.nx_sf[i] : 0) +
+                                   (int64_t)(4 * h) * d.nx_sc[i]) << 2);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) (zb + (int64_t)PDSE_KR(r) * d.nx_sc[i])[o] = z[r];
+    for (int r = 0; r < 16; ++r) bstore4(z[r], i == 0 ? r_sk0 : r_sk1, o, (int)((PDSE_KR(r) * d.nx_sc[i]) << 2));
   };
   auto stores_masked = [&](const pos_t& ps, const auto& o0, const auto& o1) {
     if (!ps.valid) return;
@@ -369,12 +399,13 @@ __global__ __launch_bounds__(256, 1) void bglu_kernel(const pdse_bglu_desc d) {
   };
   // addend of chained tile 0 (decoders: the encoder's skip half of this conv1; its bias is part of it).  Lanes without a
   // valid position (or without an odd bin) read a position that exists.
+  const __amdgpu_buffer_rsrc_t r_add = make_rsrc((DUAL && NXN > 0) ? d.nx_add : nullptr, (DUAL && NXN > 0) ? (uint32_t)(d.B * d.add_sb * 4) : 0u);
   auto zseed = [&](const pos_t& ps, const int ph, f32x16& z) {
     const bool two = ph == 0 || ps.j < d.Fout1;
     const int bin = 2 * ps.j + (two ? ph : 0);
-    const unsigned o = (unsigned)((int64_t)b * d.add_sb + (int64_t)ps.t * d.add_st + (int64_t)bin * d.add_sf + (int64_t)(4 * h) * d.add_sc);
+    const uint32_t o = (uint32_t)(((int64_t)b * d.add_sb + (int64_t)ps.t * d.add_st + (int64_t)bin * d.add_sf + (int64_t)(4 * h) * d.add_sc) << 2);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) z[r] = (d.nx_add + (int64_t)PDSE_KR(r) * d.add_sc)[o];
+    for (int r = 0; r < 16; ++r) z[r] = bload4(r_add, o, (int)((PDSE_KR(r) * d.add_sc) << 2));
   };
 
 #define FRAG(buf, ptr)                                         \
@@ -431,6 +462,7 @@ __global__ __launch_bounds__(256, 1) void bglu_kernel(const pdse_bglu_desc d) {
     }                                                                       \
     split_half(S.O##m2, s_, S.yp[m2][s_]);                                  \
   }
+#define V_ZSEED(S, ph) zseed(pc, ph, S.Z0);
 #define V_SZ(S, s_) split_half(S.Z0, s_, S.zp[s_]);
 #define V_ST0(S, ph)                                                                                   \
   {                                                                                                    \
@@ -461,8 +493,21 @@ __global__ __launch_bounds__(256, 1) void bglu_kernel(const pdse_bglu_desc d) {
     _Pragma("unroll") for (int e = 0; e < 8; ++e) x_[e] = ((in.live >> (2 * (q) + (e >> 2))) & 1u) ? in.raw[2 * (q) + (e >> 2)][e & 3] : 0.f; \
     split8p<NP>(x_, kb[q]);                                                                                                       \
   }
-#define REQ(tap) request_tap(pnn, in, tap);
-#define REQ_IN4() request_in4(pnn, in);
+#define REQ(tap) request_tap(p_req, in, tap);
+#define REQ_CUR(tap) request_tap(pc, in, tap);
+#define REQ_IN4() request_in4(p_req, in);
+#define V_TAKE()          \
+  {                       \
+    SA.L = acc.L;         \
+    SA.R = acc.R;         \
+    if constexpr (DUAL) { \
+      SB.L = acc.L1;      \
+      SB.R = acc.R1;      \
+    }                     \
+  }
+#ifndef BGLU_VPER
+#define BGLU_VPER 9   // vector instructions placed behind each MFMA of a slot (tuning: tools/time_bglu.py with PDSE_LIB builds)
+#endif
 #define FRAG_FENCE __builtin_amdgcn_sched_barrier(0);
 #if defined(BGLU_DIAG) && defined(BGLU_NO_V)
 #undef V_SL
@@ -483,6 +528,8 @@ __global__ __launch_bounds__(256, 1) void bglu_kernel(const pdse_bglu_desc d) {
 #define V_PR(S, m2)
 #define V_SY(S, m2, s_)
 #define V_SZ(S, s_)
+#undef V_ZSEED
+#define V_ZSEED(S, ph)
 #define V_ST0(S, ph)
 #define V_STSKIP(S, i)
 #define V_DOT(S, ph)
@@ -490,8 +537,10 @@ __global__ __launch_bounds__(256, 1) void bglu_kernel(const pdse_bglu_desc d) {
 #endif
 #if defined(BGLU_DIAG) && defined(BGLU_NO_REQ)
 #undef REQ
+#undef REQ_CUR
 #undef REQ_IN4
 #define REQ(tap)
+#define REQ_CUR(tap)
 #define REQ_IN4()
 #endif
 #if defined(BGLU_DIAG) && defined(BGLU_NO_FRAG)
@@ -505,7 +554,7 @@ __global__ __launch_bounds__(256, 1) void bglu_kernel(const pdse_bglu_desc d) {
   if constexpr (NP == 3) {                                                         \
     _Pragma("unroll") for (int g_ = 0; g_ < 6; ++g_) {                             \
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                           \
-      __builtin_amdgcn_sched_group_barrier(0x002, 9, 0);                           \
+      __builtin_amdgcn_sched_group_barrier(0x002, BGLU_VPER, 0);                   \
     }                                                                              \
   } else {                                                                         \
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                             \
@@ -517,19 +566,21 @@ __global__ __launch_bounds__(256, 1) void bglu_kernel(const pdse_bglu_desc d) {
   const int stride = gridDim.x;
   int rd = blockIdx.x;
   if (rd >= nrounds) return;
+  if constexpr (PIPE) {
   pos_t pc, pn;
   in_t in;
-  acc_t acc, accn;
+  acc_t accs[2];   // accumulators of the current / the next tile; the roles swap every iteration (the loop is unrolled twice:
+                   // as one body with "acc = accn" at its end hipcc copied all 64 accumulator registers per iteration)
   locate(rd, pc);
   request_all(pc, in);
-  seed(pc, acc);
+  seed(pc, accs[0]);
   if constexpr (IN4) {
-    kloop_in4(acc, in);
+    kloop_in4(accs[0], in);
   } else {
 #pragma unroll
     for (int tap = 0; tap < NT; ++tap)
 #pragma unroll
-      for (int q = 0; q < 2; ++q) kblock(acc, in.pl[tap][q], tap, q);
+      for (int q = 0; q < 2; ++q) kblock(accs[0], in.pl[tap][q], tap, q);
   }
   locate(rd + stride, pn);
   request_all(pn, in);
@@ -538,11 +589,16 @@ __global__ __launch_bounds__(256, 1) void bglu_kernel(const pdse_bglu_desc d) {
   const unsigned long long dg_c0 = __builtin_amdgcn_s_memtime(), dg_r0 = __builtin_amdgcn_s_memrealtime();
   unsigned dg_n = 0;
 #endif
-  while (true) {
-    // one iteration: tail of the current tile (vector instructions) beside the K loop of the next tile (matrix
-    // instructions), the requests of the tile after that behind each consumed tap - in the order of bglu_sched.inc
+  // one iteration: tail of the current tile (vector instructions) beside the K loop of the next tile (matrix instructions),
+  // the requests of the tile after that behind each consumed tap - in the order of bglu_sched.inc.  Returns true after
+  // the last tile of this wave.
+  auto iteration = [&](auto PAR) __attribute__((always_inline)) -> bool {
+    constexpr int I = decltype(PAR)::value;
+    acc_t& acc = accs[I];
+    acc_t& accn = accs[1 - I];
     pos_t pnn;
     locate(rd + 2 * stride, pnn);
+    const pos_t& p_req = pnn;
     ph_t SA, SB;
     uint4 fr[2][NP];
     uint4 kb[IN4 ? 3 : 1][NP];
@@ -551,27 +607,8 @@ __global__ __launch_bounds__(256, 1) void bglu_kernel(const pdse_bglu_desc d) {
     if constexpr (DUAL) {
       SB.L = acc.L1;
       SB.R = acc.R1;
-      if constexpr (NXN > 0) {
-        zseed(pc, 0, SA.Z0);
-        zseed(pc, 1, SB.Z0);
-      }
     }
     seed(pn, accn);
-#if defined(BGLU_DIAG) && (defined(BGLU_NO_V) || defined(BGLU_NO_FRAG))
-    {   // timing ablations: every operand the skipped code would have produced is defined (from live values)
-      const uint4 u_ = make_uint4(__float_as_uint(acc.L[0]), __float_as_uint(acc.R[1]), lane, rd);
-      for (int a_ = 0; a_ < 2; ++a_)
-        for (int p_ = 0; p_ < NP; ++p_) {
-          SA.lp[a_][p_] = SA.rp[a_][p_] = SA.gp[a_][p_] = SA.zp[a_][p_] = SB.lp[a_][p_] = SB.rp[a_][p_] = SB.gp[a_][p_] = SB.zp[a_][p_] = u_;
-          SA.yp[0][a_][p_] = SA.yp[1][a_][p_] = SB.yp[0][a_][p_] = SB.yp[1][a_][p_] = u_;
-          fr[a_][p_] = u_;
-          if constexpr (IN4) kb[a_][p_] = kb[2][p_] = u_;
-        }
-      SA.mL = SA.mR = SA.G = SA.O0 = SA.O1 = SA.Z1 = SA.Z2 = SB.mL = SB.mR = SB.G = SB.O0 = SB.O1 = acc.L;
-      if constexpr (!DUAL) SA.Z0 = acc.R;
-      SA.v = SB.v = acc.L[3];
-    }
-#endif
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (SCHED == 1) {
 #define BGLU_SCHED 1
@@ -605,10 +642,62 @@ __global__ __launch_bounds__(256, 1) void bglu_kernel(const pdse_bglu_desc d) {
       atomicAdd(&g_bglu_diag[3], 1ull);
     }
 #endif
-    if (rd >= nrounds) break;
-    acc = accn;
     pc = pn;
     pn = pnn;
+    return rd >= nrounds;
+  };
+  while (true) {
+    if (iteration(std::integral_constant<int, 0>{})) break;
+    if (iteration(std::integral_constant<int, 1>{})) break;
+  }
+    return;
+  } else {
+    // ---- 8 waves: K loop, then tail, per tile; the first two taps of the next tile are in flight during the tail
+    pos_t pc, pn;
+    in_t in;
+    acc_t acc;
+    locate(rd, pc);
+    if constexpr (IN4) {
+      request_in4(pc, in);
+    } else {
+      request_tap(pc, in, 0);
+      request_tap(pc, in, 1);
+    }
+    constexpr int SCHED = 10 + (IN4 ? 5 : (DUAL ? (C2 == 64 ? 1 : 2) : (NXN == 3 ? 3 : 4)));
+    while (true) {
+      locate(rd + stride, pn);
+      const pos_t& p_req = pn;
+      ph_t SA, SB;
+      uint4 fr[2][NP];
+      uint4 kb[IN4 ? 3 : 1][NP];
+      seed(pc, acc);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (SCHED == 11) {
+#define BGLU_SCHED 11
+#include "bglu_sched.inc"
+#undef BGLU_SCHED
+      } else if constexpr (SCHED == 12) {
+#define BGLU_SCHED 12
+#include "bglu_sched.inc"
+#undef BGLU_SCHED
+      } else if constexpr (SCHED == 13) {
+#define BGLU_SCHED 13
+#include "bglu_sched.inc"
+#undef BGLU_SCHED
+      } else if constexpr (SCHED == 14) {
+#define BGLU_SCHED 14
+#include "bglu_sched.inc"
+#undef BGLU_SCHED
+      } else {
+#define BGLU_SCHED 15
+#include "bglu_sched.inc"
+#undef BGLU_SCHED
+      }
+      if constexpr (C2 == 1 || NXN == 0) stores_masked(pc, SA, SB);
+      rd += stride;
+      if (rd >= nrounds) break;
+      pc = pn;
+    }
   }
 }
 
@@ -636,9 +725,9 @@ __global__ __launch_bounds__(256) void planes_kernel(const pdse_planes_desc d) {
   for (int pl = 0; pl < NP; ++pl) base[pl * d.hp_Fp] = p[pl];
 }
 
-template <int NT, int P1MASK, int C2, int NXN, bool IN4, int NP>
-int launch(const pdse_bglu_desc* d, hipStream_t s) {
-  using CF = bglu_cfg<NT, P1MASK, C2, NXN, IN4, NP>;
+template <int NT, int P1MASK, int C2, int NXN, bool IN4, int NP, bool PIPE>
+int launch_(const pdse_bglu_desc* d, hipStream_t s) {
+  using CF = bglu_cfg<NT, P1MASK, C2, NXN, IN4, NP, PIPE>;
   const int P = d->Tout * d->Fout;
   const int rounds = (((P + 31) >> 5) + CF::WV - 1) / CF::WV;
   static const int wgs = getenv("PDSE_BGLU_WGS") ? atoi(getenv("PDSE_BGLU_WGS")) : 256;
@@ -649,7 +738,7 @@ int launch(const pdse_bglu_desc* d, hipStream_t s) {
     pdse_set_error("bglu: LDS image too large");
     return 1;
   }
-  const void* fn = (const void*)bglu_kernel<NT, P1MASK, C2, NXN, IN4, NP>;
+  const void* fn = (const void*)bglu_kernel<NT, P1MASK, C2, NXN, IN4, NP, PIPE>;
   // the attribute is per (function, device): a plan may be bound to any device of the process (pdse_plan_set_device)
   static unsigned long long attr_mask = 0;
   int dev = 0;
@@ -662,7 +751,7 @@ int launch(const pdse_bglu_desc* d, hipStream_t s) {
   unsigned long long z[4] = {0, 0, 0, 0};
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bglu_diag), z, sizeof(z));
 #endif
-  hipLaunchKernelGGL((bglu_kernel<NT, P1MASK, C2, NXN, IN4, NP>), dim3(gx, d->B, 1), dim3(64 * CF::WV), CF::lds_bytes, s, *d);
+  hipLaunchKernelGGL((bglu_kernel<NT, P1MASK, C2, NXN, IN4, NP, PIPE>), dim3(gx, d->B, 1), dim3(64 * CF::WV), CF::lds_bytes, s, *d);
 #ifdef BGLU_DIAG
   (void)hipStreamSynchronize(s);
   (void)hipMemcpyFromSymbol(z, HIP_SYMBOL(g_bglu_diag), sizeof(z));
@@ -670,6 +759,17 @@ int launch(const pdse_bglu_desc* d, hipStream_t s) {
                     (double)z[0] / (double)z[2], (double)z[2] / (double)z[3], (double)z[0] / (double)z[1] * 100.0);
 #endif
   return pdse_check_launch("bglu");
+}
+
+template <int NT, int P1MASK, int C2, int NXN, bool IN4, int NP>
+int launch(const pdse_bglu_desc* d, hipStream_t s) {
+  // PDSE_BGLU_PIPE = 0 | 1 overrides the form (tuning); default: see bglu_kernel
+  static const int force = getenv("PDSE_BGLU_PIPE") ? atoi(getenv("PDSE_BGLU_PIPE")) : -1;
+  // measured (profiles/r03_bglu_forms.txt, B=32, T=401): the 8-wave form is 10-25 % faster than the pipelined 4-wave form
+  // on every geometry and for both plane counts: a wave issues at most one instruction per four cycles whatever its type,
+  // so two waves per SIMD double the issue rate, which the interleaving inside one wave does not make up for
+  const bool pipe = force >= 0 ? force != 0 : false;
+  return pipe ? launch_<NT, P1MASK, C2, NXN, IN4, NP, true>(d, s) : launch_<NT, P1MASK, C2, NXN, IN4, NP, false>(d, s);
 }
 
 template <int NP>
@@ -719,7 +819,7 @@ int pdse_bglu_launch(const pdse_bglu_desc* d, hipStream_t s) {
       return 1;
     }
     const long long frame = 4ll * d->np * d->hp_Fp;
-    if ((long long)d->hp_Tp * frame >= (1ll << 31)) {
+    if ((long long)d->hp_Tp * frame * 16 >= (1ll << 32)) {
       pdse_set_error("bglu: hp item exceeds 32-bit lane offsets");
       return 1;
     }
@@ -731,7 +831,7 @@ int pdse_bglu_launch(const pdse_bglu_desc* d, hipStream_t s) {
         return 1;
       }
     }
-  } else if (!d->x1.ptr || d->ntaps != 10 || d->p1mask) {
+  } else if (!d->x1.ptr || d->ntaps != 10 || d->p1mask || (long long)d->B * d->x0.sb * 4 >= (1ll << 32) || (long long)d->B * d->x1.sb * 4 >= (1ll << 32)) {
     pdse_set_error("bglu: encoder stage 1 needs two fp32 sources and the ten (2,5) taps");
     return 1;
   }
@@ -741,16 +841,16 @@ int pdse_bglu_launch(const pdse_bglu_desc* d, hipStream_t s) {
     if (d->p1mask) maxbin = 2 * (d->Fout - 1) > 2 * (d->Fout1 - 1) + 1 ? 2 * (d->Fout - 1) : 2 * (d->Fout1 - 1) + 1;
     if (d->nx_t0 + d->Tout > d->nx_Tp || d->nx_t0 - (d->nx_row0 ? 1 : 0) < 0 || d->nx_f0 < 0 || maxbin + d->nx_f0 >= d->nx_Fp ||
         (long long)d->nx_Tp * frame >= (1ll << 31) || (d->p1mask != 0) != (d->nx_add != nullptr) ||
-        (long long)(d->B + 1) * d->nx_hp_sb / 8 >= (1ll << 32)) {
+        (long long)(d->B + 1) * d->nx_hp_sb * 2 >= (1ll << 32)) {
       pdse_set_error("bglu: the chained tile does not fit its hp tensor");
       return 1;
     }
-    if (d->nx_add && (long long)d->B * d->add_sb >= (1ll << 31)) {
+    if (d->nx_add && (long long)d->B * d->add_sb * 4 >= (1ll << 32)) {
       pdse_set_error("bglu: addend exceeds 32-bit lane offsets");
       return 1;
     }
     for (int i = 0; i + 1 < d->nx_n; ++i)
-      if ((long long)(d->B + 1) * d->nx_sb[i] >= (1ll << 32)) {
+      if ((long long)(d->B + 1) * d->nx_sb[i] * 4 >= (1ll << 32)) {
         pdse_set_error("bglu: skip tensor exceeds 32-bit lane offsets");
         return 1;
       }

@@ -343,13 +343,11 @@ class EpsNetPlan(PlanBase):
     # (same goldens, same tolerances) at 16/6 of the fp32 MFMA rate.  False: v_mfma_f32_32x32x2_f32 throughout.
     split_bf16 = True
     split_tcm = True        # (with split_bf16 and fused_tcm) TCM blocks on the bf16 matrix cores too (csrc/tcm2.hip)
-    # (with split_bf16, chain_conv1, compose_stage1, DiffUNet1 only) the BIGLU blocks on PLANE tensors, software-pipelined
-    # (csrc/bglu.hip): the conv1 outputs travel between launches as bf16 split planes.  "auto": the stages where it is
-    # the faster kernel; True: every stage; False: csrc/gconv3.hip throughout.  Measured (profiles/r03_bglu_vs_gconv3.txt,
-    # B=32, T=401): with three planes the two kernels are within 2 % of each other over the encoder (584 vs 576 us) and
-    # gconv3 is faster over the decoders, so the fp32-equivalent default stays on gconv3; the bf16 mode (planes 1) exists
-    # only here.
-    plane_h = False
+    # (with split_bf16, chain_conv1, compose_stage1, DiffUNet1 only, PReLU slopes <= 1) the BIGLU blocks on PLANE tensors
+    # (csrc/bglu.hip): the conv1 outputs travel between launches as bf16 split planes written once by their producer.
+    # True: every stage (10-20 % faster than csrc/gconv3.hip per launch, profiles/r03_bglu_forms.txt; the only form of the
+    # bf16 mode); "auto": the encoder only; False: csrc/gconv3.hip throughout (fp32 conv1 tensors, split in every tap).
+    plane_h = True
     planes = 3              # 3: exact three-way bf16 split (fp32-equivalent); 1: plain bf16 operands (the opt-in bf16 mode)
     NSLOT = 20  # 15 stages + en1 real-row bias + 4 composed encoder-stage-1 biases (l/r x frame >= 1 / frame 0)
 

@@ -359,7 +359,8 @@ def test_split_bf16_networks_vs_goldens(L, weights, monkeypatch):
     out = op(x.to(DEV), xi.to(DEV), t)
     net = op._plans[(B, T)]
     torch.cuda.synchronize()
-    assert sum(1 for d, _ in net.descs if isinstance(d, L.GconvDesc) and d.korder == 2) == 15
+    # the 15 BIGLU stages: on plane tensors by default (csrc/bglu.hip), on csrc/gconv3.hip with plane_h False
+    assert sum(1 for d, _ in net.descs if isinstance(d, L.BgluDesc) or (isinstance(d, L.GconvDesc) and d.korder == 2)) == 15
     assert rel_l2(net.en[4].cpu().permute(0, 1, 3, 2), g["en5"]) < 2e-5
     print("split-bf16 vs golden %.2e | fp32 kernels vs golden %.2e | split vs fp32 kernels %.2e" % (
         rel_l2(out.cpu(), g["out"]), rel_l2(out32.cpu(), g["out"]), rel_l2(out.cpu(), out32.cpu())))

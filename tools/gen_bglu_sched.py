@@ -35,7 +35,10 @@ def popc(m):
 
 def build(variant):
     NT, P1, C2, NXN, IN4 = variant["NT"], variant["P1"], variant["C2"], variant["NXN"], variant["IN4"]
+    pipe = variant.get("pipe", True)      # False: K loop and tail of the SAME tile, one after the other (8-wave workgroups)
     dual = P1 != 0
+    accn = "accn" if pipe else "acc"
+    kprio = -1 if pipe else 1000
     items = []
     M, V = [], []
 
@@ -54,28 +57,35 @@ def build(variant):
     # ---- K loop of the NEXT tile (accn), always ready
     if IN4:
         for q in range(3):
-            vk = v("K.split%d" % q, "V_KSPLIT(%d);" % q, prio=100 - q)
-            m("K.L%d" % q, "MM(accn.L, kb[%d]);" % q, "GLI(%d)" % q, [vk], prio=-1)
-            m("K.R%d" % q, "MM(accn.R, kb[%d]);" % q, "GRI(%d)" % q, [vk], prio=-1,
-              after="REQ_IN4();" if q == 2 else None)
+            vk = v("K.split%d" % q, "V_KSPLIT(%d);" % q, prio=2000 - q)
+            m("K.L%d" % q, "MM(%s.L, kb[%d]);" % (accn, q), "GLI(%d)" % q, [vk], prio=kprio)
+            last = m("K.R%d" % q, "MM(%s.R, kb[%d]);" % (accn, q), "GRI(%d)" % q, [vk], prio=kprio,
+                     after="REQ_IN4();" if q == 2 else None)
     else:
         for tap in range(NT):
             for q in range(2):
                 last = None
-                m("K.L%d%d" % (tap, q), "MM(accn.L, in.pl[%d][%d]);" % (tap, q), "GL(%d,%d)" % (tap, q), prio=-1)
-                last = m("K.R%d%d" % (tap, q), "MM(accn.R, in.pl[%d][%d]);" % (tap, q), "GR(%d,%d)" % (tap, q), prio=-1)
+                m("K.L%d%d" % (tap, q), "MM(%s.L, in.pl[%d][%d]);" % (accn, tap, q), "GL(%d,%d)" % (tap, q), prio=kprio)
+                last = m("K.R%d%d" % (tap, q), "MM(%s.R, in.pl[%d][%d]);" % (accn, tap, q), "GR(%d,%d)" % (tap, q), prio=kprio)
                 if (P1 >> tap) & 1:
                     rk = popc(P1 & ((1 << tap) - 1))
-                    m("K.L1%d%d" % (tap, q), "MM(accn.L1, in.pl[%d][%d]);" % (tap, q), "GL1(%d,%d)" % (rk, q), prio=-1)
-                    last = m("K.R1%d%d" % (tap, q), "MM(accn.R1, in.pl[%d][%d]);" % (tap, q), "GR1(%d,%d)" % (rk, q), prio=-1)
+                    m("K.L1%d%d" % (tap, q), "MM(%s.L1, in.pl[%d][%d]);" % (accn, tap, q), "GL1(%d,%d)" % (rk, q), prio=kprio)
+                    last = m("K.R1%d%d" % (tap, q), "MM(%s.R1, in.pl[%d][%d]);" % (accn, tap, q), "GR1(%d,%d)" % (rk, q), prio=kprio)
                 if q == 1:
-                    last.after = "REQ(%d);" % tap
+                    if pipe:
+                        last.after = "REQ(%d);" % tap
+                    else:   # two taps ahead: the rest of this tile, then the first two taps of the next one
+                        last.after = "REQ_CUR(%d);" % (tap + 2) if tap + 2 < NT else "REQ(%d);" % (tap + 2 - NT)
+    klast = last
 
     # ---- tails (current tile), phase A (and B)
     for ph, S in enumerate(("SA", "SB") if dual else ("SA",)):
         base = 50 - 5 * ph      # phase A slightly ahead of phase B
-        sl = [v("%s.sL%d" % (S, s), "V_SL(%s,%d);" % (S, s), prio=base + 40) for s in range(2)]
-        sr = [v("%s.sR%d" % (S, s), "V_SR(%s,%d);" % (S, s), prio=base + 39) for s in range(2)]
+        if not pipe and ph == 0:
+            take = v("take", "V_TAKE();", [klast], prio=3000)
+        kdep = [] if pipe else [take]
+        sl = [v("%s.sL%d" % (S, s), "V_SL(%s,%d);" % (S, s), kdep, prio=base + 40) for s in range(2)]
+        sr = [v("%s.sR%d" % (S, s), "V_SR(%s,%d);" % (S, s), kdep, prio=base + 39) for s in range(2)]
         lc = [m("%s.lc%d" % (S, s), "MM(%s.mL, %s.lp[%d]);" % (S, S, s), "LCW(%d)" % s, [sl[s]], prio=base + 40) for s in range(2)]
         rc = [m("%s.rc%d" % (S, s), "MM(%s.mR, %s.rp[%d]);" % (S, S, s), "RCW(%d)" % s, [sr[s]], prio=base + 39) for s in range(2)]
         sg = [v("%s.SG%d" % (S, i), "V_SG(%s,%d,%d);" % (S, lo, hi), [lc[1], rc[1]], prio=base + 35)
@@ -93,9 +103,12 @@ def build(variant):
         if NXN == 0:
             v("%s.keep" % S, "V_KEEP(%s);" % S, [sy[1][1]], prio=base + 10)    # the split chunks are dropped for NXN == 0 (see emit)
             continue
+        zs = []
+        if dual:    # the fp32 addend of chained tile 0 (16 loads): requested when conv2 starts, four to five slots before its use
+            zs = [v("%s.zseed" % S, "V_ZSEED(%s,%d);" % (S, ph), [c2[0][0]], prio=base + 28)]
         for i in range(NXN):
             nx = [m("%s.nx%d%d%d" % (S, i, m2, s), "MM(%s.Z%d, %s.yp[%d][%d]);" % (S, i, S, m2, s), "NXW(%d,%d,%d)" % (i, m2, s),
-                    [sy[m2][s]], prio=base + 20 - i) for m2 in range(2) for s in range(2)]
+                    [sy[m2][s]] + (zs if i == 0 else []), prio=base + 20 - i) for m2 in range(2) for s in range(2)]
             if i == 0:
                 sz = [v("%s.sZ%d" % (S, s), "V_SZ(%s,%d);" % (S, s), [nx[3]], prio=base + 10) for s in range(2)]
                 v("%s.st0" % S, "V_ST0(%s,%d);" % (S, ph), sz, prio=base + 9)
@@ -187,13 +200,16 @@ def emit(name, variant, f):
     return slots
 
 
-VARIANTS = [
+VARIANTS0 = [
     ("decoder stages 5..2: dual phase, 4 taps, C2 = 64, one chained tile", dict(id=1, NT=4, P1=5, C2=64, NXN=1, IN4=False)),
     ("last decoder stage: dual phase, 6 taps, C2 = 1", dict(id=2, NT=6, P1=27, C2=1, NXN=0, IN4=False)),
     ("encoder stages 2..4: 6 taps, C2 = 64, three chained tiles", dict(id=3, NT=6, P1=0, C2=64, NXN=3, IN4=False)),
     ("encoder stage 5: 6 taps, C2 = 64, block output kept", dict(id=4, NT=6, P1=0, C2=64, NXN=0, IN4=False)),
     ("encoder stage 1: fp32 inputs, K = 40, three chained tiles", dict(id=5, NT=10, P1=0, C2=64, NXN=3, IN4=True)),
 ]
+
+
+VARIANTS = VARIANTS0 + [(name + " - K loop, then tail (8 waves)", dict(var, id=var["id"] + 10, pipe=False)) for name, var in VARIANTS0]
 
 
 def main():

@@ -62,8 +62,8 @@ def bench(name, NT, p1mask, C2, nx_n, Fin, Fout, Fout1, sf_in, taps, NP=3, B=32,
         d.out, d.out_sb, d.out_sc, d.out_st = out.data_ptr(), out[0].numel(), T * (Fo + 2), Fo + 2
         d.out_sf = 2 if p1mask else 1
     if nx_n:
-        nFp = Fo + 5
-        nhp = torch.zeros(B, T + 1, 4, NP, nFp, 8, dtype=torch.int16, device=DEV)
+        nFp = Fo + 4 + (1 if p1mask else 0)
+        nhp = torch.zeros(B + 1, T + 1, 4, NP, nFp, 8, dtype=torch.int16, device=DEV)   # item B: dump target
         keep.append(nhp)
         d.nx_hp, d.nx_hp_sb, d.nx_Tp, d.nx_Fp, d.nx_t0, d.nx_f0 = nhp.data_ptr(), nhp[0].numel(), T + 1, nFp, 1, 2
         if p1mask:
@@ -73,9 +73,9 @@ def bench(name, NT, p1mask, C2, nx_n, Fin, Fout, Fout1, sf_in, taps, NP=3, B=32,
         for i in range(nx_n):
             d.nx_bias[i], d.nx_bias_sb[i] = Fv(32 * B), 32
         for i in range(nx_n - 1):
-            sk = torch.empty(B, 32, T + 1, Fout, device=DEV)
+            sk = torch.empty(B + 1, 32, T, Fout, device=DEV)
             keep.append(sk)
-            d.nx_out[i], d.nx_sb[i], d.nx_sc[i], d.nx_st[i], d.nx_sf[i] = sk.data_ptr(), sk[0].numel(), (T + 1) * Fout, Fout, 1
+            d.nx_out[i], d.nx_sb[i], d.nx_sc[i], d.nx_st[i], d.nx_sf[i] = sk.data_ptr(), sk[0].numel(), T * Fout, Fout, 1
     st = torch.cuda.current_stream().cuda_stream
     for _ in range(3):
         L.launch(d, st)
