@@ -125,8 +125,14 @@ __device__ __forceinline__ f32x16 chain(const uint4* w, const uint4 (&p)[2][NP],
 // reads beyond the resource return zero instead of faulting.
 typedef int v4i_t __attribute__((ext_vector_type(4)));
 #define PDSE_RSRC_FLAGS 0x00020000
+// The base and the size pass through readfirstlane: a resource that hipcc does not PROVE wave-uniform (it kept the one of the
+// plane loads in vector registers) makes every access a waterfall loop - four readfirstlane, two compares, a saveexec and a
+// branch per load, 36 of them per tile, each splitting the basic block the slot schedule lives in.
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, const uint32_t bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, (int)bytes, PDSE_RSRC_FLAGS);
+  const uint64_t a = reinterpret_cast<uint64_t>(p);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+  void* const q = reinterpret_cast<void*>(((uint64_t)hi << 32) | lo);
+  return __builtin_amdgcn_make_buffer_rsrc(q, (short)0, (int)__builtin_amdgcn_readfirstlane(bytes), PDSE_RSRC_FLAGS);
 }
 __device__ __forceinline__ uint4 bload16(const __amdgpu_buffer_rsrc_t r, const uint32_t voff, const int soff) {
   const v4i_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, 0);
@@ -246,12 +252,9 @@ __global__ __launch_bounds__(PIPE ? 256 : 512, PIPE ? 1 : 2) void bglu_kernel(co
   };
   // (tap, K block q, plane pl) of a lane = buffer resource of this item's hp + the lane's byte offset (pos_t::vin) + a
   // wave-uniform byte offset in a scalar register
-  const __amdgpu_buffer_rsrc_t r_in = IN4 ? make_rsrc(nullptr, 0)
-                                          : make_rsrc(d.hp + (int64_t)b * d.hp_sb, (uint32_t)d.hp_Tp * 4u * NP * (uint32_t)Fp * 16u);
   auto soff_in = [&](const int tap, const int q, const int pl) -> int {
     return (((d.tap_dt[tap] + d.hp_t0) * 4 + 2 * q) * (NP * Fp) + pl * Fp + d.tap_df[tap] + d.hp_f0) << 4;
   };
-  const __amdgpu_buffer_rsrc_t r_x0 = IN4 ? make_rsrc(d.x0.ptr, 0xfffffffcu) : r_in, r_x1 = IN4 ? make_rsrc(d.x1.ptr, 0xfffffffcu) : r_in;
   // input operands of one tile: planes [tap][q][plane] (or, stage 1, the raw fp32 gathers [slot][4])
   struct in_t {
     uint4 pl[IN4 ? 1 : NT][2][NP];
@@ -259,6 +262,7 @@ __global__ __launch_bounds__(PIPE ? 256 : 512, PIPE ? 1 : 2) void bglu_kernel(co
     unsigned live;
   };
   auto request_tap = [&](const pos_t& ps, in_t& in, const int tap) {
+    const __amdgpu_buffer_rsrc_t r_in = make_rsrc(d.hp + (int64_t)b * d.hp_sb, (uint32_t)d.hp_Tp * 4u * NP * (uint32_t)Fp * 16u);
 #pragma unroll
     for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -267,6 +271,7 @@ __global__ __launch_bounds__(PIPE ? 256 : 512, PIPE ? 1 : 2) void bglu_kernel(co
   auto request_in4 = [&](const pos_t& ps, in_t& in) {
     // slot s = 2q + w: tap 4q + 2h + w of the ten (2,5) taps, channels (x 0, x 1, x_init 0, x_init 1); taps >= 10: zero
     in.live = 0;
+    const __amdgpu_buffer_rsrc_t r_x0 = make_rsrc(d.x0.ptr, 0xfffffffcu), r_x1 = make_rsrc(d.x1.ptr, 0xfffffffcu);
 #pragma unroll
     for (int s_ = 0; s_ < 6; ++s_) {
       const int ta = 4 * (s_ >> 1) + (s_ & 1), tb = ta + 2;
