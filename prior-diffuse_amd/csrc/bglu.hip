@@ -744,14 +744,8 @@ int launch_(const pdse_bglu_desc* d, hipStream_t s) {
     return 1;
   }
   const void* fn = (const void*)bglu_kernel<NT, P1MASK, C2, NXN, IN4, NP, PIPE>;
-  // the attribute is per (function, device): a plan may be bound to any device of the process (pdse_plan_set_device)
-  static unsigned long long attr_mask = 0;
-  int dev = 0;
-  if (pdse_check_hip(hipGetDevice(&dev), "bglu: device")) return 1;
-  if (dev >= 64 || !((attr_mask >> dev) & 1ull)) {
-    if (pdse_check_hip(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "bglu lds attribute")) return 1;
-    if (dev < 64) attr_mask |= 1ull << dev;
-  }
+  static unsigned long long attr_mask = 0;   // per instantiation and device
+  if (pdse_lds_attr(fn, &attr_mask, "bglu lds attribute")) return 1;
 #ifdef BGLU_DIAG
   unsigned long long z[4] = {0, 0, 0, 0};
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bglu_diag), z, sizeof(z));

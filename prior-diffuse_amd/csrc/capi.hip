@@ -23,6 +23,15 @@ int pdse_check_hip(hipError_t e, const char* what) {
 
 int pdse_check_launch(const char* what) { return pdse_check_hip(hipGetLastError(), what); }
 
+int pdse_lds_attr(const void* fn, unsigned long long* mask, const char* what) {
+  int dev = 0;
+  if (pdse_check_hip(hipGetDevice(&dev), what)) return 1;
+  if (dev >= 0 && dev < 64 && ((*mask >> dev) & 1ull)) return 0;
+  if (pdse_check_hip(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), what)) return 1;
+  if (dev >= 0 && dev < 64) *mask |= 1ull << dev;
+  return 0;
+}
+
 union pdse_any_desc {
   pdse_gconv_desc gconv;
   pdse_time_desc time;

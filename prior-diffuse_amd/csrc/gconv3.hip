@@ -201,7 +201,11 @@ __device__ long long* g_trace3 = nullptr;   // PDSE_S3_TRACE=1 (diagnostic): [wo
 
 template <int NT, int P1MASK, bool NX, int WV, bool PF = (WV != 16), bool PERSIST = (WV != 16)>
 __global__ __launch_bounds__(64 * WV, WV / 4) void gconv3_kernel(const pdse_gconv_desc d) {
+#ifdef PDSE_DIAG
   long long* const trace = g_trace3;
+#else
+  long long* const trace = nullptr;
+#endif
   const long long c_start = trace ? clock64() : 0;
   constexpr int NB = 2 * NT, NT1 = popc3(P1MASK), NB1 = 2 * NT1;
   extern __shared__ uint4 img[];
@@ -449,11 +453,11 @@ static int launch3(const pdse_gconv_desc* d, hipStream_t s) {
   if (gx > rounds || !PERSIST) gx = rounds;
   if (gx < 1) gx = 1;
   const dim3 grid(gx, d->B, 1), block(64 * WV);
-  static const bool tracing = getenv("PDSE_S3_TRACE") != nullptr;
+  static const bool tracing = PDSE_DIAG_ENV("PDSE_S3_TRACE") != nullptr;
   static long long* tbuf = nullptr;
   if (tracing && !tbuf) {
-    hipMalloc(&tbuf, (size_t)1 << 22);
-    hipMemcpyToSymbol(HIP_SYMBOL(g_trace3), &tbuf, sizeof(tbuf));
+    (void)hipMalloc(&tbuf, (size_t)1 << 22);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_trace3), &tbuf, sizeof(tbuf));
   }
   const size_t lds = (size_t)s3_blocks(NT, P1MASK, d->C2, d->nx_n) * 192 * sizeof(uint4) + S3_FLOATS * sizeof(float);
   if (lds > 160 * 1024) {
@@ -461,18 +465,15 @@ static int launch3(const pdse_gconv_desc* d, hipStream_t s) {
     return 1;
   }
   const void* fn = (const void*)gconv3_kernel<NT, P1MASK, NX, WV, PF, PERSIST>;
-  static bool attr_done = false;   // per instantiation
-  if (!attr_done) {
-    if (pdse_check_hip(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "gconv3 lds attribute")) return 1;
-    attr_done = true;
-  }
-  if (tracing) hipMemsetAsync(tbuf, 0, (size_t)gx * d->B * WV * 64, s);
+  static unsigned long long attr_mask = 0;   // per instantiation and device
+  if (pdse_lds_attr(fn, &attr_mask, "gconv3 lds attribute")) return 1;
+  if (tracing) (void)hipMemsetAsync(tbuf, 0, (size_t)gx * d->B * WV * 64, s);
   hipLaunchKernelGGL((gconv3_kernel<NT, P1MASK, NX, WV, PF, PERSIST>), grid, block, lds, s, *d);
   if (tracing && PERSIST && PF) {   // diagnostic: averages over all waves of the persistent loop's phases, in shader clocks
-    hipStreamSynchronize(s);
+    (void)hipStreamSynchronize(s);
     const size_t nw = (size_t)gx * d->B * WV;
     long long* h = (long long*)malloc(nw * 64);
-    hipMemcpy(h, tbuf, nw * 64, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(h, tbuf, nw * 64, hipMemcpyDeviceToHost);
     double sum[6] = {0};
     for (size_t i = 0; i < nw; ++i)
       for (int k = 0; k < 6; ++k) sum[k] += (double)h[i * 8 + k];
@@ -488,12 +489,8 @@ static int launch3_in4(const pdse_gconv_desc* d, hipStream_t s) {
   const int P = d->Tout * d->Fout;
   const dim3 grid(((P + 31) / 32 + 15) / 16, d->B, 1), block(1024);
   const size_t lds = (size_t)s3_blocks(0, 0, 64, d->nx_n) * 192 * sizeof(uint4) + 6 * 192 * sizeof(uint4) + S3_FLOATS * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (pdse_check_hip(hipFuncSetAttribute((const void*)gconv3_in4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
-                       "gconv3 lds attribute")) return 1;
-    attr_done = true;
-  }
+  static unsigned long long attr_mask = 0;
+  if (pdse_lds_attr((const void*)gconv3_in4_kernel, &attr_mask, "gconv3 lds attribute")) return 1;
   hipLaunchKernelGGL(gconv3_in4_kernel, grid, block, lds, s, *d);
   return pdse_check_launch("gconv3");
 }

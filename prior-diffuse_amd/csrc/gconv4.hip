@@ -89,7 +89,11 @@ __device__ long long* g_trace4 = nullptr;   // PDSE_G4_TRACE=1 (diagnostic): [wo
 
 template <int EPI, int MT>
 __global__ __launch_bounds__(512, 2) void gconv4_kernel(const pdse_gconv_desc d) {
+#ifdef PDSE_DIAG
   long long* const trace = g_trace4;
+#else
+  long long* const trace = nullptr;
+#endif
   const long long c_start = trace ? clock64() : 0;
   long long c_req = 0, c_cmp = 0, c_bar = 0;
   constexpr bool DUAL = (EPI != PDSE_EPI_LINEAR);
@@ -259,27 +263,23 @@ static int launch4(const pdse_gconv_desc* d, hipStream_t s, const int mtiles) {
   const dim3 grid(((P + 31) / 32 + 7) / 8, d->B, (mtiles + MT - 1) / MT), block(512);
   constexpr int FR = (EPI == PDSE_EPI_LINEAR ? 1 : 2) * MT;
   const size_t lds = (size_t)2 * G4_CH * FR * 192 * sizeof(uint4);
-  static bool attr_done = false;   // per instantiation
-  if (!attr_done && lds > 64 * 1024) {
-    if (pdse_check_hip(hipFuncSetAttribute((const void*)gconv4_kernel<EPI, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
-                       "gconv4 lds attribute")) return 1;
-    attr_done = true;
-  }
-  static const bool tracing = getenv("PDSE_G4_TRACE") != nullptr;
+  static unsigned long long attr_mask = 0;   // per instantiation and device
+  if (lds > 64 * 1024 && pdse_lds_attr((const void*)gconv4_kernel<EPI, MT>, &attr_mask, "gconv4 lds attribute")) return 1;
+  static const bool tracing = PDSE_DIAG_ENV("PDSE_G4_TRACE") != nullptr;
   static long long* tbuf = nullptr;
   const size_t nw = (size_t)grid.x * grid.y * grid.z * 8;
   if (tracing) {
     if (!tbuf) {
-      hipMalloc(&tbuf, (size_t)1 << 24);
-      hipMemcpyToSymbol(HIP_SYMBOL(g_trace4), &tbuf, sizeof(tbuf));
+      (void)hipMalloc(&tbuf, (size_t)1 << 24);
+      (void)hipMemcpyToSymbol(HIP_SYMBOL(g_trace4), &tbuf, sizeof(tbuf));
     }
-    hipMemsetAsync(tbuf, 0, nw * 64, s);
+    (void)hipMemsetAsync(tbuf, 0, nw * 64, s);
   }
   hipLaunchKernelGGL((gconv4_kernel<EPI, MT>), grid, block, lds, s, *d);
   if (tracing && nw * 64 <= ((size_t)1 << 24)) {   // diagnostic: per-wave averages in shader clocks
-    hipStreamSynchronize(s);
+    (void)hipStreamSynchronize(s);
     long long* h = (long long*)malloc(nw * 64);
-    hipMemcpy(h, tbuf, nw * 64, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(h, tbuf, nw * 64, hipMemcpyDeviceToHost);
     double sum[7] = {0};
     for (size_t i = 0; i < nw; ++i)
       for (int k = 0; k < 7; ++k) sum[k] += (double)h[i * 8 + k];

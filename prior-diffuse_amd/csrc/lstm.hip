@@ -145,7 +145,11 @@ __global__ __launch_bounds__(512) void glstm_wave_kernel(const pdse_glstm_desc d
   const int stage = blockIdx.z / nbt, bt = blockIdx.z - stage * nbt;
   const int t = s - stage;
   if (t < 0 || t >= d.T || !((stage_mask >> stage) & 1)) return;
+#ifdef PDSE_DIAG
   long long* const trace = (s == d.T / 2) ? g_trace_l : nullptr;
+#else
+  long long* const trace = nullptr;
+#endif
   LSTAMP(0);
   LSTAMP(1);
   const int H = d.H, Bp = d.Bp, G = d.G;
@@ -331,22 +335,22 @@ int pdse_glstm_launch(const pdse_glstm_desc* d, hipStream_t s) {
   }
   const dim3 grid(d->H / 8, d->G, 3 * (d->Bp / 32)), block(512);
   // PDSE_GLSTM_MASK (diagnostic, tools/time_glstm.py): run only some stages to time them apart - results are then wrong
-  static const int mask = getenv("PDSE_GLSTM_MASK") ? atoi(getenv("PDSE_GLSTM_MASK")) : 7;
-  static const bool tracing = getenv("PDSE_GLSTM_TRACE") != nullptr;
+  static const int mask = PDSE_DIAG_ENV("PDSE_GLSTM_MASK") ? atoi(PDSE_DIAG_ENV("PDSE_GLSTM_MASK")) : 7;
+  static const bool tracing = PDSE_DIAG_ENV("PDSE_GLSTM_TRACE") != nullptr;
   static long long* tbuf = nullptr;
   const size_t nw = (size_t)grid.x * grid.y * grid.z * 8;
   if (tracing) {
     if (!tbuf) {
-      hipMalloc(&tbuf, nw * 64);
-      hipMemcpyToSymbol(HIP_SYMBOL(g_trace_l), &tbuf, sizeof(tbuf));
+      (void)hipMalloc(&tbuf, nw * 64);
+      (void)hipMemcpyToSymbol(HIP_SYMBOL(g_trace_l), &tbuf, sizeof(tbuf));
     }
-    hipMemsetAsync(tbuf, 0, nw * 64, s);
+    (void)hipMemsetAsync(tbuf, 0, nw * 64, s);
   }
   for (int st = 0; st < d->T + 2; ++st) hipLaunchKernelGGL(glstm_wave_kernel, grid, block, 0, s, *d, st, mask);
   if (tracing) {   // diagnostic: stamps of wavefront step T/2 - start spread (100 MHz clock) and shader clocks since the wave started
-    hipStreamSynchronize(s);
+    (void)hipStreamSynchronize(s);
     long long* h = (long long*)malloc(nw * 64);
-    hipMemcpy(h, tbuf, nw * 64, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(h, tbuf, nw * 64, hipMemcpyDeviceToHost);
     for (int stg = 0; stg < 3; ++stg) {
       double sum[8] = {0};
       long long w0 = -1, w1 = 0;

@@ -9,6 +9,18 @@ void pdse_set_error(const char* msg);
 // returns 0 when the last launch was accepted, else records "<what>: <hip error>" and returns 1
 int pdse_check_launch(const char* what);
 int pdse_check_hip(hipError_t e, const char* what);
+// hipFuncAttributeMaxDynamicSharedMemorySize, once per (function, device): a plan may be bound to any device of the
+// process (pdse_plan_set_device), and the attribute belongs to the device the function is loaded on.  `mask` is the
+// caller's per-function record (bit d: done on device d).  Returns 0 on success.
+int pdse_lds_attr(const void* fn, unsigned long long* mask, const char* what);
+// Diagnostic hooks (clock-stamp traces, stage masks) exist only in -DPDSE_DIAG builds: in the product library the
+// environment cannot change a launch (a stage mask gives wrong results; a trace mallocs / synchronises inside a launch,
+// which is illegal during hipGraph capture).
+#ifdef PDSE_DIAG
+#define PDSE_DIAG_ENV(name) (getenv(name))
+#else
+#define PDSE_DIAG_ENV(name) ((const char*)nullptr)
+#endif
 
 int pdse_gconv_launch(const pdse_gconv_desc* d, hipStream_t s);
 int pdse_gconv2_launch(const pdse_gconv_desc* d, hipStream_t s);  // korder 1, validated by pdse_gconv_launch

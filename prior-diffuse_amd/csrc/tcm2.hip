@@ -105,7 +105,11 @@ __global__ __launch_bounds__(512 * TW, NT == 1 ? 4 : 2) void tcm2_kernel(const p
   const int col = lane & 31, hh = lane >> 5;
   const int b = blockIdx.y, t0 = (blockIdx.x * TW + team) * (32 * NT), T = d.T, TP = T + 2 * HS_PAD;
   const bool chain = d.hs_out != nullptr;
+#ifdef PDSE_DIAG
   long long* trace = g_trace;
+#else
+  long long* trace = nullptr;
+#endif
   STAMP(0);
   STAMP(1);
 
@@ -376,22 +380,24 @@ __global__ __launch_bounds__(512 * TW, NT == 1 ? 4 : 2) void tcm2_kernel(const p
 template <int NT, int TW>
 int launch_tcm2(const pdse_tcm2_desc* d, hipStream_t s) {
   const dim3 grid((d->T + 32 * NT * TW - 1) / (32 * NT * TW), d->B);
-  static const bool tracing = getenv("PDSE_TCM2_TRACE") != nullptr;
   static long long* tbuf = nullptr;
   const size_t nst = (size_t)grid.x * grid.y * 64 * TW;
+  // (diagnostic builds only) the trace buffer holds 65536 * 64 stamps: larger launches are not traced
+  static const bool tracing_env = PDSE_DIAG_ENV("PDSE_TCM2_TRACE") != nullptr;
+  const bool tracing = tracing_env && nst <= (size_t)65536 * 64;
   if (tracing) {
     if (!tbuf) {
-      hipMalloc(&tbuf, 65536 * 64 * sizeof(long long));
-      hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &tbuf, sizeof(tbuf));
+      (void)hipMalloc(&tbuf, 65536 * 64 * sizeof(long long));
+      (void)hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &tbuf, sizeof(tbuf));
     }
-    hipMemsetAsync(tbuf, 0, nst * sizeof(long long), s);
+    (void)hipMemsetAsync(tbuf, 0, nst * sizeof(long long), s);
   }
   if (d->mode == 1) hipLaunchKernelGGL((tcm2_kernel<1, NT, TW>), grid, dim3(512 * TW), 0, s, *d);
   else hipLaunchKernelGGL((tcm2_kernel<0, NT, TW>), grid, dim3(512 * TW), 0, s, *d);
   if (tracing) {   // diagnostic: per-phase shader-clock averages over all waves, and the spread of start times (100 MHz clock)
-    hipStreamSynchronize(s);
+    (void)hipStreamSynchronize(s);
     long long* h = (long long*)malloc(nst * sizeof(long long));
-    hipMemcpy(h, tbuf, nst * sizeof(long long), hipMemcpyDeviceToHost);
+    (void)hipMemcpy(h, tbuf, nst * sizeof(long long), hipMemcpyDeviceToHost);
     double sum[8] = {0};
     long long w0 = -1, w1 = 0;
     const size_t nw = nst / 8;
