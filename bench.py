@@ -279,9 +279,9 @@ def main():
     # HBM traffic of the same launches from the committed rocprofv3 PMC passes (FETCH_SIZE | WRITE_SIZE collected
     # separately, profiles/r01_pmc_traffic_final.json); read-side doubled as MI355X_MICROARCH.md prescribes for gfx950
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
     if not os.path.exists(tpath):
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic_final.json")
+        tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
     n_eps_launch = max(1, sum(per_tag[k]["launches"] for k in ("eps_block", "eps_conv1", "tcm")))
     if os.path.exists(tpath) and B == 32 and T == 401 and fast and args.prior == "GCRN":
         pj = json.load(open(tpath))["eps_net_one_pass"]
@@ -291,7 +291,7 @@ def main():
     peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if args.split_bf16 else FP32_MFMA_PEAK_TFLOPS
     if args.bf16:
         peak = BF16_MFMA_PEAK_TFLOPS
-    roofline = {"bound": "mfma", "kernel": ("gconv3_kernel (split-bf16 BIGLU blocks) + tcm2_kernel" if args.split_bf16 else
+    roofline = {"bound": "mfma", "kernel": ("bglu_kernel (split-bf16 BIGLU blocks on plane tensors) + tcm2_kernel" if args.split_bf16 else
                                             "gconv2_kernel + tcm_block_kernel") + " (eps-net: BiConvGLU/BiConvTransGLU/TCM launches)",
                 "achieved": round(achieved, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
                 "peak_note": ("dense bf16 MFMA 2500 TFLOP/s / 6 products per fp32-equivalent multiply-add" if args.split_bf16
@@ -306,7 +306,16 @@ def main():
     # ---- the single largest launch of the eps-net: algorithmic FLOPs from its descriptor / its own hipEvent time
     lib = importlib.import_module("prior-diffuse_amd._lib")
 
+    def bglu_flops(d):
+        pos0, pos1 = d.B * d.Tout * d.Fout, (d.B * d.Tout * d.Fout1 if d.p1mask else 0)
+        cin = 4 if d.x0.ptr else 32
+        tail = 2.0 * (2 * 32 * 32 + 32 * d.C2) + 2.0 * 64 * 32 * d.nx_n
+        return (2.0 * pos0 * 2 * d.ntaps * cin * 32 + pos0 * tail +
+                2.0 * pos1 * 2 * bin(d.p1mask).count("1") * cin * 32 + pos1 * tail)
+
     def gconv_flops(d):
+        if isinstance(d, lib.BgluDesc):
+            return bglu_flops(d)
         pos0 = d.B * d.Tout * d.Fout
         accs = 1 if d.epi == lib.EPI_LINEAR else 2
         cin = d.in0.C + d.in1.C
@@ -322,13 +331,17 @@ def main():
 
     b0, e0 = pipe.ranges["step%d" % (pipe.nsteps - 1)]
     ms_ops = [min(col) for col in zip(*[pipe.plan.time_ops(b0, e0, stream) for _ in range(3)])]
-    cand = [(ms_ops[i - b0], i) for i in range(b0, e0) if isinstance(pipe.descs[i][0], lib.GconvDesc)]
+    cand = [(ms_ops[i - b0], i) for i in range(b0, e0) if isinstance(pipe.descs[i][0], (lib.GconvDesc, lib.BgluDesc))]
     top_ms, top_i = max(cand)
     top_d = pipe.descs[top_i][0]
+    if isinstance(top_d, lib.BgluDesc):
+        top_name, top_dual = "bglu_kernel (%d plane%s)" % (top_d.np, "s" if top_d.np > 1 else ""), bool(top_d.p1mask)
+    else:
+        top_name, top_dual = ("gconv3_kernel" if top_d.korder == 2 else "gconv2_kernel"), bool(top_d.w2)
     top_tf = gconv_flops(top_d) / (top_ms * 1e-3) / 1e12
     roofline["largest_launch"] = {
-        "kernel": ("gconv3_kernel" if top_d.korder == 2 else "gconv2_kernel") + " BIGLU%s, %d taps, %d -> 32 -> %d channels, %d x %d x %d positions" % (
-            " dual-phase" if top_d.w2 else "", top_d.ntaps, top_d.in0.C, top_d.C2, top_d.B, top_d.Tout, top_d.Fout),
+        "kernel": top_name + " BIGLU%s, %d taps, 32 -> 32 -> %d channels, %d x %d x %d positions" % (
+            " dual-phase" if top_dual else "", top_d.ntaps, top_d.C2, top_d.B, top_d.Tout, top_d.Fout),
         "ms": round(top_ms, 4), "algorithmic_gflop": round(gconv_flops(top_d) / 1e9, 2),
         "achieved": round(top_tf, 2), "frac": round(top_tf / peak, 4)}
 
@@ -354,6 +367,46 @@ def main():
                                        "achieved": round(bsum / tsum / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                                        "frac": round(bsum / tsum / 8e12, 4), "algorithmic_bytes": bsum, "ms": round(tsum * 1e3, 4)}
         roofline["peak_note"] = "bf16 mode: blocks issue ONE bf16 MFMA product per multiply-add: roof of their algorithmic FLOP rate = dense bf16 peak"
+    # ---- the reference's own entry point: generate_wav, B = 1, one 4 s file after the other (wav read -> enhance -> wav write)
+    file_loop = None
+    if fast and args.prior == "GCRN" and not args.bf16:
+        import argparse as _ap
+        import tempfile
+
+        import numpy as np
+
+        wavio = importlib.import_module("prior-diffuse_amd.wavio")
+        trainer_mod = importlib.import_module("prior-diffuse_amd.trainer")
+        nfiles = 8
+        with tempfile.TemporaryDirectory() as td:
+            src, dst = os.path.join(td, "noisy"), os.path.join(td, "out")
+            os.makedirs(src)
+            rng = np.random.default_rng(7)
+            for i in range(nfiles):
+                wavio.write_wav(os.path.join(src, "f%02d.wav" % i), 0.1 * rng.standard_normal(L_))
+            ns = _ap.Namespace
+            tr = trainer_mod.ComplexDDPMTrainer(
+                ns(retrain=False, joint=True, draw=False, sigma=False, checkpoint="x", generated_wav=dst),
+                ns(model=ns(name="GCRN"), train=ns(fft_num=320, win_size=320, win_shift=160, feat_type="sqrt")),
+                device=dev, prior_state_dict=gs, ddpm_state_dict=ds)
+            tr.generate_wav(load_pre_train=False, data_path=src)          # warm-up: packs the weights, records the plan
+            torch.cuda.synchronize()
+            tf0 = time.perf_counter()
+            tr.generate_wav(load_pre_train=False, data_path=src)
+            torch.cuda.synchronize()
+            tfl = time.perf_counter() - tf0
+            te0 = time.perf_counter()
+            one = torch.zeros(1, L_, device=dev) + 0.01
+            for _ in range(nfiles):
+                tr.enhance(one)
+            torch.cuda.synchronize()
+            ten = time.perf_counter() - te0
+            del tr
+        file_loop = {"files": nfiles, "seconds_per_file": args.seconds, "wall_s": round(tfl, 4),
+                     "value": round(nfiles * args.seconds / tfl, 1), "unit": "audio_s/s",
+                     "ms_per_file": round(tfl / nfiles * 1e3, 2), "ms_per_file_enhance_only": round(ten / nfiles * 1e3, 2),
+                     "note": "ComplexDDPMTrainer.generate_wav (trainer/complex_ddpm_trainer.py:903-1018), B = 1, wav read + "
+                             "enhance + wav write per file, eager launches (no graph); enhance_only: the same without file I/O"}
     cpu = None
     if not args.no_cpu_baseline:
         from oracle import restate as R
@@ -408,7 +461,7 @@ def main():
                    "global_batch": B * world, "frames": T, "parallelism": "batch-shard x%d" % world,
                    "graph": use_graph and (not args.overlap or args.by_batch), "streams_per_gpu": args.streams,
                    "batches_in_flight": args.inflight},
-        "roofline": roofline, "cpu_baseline": cpu, "fp32_exact": fp32_exact,
+        "roofline": roofline, "cpu_baseline": cpu, "fp32_exact": fp32_exact, "file_loop_b1": file_loop,
     }
     print(json.dumps(out))
     if dist is not None:

@@ -19,7 +19,7 @@ def load(path):
 
 
 def short(n):
-    m = re.match(r"void (?:\(anonymous namespace\)::)?(gconv[234]?_kernel|tcm2_kernel)<(.*)>\(", n)
+    m = re.match(r"void (?:\(anonymous namespace\)::)?(gconv[234]?_kernel|tcm2_kernel|bglu_kernel)<(.*)>\(", n)
     if m:
         return m.group(1).replace("_kernel", "") + "<" + m.group(2).replace("false", "F").replace("true", "T").replace(" ", "") + ">"
     return re.sub(r"\(.*", "", n)[:30]
@@ -50,7 +50,7 @@ i1 = [k for k, n in enumerate(names) if n.startswith("compand") and k > i0][0]
 rd = wr = 0.0
 n = 0
 for k in range(i0 + 1, i1):
-    if "gconv" in names[k] or "tcm_block" in names[k] or "tcm2_kernel" in names[k]:
+    if "gconv" in names[k] or "tcm_block" in names[k] or "tcm2_kernel" in names[k] or "bglu_kernel" in names[k] or "planes_kernel" in names[k]:
         rd += f[ids[k]].get("FETCH_SIZE", 0) * 1024
         wr += w[idw[k]].get("WRITE_SIZE", 0) * 1024
         n += 1
@@ -60,7 +60,7 @@ json.dump(dict(
          "reads, so fetch_size_bytes_x2 is the corrected figure (an upper bound for our 4-byte gathers).",
     kernels=out,
     eps_net_one_pass=dict(launches=n, fetch_size_bytes_raw=rd, fetch_size_bytes_x2=2 * rd, write_size_bytes=wr,
-                          note="all gconv / tcm_block launches of the 6 eps-net forwards of one pass")), open(sys.argv[4], "w"), indent=1)
+                          note="all gconv / bglu / planes / tcm launches of the 6 eps-net forwards of one pass")), open(sys.argv[4], "w"), indent=1)
 print(n, rd / 1e9, wr / 1e9)
 for o in out[:10]:
     print(o)
