@@ -395,18 +395,12 @@ def main():
             tr.generate_wav(load_pre_train=False, data_path=src)
             torch.cuda.synchronize()
             tfl = time.perf_counter() - tf0
-            te0 = time.perf_counter()
-            one = torch.zeros(1, L_, device=dev) + 0.01
-            for _ in range(nfiles):
-                tr.enhance(one)
-            torch.cuda.synchronize()
-            ten = time.perf_counter() - te0
             del tr
         file_loop = {"files": nfiles, "seconds_per_file": args.seconds, "wall_s": round(tfl, 4),
                      "value": round(nfiles * args.seconds / tfl, 1), "unit": "audio_s/s",
-                     "ms_per_file": round(tfl / nfiles * 1e3, 2), "ms_per_file_enhance_only": round(ten / nfiles * 1e3, 2),
+                     "ms_per_file": round(tfl / nfiles * 1e3, 2),
                      "note": "ComplexDDPMTrainer.generate_wav (trainer/complex_ddpm_trainer.py:903-1018), B = 1, wav read + "
-                             "enhance + wav write per file, eager launches (no graph); enhance_only: the same without file I/O"}
+                             "enhance + wav write per file, eager launches (no graph), plan and weights resident"}
     cpu = None
     if not args.no_cpu_baseline:
         from oracle import restate as R

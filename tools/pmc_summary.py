@@ -9,7 +9,7 @@ files = glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)
 agg = collections.OrderedDict()
 for path in files:
     for x in csv.DictReader(open(path)):
-        name = re.sub(r"\(.*", "", x["Kernel_Name"]).replace("void ", "")[:60]
+        name = re.sub(r"\(.*", "", x["Kernel_Name"].replace("(anonymous namespace)::", "")).replace("void ", "")[:60]
         a = agg.setdefault((name, x["Grid_Size"]), collections.defaultdict(float))
         a[x["Counter_Name"]] += float(x["Counter_Value"])
         a["_n_" + x["Counter_Name"]] += 1
