@@ -43,6 +43,10 @@ def test_argument_errors_do_not_need_a_device(lib):
     d = lib.LstmDesc()
     with pytest.raises(lib.PdseError, match="lstm"):
         lib.launch(d)
+    with pytest.raises(lib.PdseError, match="bglu: null"):
+        lib.launch(lib.BgluDesc())
+    with pytest.raises(lib.PdseError, match="planes"):
+        lib.launch(lib.PlanesDesc())
     p = lib.Plan()
     assert len(p) == 0
     p.add(lib.EwDesc())
@@ -61,3 +65,31 @@ def test_product_refuses_cpu(lib):
         pkg("trainer").ComplexDDPMTrainer(args, config, device="cpu", prior_state_dict={}, ddpm_state_dict={})
     with pytest.raises(lib.PdseError):
         pkg("ops").DiffUNet1Op({}, "cpu")
+
+
+def test_generated_block_schedule_is_current(tmp_path, monkeypatch):
+    """csrc/bglu_sched.inc is generated (tools/gen_bglu_sched.py): the committed file must be what the generator writes, and
+    every variant's schedule must place each mm of an accumulate chain in program order and each vector chunk behind its
+    producers."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("gen_bglu_sched", os.path.join(ROOT, "tools", "gen_bglu_sched.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    committed = open(gen.OUT).read()
+    monkeypatch.setattr(gen, "OUT", str(tmp_path / "sched.inc"))
+    gen.main()
+    assert open(str(tmp_path / "sched.inc")).read() == committed
+    for name, var in gen.VARIANTS:
+        M, V = gen.build(var)
+        slots = gen.schedule(M, V)
+        at = {}
+        for i, (pm, pv) in enumerate(slots):
+            for it in (pm, pv):
+                if it is not None:
+                    at[it] = i
+        assert set(at) == set(M) | set(V), name
+        for it, i in at.items():
+            for dep in it.deps:
+                gap = i - at[dep]
+                assert gap >= (2 if (it.kind, dep.kind) == ("V", "M") else 1 if it.kind != dep.kind else 0), (name, it.name, dep.name)
