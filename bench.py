@@ -446,8 +446,8 @@ def main():
         "value_sequential": round(B * args.seconds / (ms_sequential * 1e-3), 2),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16" if args.bf16 else ("bf16x3" if args.split_bf16 else "f32"), "data": "synthetic",
-        "dtype_note": ("OPT-IN bf16 mode: plain bf16 operands (one MFMA product, fp32 accumulate) and bf16 conv1 tensors in the eps-net's "
-                       "BiConv(Trans)GLU blocks; TCM stack and prior as in the default; tolerance 3e-2 rel-L2 (tests/test_gpu_round2.py::"
+        "dtype_note": ("OPT-IN bf16 mode: plain bf16 operands (one MFMA product, fp32 accumulate) and bf16 conv1 / bottleneck tensors in the eps-net's "
+                       "BiConv(Trans)GLU and TCM blocks; prior as in the default; tolerance 3e-2 rel-L2 (tests/test_gpu_round2.py::"
                        "test_bf16_mode_tolerance) - not the graded line") if args.bf16 else ("eps-net blocks: fp32 operands split exactly into three bf16 terms, six-product bf16 MFMA, fp32 accumulate "
                        "(fp32-level accuracy, same parity tolerances); everything else fp32") if args.split_bf16 else "fp32 throughout",
         "frames_per_s_per_gpu": round(args.steps * B * T / elapsed, 1),

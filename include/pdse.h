@@ -478,6 +478,9 @@ typedef struct pdse_tcm2_desc {
   const float* par;
   float slope2, slope_main_next, slope_mask_next;
   int32_t dil, B, T, mode;
+  int32_t np;            /* planes of hs and of every packed weight: 3 (exact three-way split; 0 means 3) or 1 (plain bf16,
+                            round to nearest even: the opt-in bf16 mode) - hs is then [B][2][4][2][np][T + 128][8] */
+  int32_t pad_;
 } pdse_tcm2_desc;
 
 /* GroupNorm(1,C) statistics + the AIA layer update (dbaiat.py:142,147-148):

@@ -159,7 +159,7 @@ class TcmDesc(C.Structure):
 class Tcm2Desc(C.Structure):
     _fields_ = [("x", _fp), ("x_out", _fp), ("hs", _fp), ("hs_out", _fp), ("wbr", _fp), ("wc2", _fp), ("wn1", _fp),
                 ("par", _fp), ("slope2", _f32), ("slope_main_next", _f32), ("slope_mask_next", _f32),
-                ("dil", _i32), ("B", _i32), ("T", _i32), ("mode", _i32)]
+                ("dil", _i32), ("B", _i32), ("T", _i32), ("mode", _i32), ("np", _i32), ("pad_", _i32)]
 
 
 class BgluDesc(C.Structure):

@@ -51,16 +51,38 @@ constexpr int GL_ROW = 144;        // bytes of one frame of one plane of the con
 
 __device__ __forceinline__ float prelu2(float v, float slope) { return v > 0.f ? v : slope * v; }
 
-__device__ __forceinline__ f32x16 mfma6r(const uint4 (&a)[3], const uint4 (&b)[3], f32x16 acc) {
-  acc = mfma_bf16(a[0], b[2], acc);
-  acc = mfma_bf16(a[2], b[0], acc);
-  acc = mfma_bf16(a[1], b[1], acc);
-  acc = mfma_bf16(a[0], b[1], acc);
-  acc = mfma_bf16(a[1], b[0], acc);
-  acc = mfma_bf16(a[0], b[0], acc);
+// NP = 3: exact three-way splits, six products; NP = 1: plain bf16 operands, one product (the opt-in bf16 mode, round 3)
+template <int NP>
+__device__ __forceinline__ f32x16 mfma6r(const uint4 (&a)[NP], const uint4 (&b)[NP], f32x16 acc) {
+  if constexpr (NP == 3) {
+    acc = mfma_bf16(a[0], b[2], acc);
+    acc = mfma_bf16(a[2], b[0], acc);
+    acc = mfma_bf16(a[1], b[1], acc);
+    acc = mfma_bf16(a[0], b[1], acc);
+    acc = mfma_bf16(a[1], b[0], acc);
+    acc = mfma_bf16(a[0], b[0], acc);
+  } else {
+    acc = mfma_bf16(a[0], b[0], acc);
+  }
   return acc;
 }
 
+__device__ __forceinline__ uint32_t pack_bf16_rne(const float a, const float b) {   // v_cvt_pk_bf16_f32
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  const f32x2 v = {a, b};
+  union { bf16x2 h; uint32_t u; } c;
+  c.h = __builtin_convertvector(v, bf16x2);
+  return c.u;
+}
+template <int NP>
+__device__ __forceinline__ void split8n(const float (&x)[8], uint4 (&p)[NP]) {
+  if constexpr (NP == 3) split8(x, p[0], p[1], p[2]);
+  else p[0] = make_uint4(pack_bf16_rne(x[0], x[1]), pack_bf16_rne(x[2], x[3]), pack_bf16_rne(x[4], x[5]), pack_bf16_rne(x[6], x[7]));
+}
+
+template <int NP>
+__device__ __forceinline__ void split4n(const float (&x)[4], uint2 (&p)[NP]);
 // four values -> their three bf16 planes, 8 bytes each (element i in half i & 1 of dword i >> 1)
 __device__ __forceinline__ void split4(const float (&x)[4], uint2& p1, uint2& p2, uint2& p3) {
   uint32_t q[3][2];
@@ -80,6 +102,12 @@ __device__ __forceinline__ void split4(const float (&x)[4], uint2& p1, uint2& p2
   p3 = make_uint2(q[2][0], q[2][1]);
 }
 
+template <int NP>
+__device__ __forceinline__ void split4n(const float (&x)[4], uint2 (&p)[NP]) {
+  if constexpr (NP == 3) split4(x, p[0], p[1], p[2]);
+  else p[0] = make_uint2(pack_bf16_rne(x[0], x[1]), pack_bf16_rne(x[2], x[3]));
+}
+
 __device__ long long* g_trace = nullptr;   // PDSE_TCM2_TRACE=1 (diagnostic): [workgroup][wave][8] clock stamps
 #define STAMP(i)                                                                                       \
   do {                                                                                                 \
@@ -89,13 +117,13 @@ __device__ long long* g_trace = nullptr;   // PDSE_TCM2_TRACE=1 (diagnostic): [w
 // NT = frame tiles of 32 per wave, TW = teams of 8 waves per workgroup (workgroup = 32 NT TW frames of one utterance).
 // The teams of a workgroup run the same instruction stream on neighbouring frames between the same barriers, so
 // their weight requests reach the CU's L1 together.
-template <int MODE, int NT, int TW>
+template <int MODE, int NT, int TW, int NP = 3>
 __global__ __launch_bounds__(512 * TW, NT == 1 ? 4 : 2) void tcm2_kernel(const pdse_tcm2_desc d) {
   // par: [64][4] main bias, mask bias, BN scale, BN shift of the gate | [256] conv2 bias | [64] next conv1 bias |
   //      [64][4] next block's input transforms: main scale, shift, mask scale, shift
   __shared__ __attribute__((aligned(16))) float par[832];
   __shared__ float part_[TW * NT][4][64][33];                                    // A: [2 branch + kh]; C: partial sums of four waves
-  __shared__ __attribute__((aligned(16))) char gls_[TW * NT][3 * 32 * GL_ROW];   // conv2's B operand: [plane][frame][64 + 8 bf16]
+  __shared__ __attribute__((aligned(16))) char gls_[TW * NT][NP * 32 * GL_ROW];   // conv2's B operand: [plane][frame][64 + 8 bf16]
   const int tid = threadIdx.x & 511;                                             // within the team
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -134,16 +162,16 @@ __global__ __launch_bounds__(512 * TW, NT == 1 ? 4 : 2) void tcm2_kernel(const p
     // -------------------------------------------------------------- A: dilated branches
     const int br = wave & 1, kq = wave >> 1;
     const size_t plane = (size_t)TP * 16;                      // bytes of one fragment plane of one (kb, kg)
-    const char* hbase = (const char*)d.hs + (size_t)(b * 2 + br) * 24 * plane;   // wave-uniform
+    const char* hbase = (const char*)d.hs + (size_t)(b * 2 + br) * (8 * NP) * plane;   // wave-uniform
     int roff[NT][5];    // lane offsets of the five taps: this lane half's planes + frame (the margins are zeros)
 #pragma unroll
     for (int n = 0; n < NT; ++n)
 #pragma unroll
       for (int k = 0; k < 5; ++k)
-        roff[n][k] = hh * 3 * (int)plane + (tlive[n] ? t0 + 32 * n + col + (k - 2) * d.dil + HS_PAD : 0) * 16;
-    const uint4* WA = (const uint4*)d.wbr + ((size_t)(br * 2 * 20 + 5 * kq) * 3) * 64 + lane;   // [br][2 mi][20][3][64]
+        roff[n][k] = hh * NP * (int)plane + (tlive[n] ? t0 + 32 * n + col + (k - 2) * d.dil + HS_PAD : 0) * 16;
+    const uint4* WA = (const uint4*)d.wbr + ((size_t)(br * 2 * 20 + 5 * kq) * NP) * 64 + lane;   // [br][2 mi][20][3][64]
     constexpr int D = 2;   // K blocks in flight (a slot is requested again as soon as its MFMAs have issued)
-    uint4 qa[D][2][3], qb[D][NT][3];
+    uint4 qa[D][2][NP], qb[D][NT][NP];
     // workgroups walk their five K blocks in an order rotated by the frame tile index: neighbours in time do not ask L2
     // for the same weight lines at the same moment (-6 % on phase A); a function of the frame tile only, so an
     // utterance's result does not depend on its place in the batch
@@ -152,18 +180,18 @@ __global__ __launch_bounds__(512 * TW, NT == 1 ? 4 : 2) void tcm2_kernel(const p
       const int slot = i % D;
       const int j = (i + js) % 5;
       const int kbi = 5 * kq + j;                              // wave-uniform: tap = kbi >> 2, channel block = kbi & 3
-      const char* hq = hbase + (size_t)(kbi & 3) * 6 * plane;
+      const char* hq = hbase + (size_t)(kbi & 3) * (2 * NP) * plane;
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) qa[slot][mi][p] = WA[(size_t)((mi * 20 + j) * 3 + p) * 64];
+        for (int p = 0; p < NP; ++p) qa[slot][mi][p] = WA[(size_t)((mi * 20 + j) * NP + p) * 64];
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
         int ro = roff[n][0];
 #pragma unroll
         for (int k = 1; k < 5; ++k) ro = (kbi >> 2) == k ? roff[n][k] : ro;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) qb[slot][n][p] = *(const uint4*)(hq + p * plane + ro);
+        for (int p = 0; p < NP; ++p) qb[slot][n][p] = *(const uint4*)(hq + p * plane + ro);
       }
     };
 #pragma unroll
@@ -181,19 +209,19 @@ __global__ __launch_bounds__(512 * TW, NT == 1 ? 4 : 2) void tcm2_kernel(const p
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int n = 0; n < NT; ++n) acc[mi][n] = mfma6r(qa[j % D][mi], qb[j % D][n], acc[mi][n]);
+        for (int n = 0; n < NT; ++n) acc[mi][n] = mfma6r<NP>(qa[j % D][mi], qb[j % D][n], acc[mi][n]);
       __builtin_amdgcn_sched_barrier(0);
       if (j + D < 5) request(j + D);
       __builtin_amdgcn_sched_barrier(0);
     }
     STAMP(2);
     // conv2 weights and the residual: in flight across the gate phase
-    const uint4* W2 = (const uint4*)d.wc2 + ((size_t)wave * 4 * 3) * 64 + lane;
-    uint4 w2[4][3];
+    const uint4* W2 = (const uint4*)d.wc2 + ((size_t)wave * 4 * NP) * 64 + lane;
+    uint4 w2[4][NP];
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) w2[kb][p] = W2[(size_t)(kb * 3 + p) * 64];
+      for (int p = 0; p < NP; ++p) w2[kb][p] = W2[(size_t)(kb * NP + p) * 64];
     const float* xb = d.x + ((size_t)b * 256 + 32 * wave) * T;
     float xres[NT][16];
 #pragma unroll
@@ -239,12 +267,11 @@ __global__ __launch_bounds__(512 * TW, NT == 1 ? 4 : 2) void tcm2_kernel(const p
         const float k = (part[n][2][c][f] + part[n][3][c][f]) + gp[1];
         v[i] = gp[2] * prelu2(m * sigmoid_f(k), d.slope2) + gp[3];
       }
-      uint2 p1, p2, p3;
-      split4(v, p1, p2, p3);
+      uint2 pp[NP];
+      split4n<NP>(v, pp);
       char* g = gls[n] + f * GL_ROW + cg * 8;
-      *(uint2*)g = p1;
-      *(uint2*)(g + 32 * GL_ROW) = p2;
-      *(uint2*)(g + 64 * GL_ROW) = p3;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) *(uint2*)(g + p * 32 * GL_ROW) = pp[p];
     }
     __syncthreads();
     STAMP(4);
@@ -257,10 +284,10 @@ __global__ __launch_bounds__(512 * TW, NT == 1 ? 4 : 2) void tcm2_kernel(const p
       const char* gb = gls[n] + col * GL_ROW + hh * 16;
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb) {
-        uint4 bp[3];
+        uint4 bp[NP];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) bp[p] = *(const uint4*)(gb + p * 32 * GL_ROW + kb * 32);
-        a2[n] = mfma6r(w2[kb], bp, a2[n]);
+        for (int p = 0; p < NP; ++p) bp[p] = *(const uint4*)(gb + p * 32 * GL_ROW + kb * 32);
+        a2[n] = mfma6r<NP>(w2[kb], bp, a2[n]);
       }
     }
 #pragma unroll
@@ -282,15 +309,15 @@ __global__ __launch_bounds__(512 * TW, NT == 1 ? 4 : 2) void tcm2_kernel(const p
 
   STAMP(5);
   // next conv1's weights: requested before x' is stored
-  uint4 wn[2][2][3];
+  uint4 wn[2][2][NP];
   if (chain) {
-    const uint4* WN = (const uint4*)d.wn1 + ((size_t)(2 * wave) * 3) * 64 + lane;   // [2 mo][16 blocks][3][64]
+    const uint4* WN = (const uint4*)d.wn1 + ((size_t)(2 * wave) * NP) * 64 + lane;   // [2 mo][16 blocks][3][64]
 #pragma unroll
     for (int mo = 0; mo < 2; ++mo)
 #pragma unroll
       for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) wn[mo][s][p] = WN[(size_t)((mo * 16 + s) * 3 + p) * 64];
+        for (int p = 0; p < NP; ++p) wn[mo][s][p] = WN[(size_t)((mo * 16 + s) * NP + p) * 64];
   }
   if constexpr (MODE == 0) {
     float* xo = d.x_out + ((size_t)b * 256 + 32 * wave) * T;
@@ -318,10 +345,10 @@ __global__ __launch_bounds__(512 * TW, NT == 1 ? 4 : 2) void tcm2_kernel(const p
       float xv[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) xv[j] = a2[n][8 * s + j];
-      uint4 bp[3];
-      split8(xv, bp[0], bp[1], bp[2]);
-      a1[n][0] = mfma6r(wn[0][s], bp, a1[n][0]);
-      a1[n][1] = mfma6r(wn[1][s], bp, a1[n][1]);
+      uint4 bp[NP];
+      split8n<NP>(xv, bp);
+      a1[n][0] = mfma6r<NP>(wn[0][s], bp, a1[n][0]);
+      a1[n][1] = mfma6r<NP>(wn[1][s], bp, a1[n][1]);
     }
   STAMP(6);
   // part is free: every thread passed the barrier behind G
@@ -361,23 +388,21 @@ __global__ __launch_bounds__(512 * TW, NT == 1 ? 4 : 2) void tcm2_kernel(const p
         vk[i] = xp[2] * prelu2(s, d.slope_mask_next) + xp[3];
       }
       const size_t plane = (size_t)TP * 16;
-      char* ho = (char*)d.hs_out + ((size_t)(b * 2) * 24 + (size_t)cg * 3) * plane + (size_t)(t + HS_PAD) * 16;
-      uint4 p1, p2, p3;
-      split8(vm, p1, p2, p3);
-      *(uint4*)ho = p1;
-      *(uint4*)(ho + plane) = p2;
-      *(uint4*)(ho + 2 * plane) = p3;
-      split8(vk, p1, p2, p3);
-      ho += 24 * plane;
-      *(uint4*)ho = p1;
-      *(uint4*)(ho + plane) = p2;
-      *(uint4*)(ho + 2 * plane) = p3;
+      char* ho = (char*)d.hs_out + ((size_t)(b * 2) * (8 * NP) + (size_t)cg * NP) * plane + (size_t)(t + HS_PAD) * 16;
+      uint4 pq[NP];
+      split8n<NP>(vm, pq);
+#pragma unroll
+      for (int p = 0; p < NP; ++p) *(uint4*)(ho + p * plane) = pq[p];
+      split8n<NP>(vk, pq);
+      ho += (8 * NP) * plane;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) *(uint4*)(ho + p * plane) = pq[p];
     }
   }
   STAMP(7);
 }
 
-template <int NT, int TW>
+template <int NT, int TW, int NP>
 int launch_tcm2(const pdse_tcm2_desc* d, hipStream_t s) {
   const dim3 grid((d->T + 32 * NT * TW - 1) / (32 * NT * TW), d->B);
   static long long* tbuf = nullptr;
@@ -392,8 +417,8 @@ int launch_tcm2(const pdse_tcm2_desc* d, hipStream_t s) {
     }
     (void)hipMemsetAsync(tbuf, 0, nst * sizeof(long long), s);
   }
-  if (d->mode == 1) hipLaunchKernelGGL((tcm2_kernel<1, NT, TW>), grid, dim3(512 * TW), 0, s, *d);
-  else hipLaunchKernelGGL((tcm2_kernel<0, NT, TW>), grid, dim3(512 * TW), 0, s, *d);
+  if (d->mode == 1) hipLaunchKernelGGL((tcm2_kernel<1, NT, TW, NP>), grid, dim3(512 * TW), 0, s, *d);
+  else hipLaunchKernelGGL((tcm2_kernel<0, NT, TW, NP>), grid, dim3(512 * TW), 0, s, *d);
   if (tracing) {   // diagnostic: per-phase shader-clock averages over all waves, and the spread of start times (100 MHz clock)
     (void)hipStreamSynchronize(s);
     long long* h = (long long*)malloc(nst * sizeof(long long));
@@ -431,11 +456,13 @@ int pdse_tcm2_launch(const pdse_tcm2_desc* d, hipStream_t s) {
   // workgroup shape 10 NT + TW.  Measured at B=32, T=401 (us per forward, 18 blocks): 11 -> 592, 21 (64 frames, two
   // tiles per wave) -> 730, 12 (64 frames, two teams of 8 waves) -> 769: the shapes that halve the weight bytes per
   // CU lose more to their longer dependent chains / simultaneous identical requests.  PDSE_TCM2_SHAPE: ablation.
-  static const int force = getenv("PDSE_TCM2_SHAPE") ? atoi(getenv("PDSE_TCM2_SHAPE")) : 0;
+  REQ(d->np == 0 || d->np == 3 || d->np == 1, "tcm2: np is 3 (exact splits; 0 means 3) or 1 (plain bf16)");
+  if (d->np == 1) return launch_tcm2<1, 1, 1>(d, s);   // the opt-in bf16 mode
+  static const int force = PDSE_DIAG_ENV("PDSE_TCM2_SHAPE") ? atoi(PDSE_DIAG_ENV("PDSE_TCM2_SHAPE")) : 0;
   const int shape = force ? force : 11;
   switch (shape) {
-    case 12: return launch_tcm2<1, 2>(d, s);
-    case 21: return launch_tcm2<2, 1>(d, s);
-    default: return launch_tcm2<1, 1>(d, s);
+    case 12: return launch_tcm2<1, 2, 3>(d, s);
+    case 21: return launch_tcm2<2, 1, 3>(d, s);
+    default: return launch_tcm2<1, 1, 3>(d, s);
   }
 }

@@ -390,7 +390,7 @@ class EpsNetPlan(PlanBase):
         self.tcm_a, self.tcm_b = a(B, 256, T), a(B, 256, T)
         self.tcm_h, self.tcm_g = a(B, 64, T), a(B, 64, T)
         # the same bottleneck tensor as the split-bf16 blocks exchange it (pdse_tcm2_desc.hs; its margins stay zero)
-        self.tcm_hs = [ctx.alloc_u16(*P.tcm2_hs_shape(B, T)) for _ in range(2)]
+        self.tcm_hs = [ctx.alloc_u16(*P.tcm2_hs_shape(B, T, self.planes)) for _ in range(2)]
         self.dec = [a(B, 64, T, 79), a(B, 64, T, 79)]  # ping-pong decoder activations (largest F=79)
         if self.plane_h:
             # plane tensors of the conv1 outputs (include/pdse.h: hp), one per stage so that their margins stay zero:
@@ -733,29 +733,29 @@ class EpsNetPlan(PlanBase):
                 s2, h2 = P.bn_fold(self.sd, p + ".conv2.1")
                 par[:256] = np.stack([self.w(p + ".mainbranch.2.bias"), self.w(p + ".maskbranch.2.bias"), s2, h2], 1).reshape(-1)
                 par[256:512] = self.w(p + ".conv2.2.bias")
-                f.update(wbr=up16(P.pack_tcm2_branch(kmain, kmask)),
-                         wc2=up16(P.pack_tcm2_conv2(self.w(p + ".conv2.2.weight")[:, :, 0].T)),
+                f.update(wbr=up16(P.pack_tcm2_branch(kmain, kmask, self.planes)),
+                         wc2=up16(P.pack_tcm2_conv2(self.w(p + ".conv2.2.weight")[:, :, 0].T, self.planes)),
                          slope2=float(self.w(p + ".conv2.0.weight")[0]))
             if p_next is not None:
                 sm, hm = P.bn_fold(self.sd, p_next + ".mainbranch.1")
                 sk, hk = P.bn_fold(self.sd, p_next + ".maskbranch.1")
                 par[512:576] = self.w(p_next + ".conv1.bias")
                 par[576:] = np.stack([sm, hm, sk, hk], 1).reshape(-1)
-                f.update(wn1=up16(P.pack_s3_chain(self.w(p_next + ".conv1.weight")[:, :, 0])),
+                f.update(wn1=up16(P.pack_bglu_chain(self.w(p_next + ".conv1.weight")[:, :, 0], self.planes)),
                          slope_main_next=float(self.w(p_next + ".mainbranch.0.weight")[0]),
                          slope_mask_next=float(self.w(p_next + ".maskbranch.0.weight")[0]))
             f["par"] = self.ctx.up(par).data_ptr()
             return f
 
         d = L.Tcm2Desc()
-        for k, v in self.memo("%s.split%d" % (p if mode == 0 else p_next, mode), make).items():
+        for k, v in self.memo("%s.split%d.np%d" % (p if mode == 0 else p_next, mode, self.planes), make).items():
             setattr(d, k, v)
         d.x = xin.data_ptr()
         if mode == 0:
             d.x_out, d.hs = xout.data_ptr(), hin.data_ptr()
         if p_next is not None:
             d.hs_out = hout.data_ptr()
-        d.dil, d.B, d.T, d.mode = dil, self.B, self.T, mode
+        d.dil, d.B, d.T, d.mode, d.np = dil, self.B, self.T, mode, self.planes
         self.add(d, TAG_TCM)
 
 

@@ -304,22 +304,27 @@ def rho_bf16(s, j, h):
     return (r & 3) + 8 * (r >> 2) + 4 * h
 
 
-def pack_s3_gather(wk, ntaps, cin=32):
-    """wk [ntaps*cin, 32] (k = tap*cin + c, k-major) -> uint16 [ntaps*cin/16 blocks][3 planes][64 lanes][8]:
-    block tap*(cin/16) + q, lane (row = lane & 31, h = lane >> 5), element j = wk[tap*cin + 16q + 8h + j][row]."""
+def pack_s3_gather(wk, ntaps, cin=32, npl=3):
+    """wk [ntaps*cin, 32] (k = tap*cin + c, k-major) -> uint16 [ntaps*cin/16 blocks][npl planes][64 lanes][8]:
+    block tap*(cin/16) + q, lane (row = lane & 31, h = lane >> 5), element j = wk[tap*cin + 16q + 8h + j][row].
+    npl 3: exact three-way bf16 split; 1: the RNE bf16 value (bf16 mode)."""
     wk = np.asarray(wk, np.float64).astype(np.float32)
     assert wk.shape == (ntaps * cin, 32) and cin % 16 == 0
     nb = ntaps * cin // 16
     k = (16 * np.arange(nb)[:, None, None] + 8 * np.arange(2)[None, :, None] + np.arange(8)[None, None, :])   # [nb, h, j]
     frag = wk[k][:, :, :, :].transpose(0, 1, 3, 2)                      # [nb, h, row, j]
     frag = frag.reshape(nb, 64, 8)
+    if npl == 1:
+        return np.ascontiguousarray(bf16_rne(frag)[:, None])             # [nb, 1, 64, 8]
     p = split_bf16x3(frag)
     return np.ascontiguousarray(np.stack(p, 1))                          # [nb, 3, 64, 8]
 
 
 def unpack_s3_gather(packed, ntaps, cin=32):
-    packed = np.asarray(packed, np.uint16).reshape(ntaps * cin // 16, 3, 2, 32, 8)     # [nb, plane, h, row, j]
-    f = join_bf16x3([packed[:, i] for i in range(3)])                                  # [nb, h, row, j]
+    packed = np.asarray(packed, np.uint16)
+    npl = packed.size // (ntaps * cin // 16 * 512)
+    packed = packed.reshape(ntaps * cin // 16, npl, 2, 32, 8)                          # [nb, plane, h, row, j]
+    f = sum(bf16_to_f32(packed[:, i]) for i in range(npl))                             # [nb, h, row, j]
     return f.transpose(0, 1, 3, 2).reshape(ntaps * cin, 32)                             # k = 16 nb + 8h + j
 
 
@@ -355,50 +360,54 @@ def unpack_s3_chain(packed, mt, K):
 TCM2_HS_PAD = 64           # zero frames on either side of hs (2 x the largest dilation)
 
 
-def tcm2_hs_shape(B, T):
-    """hs (uint16): [B][2 branch][4 kb][2 kg][3 planes][T + 2 pad][8], channel 16 kb + 8 kg + j, frame t at t + pad."""
-    return (B, 2, 4, 2, 3, T + 2 * TCM2_HS_PAD, 8)
+def tcm2_hs_shape(B, T, npl=3):
+    """hs (uint16): [B][2 branch][4 kb][2 kg][npl planes][T + 2 pad][8], channel 16 kb + 8 kg + j, frame t at t + pad."""
+    return (B, 2, 4, 2, npl, T + 2 * TCM2_HS_PAD, 8)
 
 
-def pack_tcm2_branch(k_main, k_mask):
-    """k_* [320, 64] (row = tap*64 + channel) -> uint16 [2 main|mask][2 mi][20 blocks][3][64][8]."""
-    return np.ascontiguousarray(np.stack([np.stack([pack_s3_gather(np.asarray(k)[:, 32 * mi:32 * mi + 32], 5, 64)
+def pack_tcm2_branch(k_main, k_mask, npl=3):
+    """k_* [320, 64] (row = tap*64 + channel) -> uint16 [2 main|mask][2 mi][20 blocks][npl][64][8]."""
+    return np.ascontiguousarray(np.stack([np.stack([pack_s3_gather(np.asarray(k)[:, 32 * mi:32 * mi + 32], 5, 64, npl)
                                                     for mi in range(2)]) for k in (k_main, k_mask)]))
 
 
 def unpack_tcm2_branch(packed):
-    packed = np.asarray(packed, np.uint16).reshape(2, 2, 20, 3, 64, 8)
+    packed = np.asarray(packed, np.uint16)
+    packed = packed.reshape(2, 2, 20, packed.size // (2 * 2 * 20 * 512), 64, 8)
     return [np.concatenate([unpack_s3_gather(packed[br, mi], 5, 64) for mi in range(2)], axis=1) for br in range(2)]
 
 
-def pack_tcm2_conv2(k2):
-    """k2 [64, 256] (row = gate channel) -> uint16 [8 mt][4 kb][3][64][8]."""
-    return np.ascontiguousarray(np.stack([pack_s3_gather(np.asarray(k2)[:, 32 * mt:32 * mt + 32], 1, 64) for mt in range(8)]))
+def pack_tcm2_conv2(k2, npl=3):
+    """k2 [64, 256] (row = gate channel) -> uint16 [8 mt][4 kb][npl][64][8]."""
+    return np.ascontiguousarray(np.stack([pack_s3_gather(np.asarray(k2)[:, 32 * mt:32 * mt + 32], 1, 64, npl) for mt in range(8)]))
 
 
 def unpack_tcm2_conv2(packed):
-    packed = np.asarray(packed, np.uint16).reshape(8, 4, 3, 64, 8)
+    packed = np.asarray(packed, np.uint16)
+    packed = packed.reshape(8, 4, packed.size // (8 * 4 * 512), 64, 8)
     return np.concatenate([unpack_s3_gather(packed[mt], 1, 64) for mt in range(8)], axis=1)
 
 
-def tcm2_split_h(v_main, v_mask):
+def tcm2_split_h(v_main, v_mask, npl=3):
     """Transformed bottleneck tensors [B, 64, T] of the two branches -> hs uint16 (tcm2_hs_shape; margins zero)."""
     B, C, T = v_main.shape
-    hs = np.zeros(tcm2_hs_shape(B, T), np.uint16)
+    hs = np.zeros(tcm2_hs_shape(B, T, npl), np.uint16)
     for br, v in enumerate((v_main, v_mask)):
-        p = split_bf16x3(np.asarray(v, np.float32).reshape(B, 4, 2, 8, T).transpose(0, 1, 2, 4, 3))   # [B, kb, kg, T, j]
-        for i in range(3):
+        p = to_planes(np.asarray(v, np.float32).reshape(B, 4, 2, 8, T).transpose(0, 1, 2, 4, 3), npl)   # [npl][B, kb, kg, T, j]
+        for i in range(npl):
             hs[:, br, :, :, i, TCM2_HS_PAD:TCM2_HS_PAD + T, :] = p[i]
     return hs
 
 
 def tcm2_join_h(hs, B, T):
     """Inverse of tcm2_split_h: (v_main, v_mask) float32 [B, 64, T]; asserts the zero margins."""
-    hs = np.asarray(hs, np.uint16).reshape(tcm2_hs_shape(B, T))
+    hs = np.asarray(hs, np.uint16)
+    npl = hs.size // int(np.prod(tcm2_hs_shape(B, T, 1)))
+    hs = hs.reshape(tcm2_hs_shape(B, T, npl))
     assert not hs[..., :TCM2_HS_PAD, :].any() and not hs[..., TCM2_HS_PAD + T:, :].any(), "hs: the margins must stay zero"
     out = []
     for br in range(2):
-        v = join_bf16x3([hs[:, br, :, :, i, TCM2_HS_PAD:TCM2_HS_PAD + T, :] for i in range(3)])    # [B, kb, kg, T, j]
+        v = sum(bf16_to_f32(hs[:, br, :, :, i, TCM2_HS_PAD:TCM2_HS_PAD + T, :]) for i in range(npl))    # [B, kb, kg, T, j]
         out.append(np.ascontiguousarray(v.transpose(0, 1, 2, 4, 3).reshape(B, 64, T)))
     return out
 

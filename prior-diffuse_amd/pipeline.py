@@ -41,9 +41,9 @@ class SamplerPipeline:
         and the eps call :967-971 let ``pirorgrad`` win): default = deltamu; True with deltamu False is the reference's
         behaviour when BOTH flags are set (DiffUNet1 conditioned on X_init, start from noise + X_init/11, final + X_init).
         dtype: "f32" (default: fp32 or fp32-equivalent split-bf16 arithmetic, see split_bf16) or "bf16" - the OPT-IN reduced
-        precision mode of BASELINE configs 2/4/5: the eps-net's BiConv(Trans)GLU blocks multiply plain bf16 operands (one
-        MFMA product, fp32 accumulate) and exchange their conv1 outputs as bf16 tensors (csrc/bglu.hip, one plane); the
-        diffusion state, the skip halves, the TCM stack and the prior stay as in "f32".  Its tolerance is its own (stated in
+        precision mode of BASELINE configs 2/4/5: the eps-net's BiConv(Trans)GLU and TCM blocks multiply plain bf16 operands
+        (one MFMA product, fp32 accumulate) and exchange their conv1 / bottleneck tensors as bf16 (csrc/bglu.hip, csrc/tcm2.hip,
+        one plane); the diffusion state, the skip halves, the residual stream of the TCM stack and the prior stay as in "f32".  Its tolerance is its own (stated in
         tests/test_gpu_round2.py::test_bf16_mode_tolerance), it is never the default and never the graded bench line.
         bank: a ``nets.WeightBank`` shared with other pipelines built from the same state_dicts (packed weights are
         uploaded once, every further (B, T) only records descriptors).

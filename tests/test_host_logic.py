@@ -179,3 +179,30 @@ def test_stft_bases_against_numpy_fft():
     k = np.empty(322)
     k[0::2], k[1::2] = z.real, z.imag
     assert np.allclose(k @ P.istft_kmat(320), frame)
+
+
+def test_eps_net_plan_bf16_mode_vs_oracle(weights):
+    """The opt-in bf16 mode (one plane): every BiConv(Trans)GLU stage and every TCM block with plain bf16 matrix operands and
+    bf16 exchanged tensors, replayed on the interpreter (which rounds where the kernels round): the result stays within the
+    mode's stated tolerance of the fp32 oracle and is NOT fp32-equivalent."""
+    nets, Lb = pkg("nets"), pkg("_lib")
+    B, T = 2, 12
+    sd = weights("DiffUNet1")
+    ctx = nets.Ctx("cpu")
+    net = nets.EpsNetPlan(ctx, sd, B, T, time_cond=True, nsteps=1, planes=1)
+    net.build_time()
+    net.build_step(0)
+    assert all(d.np == 1 for d, _ in net.descs if isinstance(d, (Lb.BgluDesc, Lb.Tcm2Desc, Lb.PlanesDesc)))
+    assert sum(1 for d, _ in net.descs if isinstance(d, Lb.BgluDesc)) == 15 and sum(1 for d, _ in net.descs if isinstance(d, Lb.Tcm2Desc)) == 19
+    x, xi = seeded((B, 2, T, 161), 3), seeded((B, 2, T, 161), 4) * 0.3
+    t = torch.tensor([4.086654, 22.992493])
+    net.x.copy_(x)
+    net.x_init.copy_(xi)
+    net.tsteps.copy_(t.view(1, B))
+    emu.run(net.descs, ctx.all_tensors())
+    with torch.no_grad():
+        ref = R.diffunet1_forward(sd, x, xi, t)
+    e = rel_l2(net.out, ref)
+    assert 1e-4 < e < 3e-2, e
+    with pytest.raises(ValueError):
+        nets.EpsNetPlan(nets.Ctx("cpu"), weights("Nocon"), B, T, time_cond=True, nsteps=1, with_pre=False, planes=1)
