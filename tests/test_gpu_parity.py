@@ -7,6 +7,12 @@ Tolerances (fp32 both sides; only summation order differs: MFMA fmaf chains vs o
   single network forward        rel-L2 <= 2e-5
   6-step / 50-step sampling     rel-L2 <= 1e-4   (north-star tolerance)
   reverse-step arithmetic       bit-exact
+
+Sensitivity of the sampling-level bound: the seeded weights scale the eps-net's last decoder stage by 0.15 (synth.py; at unit
+gain the random network makes the reverse loop chaotic and no two fp32 implementations could be compared), so an error of the
+eps-net reaches the 6-step result about 6x weaker than it would at unit gain: the 1e-4 sampling checks alone would pass an
+eps-net that is 6e-4 off.  They do not stand alone - every network forward is checked on its own against the reference's
+golden vectors at 2e-5 (measured 1-3e-6), per-step traces at 1e-4, batch invariance bit for bit.
 """
 import importlib
 import os
