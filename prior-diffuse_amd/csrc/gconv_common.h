@@ -677,4 +677,36 @@ __device__ __forceinline__ void gconv_epilogue(const pdse_gconv_desc& d, const p
   else
     gconv_epilogue_impl<EPI, MT, false>(d, tl, acc0, acc1, b, t, j, pvalid, lane, h, mt0, mtiles, extra_off);
 }
+
+// Raw buffer access: address = resource base (4 scalar registers) + 32-bit lane byte offset + scalar byte offset, so no
+// 64-bit per-lane address lives in vector registers (with flat pointers hipcc kept one 64-bit address per load of a tile -
+// 72 registers - and spilled; every spill reload is a scratch load + s_waitcnt vmcnt(0), which drains all prefetches), and
+// reads beyond the resource return zero instead of faulting.
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+#define PDSE_RSRC_FLAGS 0x00020000
+// The base and the size pass through readfirstlane: a resource that hipcc does not PROVE wave-uniform (it kept the one of the
+// plane loads in vector registers) makes every access a waterfall loop - four readfirstlane, two compares, a saveexec and a
+// branch per load, 36 of them per tile, each splitting the basic block the slot schedule lives in.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, const uint32_t bytes) {
+  const uint64_t a = reinterpret_cast<uint64_t>(p);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+  void* const q = reinterpret_cast<void*>(((uint64_t)hi << 32) | lo);
+  return __builtin_amdgcn_make_buffer_rsrc(q, (short)0, (int)__builtin_amdgcn_readfirstlane(bytes), PDSE_RSRC_FLAGS);
+}
+__device__ __forceinline__ uint4 bload16(const __amdgpu_buffer_rsrc_t r, const uint32_t voff, const int soff) {
+  const v4i_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, 0);
+  return make_uint4((uint32_t)v.x, (uint32_t)v.y, (uint32_t)v.z, (uint32_t)v.w);
+}
+__device__ __forceinline__ float bload4(const __amdgpu_buffer_rsrc_t r, const uint32_t voff, const int soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, soff, 0));
+}
+__device__ __forceinline__ void bstore16(const uint4& x, const __amdgpu_buffer_rsrc_t r, const uint32_t voff, const int soff) {
+  v4i_t v;
+  v.x = (int)x.x; v.y = (int)x.y; v.z = (int)x.z; v.w = (int)x.w;
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff, soff, 0);
+}
+__device__ __forceinline__ void bstore4(const float x, const __amdgpu_buffer_rsrc_t r, const uint32_t voff, const int soff) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, x), r, (int)voff, soff, 0);
+}
+
 #endif

@@ -161,15 +161,18 @@ __global__ __launch_bounds__(512 * TW, NT == 1 ? 4 : 2) void tcm2_kernel(const p
   if constexpr (MODE == 0) {
     // -------------------------------------------------------------- A: dilated branches
     const int br = wave & 1, kq = wave >> 1;
-    const size_t plane = (size_t)TP * 16;                      // bytes of one fragment plane of one (kb, kg)
-    const char* hbase = (const char*)d.hs + (size_t)(b * 2 + br) * (8 * NP) * plane;   // wave-uniform
-    int roff[NT][5];    // lane offsets of the five taps: this lane half's planes + frame (the margins are zeros)
+    const int plane = TP * 16;                                 // bytes of one fragment plane of one (kb, kg)
+    // raw buffer access (gconv_common.h): the slab of (utterance, branch) and the weights are resources in scalar
+    // registers, a lane holds ONE 32-bit byte offset per frame tile, and the tap is a scalar offset.  (Until round 3 the
+    // five per-tap lane offsets sat in an array indexed by the wave-uniform tap: hipcc put it in scratch, and each
+    // scratch load's s_waitcnt made the wave wait for the other slot's operands before it asked for the next ones.)
+    const __amdgpu_buffer_rsrc_t r_hs = make_rsrc((const char*)d.hs + (size_t)(b * 2 + br) * (8 * NP) * plane, (uint32_t)(8 * NP * plane));
+    const __amdgpu_buffer_rsrc_t r_wa = make_rsrc((const uint4*)d.wbr + (size_t)(br * 2 * 20 + 5 * kq) * NP * 64,
+                                                  (uint32_t)((2 * 20 - 5 * kq) * NP * 1024));   // [br][2 mi][20][3][64]
+    int roff[NT];       // lane offset of tap 0: this lane half's planes + frame - 2 dil (the margins are zeros; a lane
+                        // without a frame reads those of frame T-1 and its column is never stored)
 #pragma unroll
-    for (int n = 0; n < NT; ++n)
-#pragma unroll
-      for (int k = 0; k < 5; ++k)
-        roff[n][k] = hh * NP * (int)plane + (tlive[n] ? t0 + 32 * n + col + (k - 2) * d.dil + HS_PAD : 0) * 16;
-    const uint4* WA = (const uint4*)d.wbr + ((size_t)(br * 2 * 20 + 5 * kq) * NP) * 64 + lane;   // [br][2 mi][20][3][64]
+    for (int n = 0; n < NT; ++n) roff[n] = hh * NP * plane + ((tlive[n] ? t0 + 32 * n + col : T - 1) - 2 * d.dil + HS_PAD) * 16;
     constexpr int D = 2;   // K blocks in flight (a slot is requested again as soon as its MFMAs have issued)
     uint4 qa[D][2][NP], qb[D][NT][NP];
     // workgroups walk their five K blocks in an order rotated by the frame tile index: neighbours in time do not ask L2
@@ -180,22 +183,21 @@ __global__ __launch_bounds__(512 * TW, NT == 1 ? 4 : 2) void tcm2_kernel(const p
       const int slot = i % D;
       const int j = (i + js) % 5;
       const int kbi = 5 * kq + j;                              // wave-uniform: tap = kbi >> 2, channel block = kbi & 3
-      const char* hq = hbase + (size_t)(kbi & 3) * (2 * NP) * plane;
+      const int hq = (kbi & 3) * (2 * NP) * plane + (kbi >> 2) * d.dil * 16;
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int p = 0; p < NP; ++p) qa[slot][mi][p] = WA[(size_t)((mi * 20 + j) * NP + p) * 64];
+        for (int p = 0; p < NP; ++p) qa[slot][mi][p] = bload16(r_wa, lane * 16, ((mi * 20 + j) * NP + p) * 1024);
 #pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        int ro = roff[n][0];
+      for (int n = 0; n < NT; ++n)
 #pragma unroll
-        for (int k = 1; k < 5; ++k) ro = (kbi >> 2) == k ? roff[n][k] : ro;
-#pragma unroll
-        for (int p = 0; p < NP; ++p) qb[slot][n][p] = *(const uint4*)(hq + p * plane + ro);
-      }
+        for (int p = 0; p < NP; ++p) qb[slot][n][p] = bload16(r_hs, roff[n], hq + p * plane);
     };
 #pragma unroll
-    for (int j = 0; j < D; ++j) request(j);
+    for (int j = 0; j < D; ++j) {
+      request(j);
+      __builtin_amdgcn_sched_barrier(0);   // slot 0's operands are requested first (hipcc interleaved the two slots)
+    }
     f32x16 acc[2][NT];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
@@ -216,18 +218,18 @@ __global__ __launch_bounds__(512 * TW, NT == 1 ? 4 : 2) void tcm2_kernel(const p
     }
     STAMP(2);
     // conv2 weights and the residual: in flight across the gate phase
-    const uint4* W2 = (const uint4*)d.wc2 + ((size_t)wave * 4 * NP) * 64 + lane;
+    const __amdgpu_buffer_rsrc_t r_w2 = make_rsrc((const uint4*)d.wc2 + (size_t)wave * 4 * NP * 64, (uint32_t)(4 * NP * 1024));
     uint4 w2[4][NP];
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-      for (int p = 0; p < NP; ++p) w2[kb][p] = W2[(size_t)(kb * NP + p) * 64];
-    const float* xb = d.x + ((size_t)b * 256 + 32 * wave) * T;
+      for (int p = 0; p < NP; ++p) w2[kb][p] = bload16(r_w2, lane * 16, (kb * NP + p) * 1024);
+    const __amdgpu_buffer_rsrc_t r_x = make_rsrc(d.x + ((size_t)b * 256 + 32 * wave) * T, (uint32_t)(32 * T * 4));
     float xres[NT][16];
 #pragma unroll
     for (int n = 0; n < NT; ++n)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) xres[n][r] = (xb + (size_t)((r & 3) + 8 * (r >> 2)) * T)[lrow[n]];
+      for (int r = 0; r < 16; ++r) xres[n][r] = bload4(r_x, lrow[n] * 4, ((r & 3) + 8 * (r >> 2)) * T * 4);
     __builtin_amdgcn_sched_barrier(0);
     store_par();
     // K quarters 2, 3 -> LDS; quarters 0, 1 add theirs: part[n][2 br + (kq & 1)] = quarter (kq & 1) + quarter (kq & 1) + 2
@@ -299,11 +301,11 @@ __global__ __launch_bounds__(512 * TW, NT == 1 ? 4 : 2) void tcm2_kernel(const p
         for (int i = 0; i < 4; ++i) a2[n][4 * r4 + i] += bb[i] + xres[n][4 * r4 + i];
     }
   } else {
-    const float* xb = d.x + ((size_t)b * 256 + 32 * wave) * T;
+    const __amdgpu_buffer_rsrc_t r_x = make_rsrc(d.x + ((size_t)b * 256 + 32 * wave) * T, (uint32_t)(32 * T * 4));
 #pragma unroll
     for (int n = 0; n < NT; ++n)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) a2[n][r] = (xb + (size_t)((r & 3) + 8 * (r >> 2)) * T)[lrow[n]];
+      for (int r = 0; r < 16; ++r) a2[n][r] = bload4(r_x, lrow[n] * 4, ((r & 3) + 8 * (r >> 2)) * T * 4);
     store_par();
   }
 
@@ -311,21 +313,21 @@ __global__ __launch_bounds__(512 * TW, NT == 1 ? 4 : 2) void tcm2_kernel(const p
   // next conv1's weights: requested before x' is stored
   uint4 wn[2][2][NP];
   if (chain) {
-    const uint4* WN = (const uint4*)d.wn1 + ((size_t)(2 * wave) * NP) * 64 + lane;   // [2 mo][16 blocks][3][64]
+    const __amdgpu_buffer_rsrc_t r_wn = make_rsrc((const uint4*)d.wn1 + (size_t)(2 * wave) * NP * 64, (uint32_t)((32 - 2 * wave) * NP * 1024));   // [2 mo][16 blocks][3][64]
 #pragma unroll
     for (int mo = 0; mo < 2; ++mo)
 #pragma unroll
       for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int p = 0; p < NP; ++p) wn[mo][s][p] = WN[(size_t)((mo * 16 + s) * NP + p) * 64];
+        for (int p = 0; p < NP; ++p) wn[mo][s][p] = bload16(r_wn, lane * 16, ((mo * 16 + s) * NP + p) * 1024);
   }
   if constexpr (MODE == 0) {
-    float* xo = d.x_out + ((size_t)b * 256 + 32 * wave) * T;
+    const __amdgpu_buffer_rsrc_t r_xo = make_rsrc(d.x_out + ((size_t)b * 256 + 32 * wave) * T, (uint32_t)(32 * T * 4));
 #pragma unroll
     for (int n = 0; n < NT; ++n)
       if (tlive[n]) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) (xo + (size_t)((r & 3) + 8 * (r >> 2)) * T)[lrow[n]] = a2[n][r];
+        for (int r = 0; r < 16; ++r) bstore4(a2[n][r], r_xo, lrow[n] * 4, ((r & 3) + 8 * (r >> 2)) * T * 4);
       }
   }
   if (!chain) return;   // uniform over the grid
