@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define PDSE_ABI_VERSION 4
+#define PDSE_ABI_VERSION 5
 
 typedef void* pdse_stream_t; /* hipStream_t */
 
@@ -51,6 +51,12 @@ typedef struct pdse_src {
   int64_t sb, sc, st, sf; /* element strides of batch, channel, frame (t), bin (f) */
   int32_t C;              /* channels taken from this source                       */
   int32_t act;            /* pdse_act applied on load (ELU on GCRN skip tensors)    */
+  /* blk 8 (korder 3 only, ABI 5): the tensor is stored in blocks of 8 channels, [B][C/8][T][F][8] - channel c lives at
+     (c >> 3)*sc + (c & 7), sc / st / sf being the element strides of a block, a frame and a bin (multiples of 4), so a
+     lane's 8 channels of one K block are 32 contiguous bytes (two 16-byte loads instead of eight 4-byte gathers).  It is
+     what a launch with out_cr = 8, out_sc_lo = 1 writes.  0: plain strides, channel c at c*sc. */
+  int32_t blk;
+  int32_t pad_;
 } pdse_src;
 
 /* Gather-GEMM convolution:
@@ -270,7 +276,9 @@ typedef struct pdse_sigma_desc {
 } pdse_sigma_desc;
 
 /* LayerNorm over the last dim of [B][T][N] rows with a strided/transposed store
- * (gcrn.py:31, :35): out[b*osb + (j / r)*os_hi + (j % r)*os_lo + t*os_t]. */
+ * (gcrn.py:31, :35): out[b*osb + (j / r)*os_hi + (j % r)*os_lo + t*os_t];
+ * blk 8 (ABI 5): c = j / r is a channel of a tensor kept in blocks of 8 channels (pdse_src.blk): it is stored at
+ * (c >> 3)*os_hi + (c & 7) instead of c*os_hi. */
 typedef struct pdse_ln_desc {
   const float* in;
   const float* gamma;
@@ -279,7 +287,7 @@ typedef struct pdse_ln_desc {
   int64_t osb, os_hi, os_lo, os_t;
   int32_t B, T, N, r;
   float eps;
-  int32_t pad_;
+  int32_t blk;
 } pdse_ln_desc;
 
 /* One LSTM layer of the grouped LSTM (gcrn.py:6-40), all T steps, G independent groups.

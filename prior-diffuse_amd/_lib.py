@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PDSE_LIB") or os.path.join(_HERE, "libpdse.so")   # PDSE_LIB: diagnostic builds only
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 ACT_NONE, ACT_PRELU, ACT_ELU, ACT_SIGMOID = 0, 1, 2, 3
 EPI_LINEAR, EPI_GLU, EPI_BIGLU = 0, 1, 2
@@ -25,7 +25,7 @@ _i32, _i64, _f32 = C.c_int32, C.c_int64, C.c_float
 
 class Src(C.Structure):
     _fields_ = [("ptr", _fp), ("sb", _i64), ("sc", _i64), ("st", _i64), ("sf", _i64),
-                ("C", _i32), ("act", _i32)]
+                ("C", _i32), ("act", _i32), ("blk", _i32), ("pad_", _i32)]
 
 
 class GconvDesc(C.Structure):
@@ -88,7 +88,7 @@ class SigmaDesc(C.Structure):
 class LnDesc(C.Structure):
     _fields_ = [("in_", _fp), ("gamma", _fp), ("beta", _fp), ("out", _fp),
                 ("osb", _i64), ("os_hi", _i64), ("os_lo", _i64), ("os_t", _i64),
-                ("B", _i32), ("T", _i32), ("N", _i32), ("r", _i32), ("eps", _f32), ("pad_", _i32)]
+                ("B", _i32), ("T", _i32), ("N", _i32), ("r", _i32), ("eps", _f32), ("blk", _i32)]
 
 
 class LstmDesc(C.Structure):

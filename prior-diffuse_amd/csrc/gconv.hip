@@ -167,6 +167,7 @@ int pdse_gconv_launch(const pdse_gconv_desc* d, hipStream_t s) {
     else PDSE_REQUIRE(d->ksteps >= d->ntaps * (Cin / 2), "ksteps < ntaps*Cin/2");
     PDSE_REQUIRE(d->korder < 3 || d->epi != PDSE_EPI_BIGLU, "korder 3 has LINEAR / GLU epilogues only");
   }
+  PDSE_REQUIRE((d->in0.blk == 0 && d->in1.blk == 0) || d->korder == 3, "channel-blocked sources (pdse_src.blk) are read by the korder 3 kernel only");
   if (d->xf_mode) {
     PDSE_REQUIRE(d->xf_scale0 && d->xf_shift0, "xf_mode set without scale/shift");
     PDSE_REQUIRE(d->xf_mode != 2 || (d->xf_scale1 && d->xf_shift1), "xf_mode 2 without second set");

@@ -24,7 +24,13 @@
 
 #include "gconv_common.h"
 
-#define G4_CH 4   // 16-channel K blocks per LDS chunk
+// 16-channel K blocks per LDS chunk.  The ring (2 buffers x G4_CH x fragments x 3 KB) decides how many workgroups share
+// a CU: with 4 blocks the four-fragment launches (GLU with two channel tiles, LINEAR with four) need 96 KB, i.e. ONE
+// workgroup = 8 waves per CU although their registers allow two; 3 blocks = 72 KB lets two workgroups cover each
+// other's chunk barriers and epilogues.
+#ifndef G4_CH
+#define G4_CH 3
+#endif
 
 __device__ __forceinline__ void glds16_g4(const void* g, void* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l,
@@ -41,13 +47,41 @@ __device__ __forceinline__ float g4_load(const float* sbase, const unsigned byte
   asm volatile("global_load_dword %0, %1, %2" : "=v"(v) : "v"(byte_off), "s"(sbase) : "memory");
   return v;
 }
+// channel-blocked sources (pdse_src.blk = 8): the lane's eight channels of a K block are 32 contiguous bytes
+typedef float g4_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ g4_f32x4 g4_load16(const float* sbase, const unsigned byte_off) {
+  g4_f32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(byte_off), "s"(sbase) : "memory");
+  return v;
+}
+// The gathered values of one chunk.  A load written as inline asm returns before its data: between the request and the
+// chunk barrier NOTHING may touch the destination registers - not even a copy - so every load writes the registers the
+// values are read from later: scalars for plain sources, whole 16-byte vectors for channel-blocked ones (extracting the
+// elements of a vector right behind its load made hipcc copy them at once, i.e. before they had landed, and re-use the
+// vector's registers while the load was still in flight).
+template <bool BLK>
+struct g4_raw {
+  float v[G4_CH][8];
+  __device__ __forceinline__ float get(const int i, const int e) const { return v[i][e]; }
+};
+template <>
+struct g4_raw<true> {
+  g4_f32x4 v[G4_CH][2];
+  __device__ __forceinline__ float get(const int i, const int e) const { return v[i][e >> 2][e & 3]; }
+};
 // no instruction: pins the point after which the values may be read (register-only uses could otherwise be scheduled above
 // the barrier that makes them valid)
-__device__ __forceinline__ void g4_landed(float (&raw)[G4_CH][8]) {
+__device__ __forceinline__ void g4_landed(g4_raw<false>& raw) {
 #pragma unroll
   for (int i = 0; i < G4_CH; ++i)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(raw[i][e]));
+    for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(raw.v[i][e]));
+}
+__device__ __forceinline__ void g4_landed(g4_raw<true>& raw) {
+#pragma unroll
+  for (int i = 0; i < G4_CH; ++i)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) asm volatile("" : "+v"(raw.v[i][e]));
 }
 
 // A fragments are read from the ring with ds_read_b128 written as inline asm too: the compiler cannot tell the ring
@@ -87,7 +121,8 @@ struct g4_chunk {
 
 __device__ long long* g_trace4 = nullptr;   // PDSE_G4_TRACE=1 (diagnostic): [workgroup][wave][8] clock sums
 
-template <int EPI, int MT>
+// BLK: every source is channel-blocked (pdse_src.blk = 8) / none is
+template <int EPI, int MT, bool BLK>
 __global__ __launch_bounds__(512, 2) void gconv4_kernel(const pdse_gconv_desc d) {
 #ifdef PDSE_DIAG
   long long* const trace = g_trace4;
@@ -143,7 +178,7 @@ __global__ __launch_bounds__(512, 2) void gconv4_kernel(const pdse_gconv_desc d)
     }
   };
   // B operand of a chunk: raw[i][e] = channel 16 (cb0 + i) + 8h + e of this lane's position at the chunk's tap
-  auto gather = [&](const g4_chunk& c, float (&raw)[G4_CH][8], bool& inb) {
+  auto gather = [&](const g4_chunk& c, g4_raw<BLK>& raw, bool& inb) {
     const bool s1 = c.s != 0;   // field-by-field scalar selects (a reference to one of two kernel-argument structs is not)
     const float* const sptr = s1 ? d.in1.ptr : d.in0.ptr;
     const int64_t ssb = s1 ? d.in1.sb : d.in0.sb, ssc = s1 ? d.in1.sc : d.in0.sc, sst = s1 ? d.in1.st : d.in0.st,
@@ -156,14 +191,26 @@ __global__ __launch_bounds__(512, 2) void gconv4_kernel(const pdse_gconv_desc d)
     }
     const int tin = t + dt, fin = j * d.sf_in + df;
     inb = pvalid && fin >= 0 && fin < d.Fin && tin >= 0 && tin < d.Tin;
+    if constexpr (BLK) {   // [B][C/8][T][F][8]: block 2 (cb0 + i) + h, two 16-byte loads per K block
+      const unsigned off = 4u * (unsigned)((inb ? (int64_t)b * ssb + (int64_t)tin * sst + (int64_t)fin * ssf : 0) + (int64_t)h * ssc);
+#pragma unroll
+      for (int i = 0; i < G4_CH; ++i) {
+        if (i < c.n) {
+          const float* base = sptr + (int64_t)(2 * (c.cb0 + i)) * ssc;
+          raw.v[i][0] = g4_load16(base, off);
+          raw.v[i][1] = g4_load16(base + 4, off);
+        }
+      }
+    } else {
     const unsigned off = 4u * (unsigned)((inb ? (int64_t)b * ssb + (int64_t)tin * sst + (int64_t)fin * ssf : 0) + (int64_t)(8 * h) * ssc);
 #pragma unroll
     for (int i = 0; i < G4_CH; ++i) {
       if (i < c.n) {   // wave-uniform
         const float* base = sptr + (int64_t)(16 * (c.cb0 + i)) * ssc;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) raw[i][e] = g4_load(base + (int64_t)e * ssc, off);
+        for (int e = 0; e < 8; ++e) raw.v[i][e] = g4_load(base + (int64_t)e * ssc, off);
       }
+    }
     }
   };
 
@@ -176,14 +223,14 @@ __global__ __launch_bounds__(512, 2) void gconv4_kernel(const pdse_gconv_desc d)
       if (DUAL) acc1[m][r] = 0.f;
     }
   }
-  auto compute = [&](const g4_chunk& c, const float (&raw)[G4_CH][8], const bool inb, const int buf) {
+  auto compute = [&](const g4_chunk& c, const g4_raw<BLK>& raw, const bool inb, const int buf) {
     const bool elu = uni((c.s ? d.in1.act : d.in0.act) == PDSE_ACT_ELU) != 0;   // GCRN re-applies ELU to the skip half (gcrn.py:152-155)
 #pragma unroll
     for (int i = 0; i < G4_CH; ++i) {
       if (i < c.n) {
         float x[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] = inb ? raw[i][e] : 0.f;
+        for (int e = 0; e < 8; ++e) x[e] = inb ? raw.get(i, e) : 0.f;
         if (elu) {   // wave-uniform; exp2-based like the epilogues' ELU (act_c); elu(0) = 0 keeps masked lanes zero
 #pragma unroll
           for (int e = 0; e < 8; ++e) x[e] = x[e] < 0.f ? fast_exp(x[e]) - 1.0f : x[e];
@@ -205,7 +252,7 @@ __global__ __launch_bounds__(512, 2) void gconv4_kernel(const pdse_gconv_desc d)
     }
   };
 
-  float rawA[G4_CH][8], rawB[G4_CH][8];
+  g4_raw<BLK> rawA, rawB;
   bool inbA = false, inbB = false;
   g4_chunk cA = decode(0), cB = cA;
   gather(cA, rawA, inbA);
@@ -257,14 +304,14 @@ __global__ __launch_bounds__(512, 2) void gconv4_kernel(const pdse_gconv_desc d)
   }
 }
 
-template <int EPI, int MT>
-static int launch4(const pdse_gconv_desc* d, hipStream_t s, const int mtiles) {
+template <int EPI, int MT, bool BLK>
+static int launch4b(const pdse_gconv_desc* d, hipStream_t s, const int mtiles) {
   const int P = d->Tout * d->Fout;
   const dim3 grid(((P + 31) / 32 + 7) / 8, d->B, (mtiles + MT - 1) / MT), block(512);
   constexpr int FR = (EPI == PDSE_EPI_LINEAR ? 1 : 2) * MT;
   const size_t lds = (size_t)2 * G4_CH * FR * 192 * sizeof(uint4);
   static unsigned long long attr_mask = 0;   // per instantiation and device
-  if (lds > 64 * 1024 && pdse_lds_attr((const void*)gconv4_kernel<EPI, MT>, &attr_mask, "gconv4 lds attribute")) return 1;
+  if (lds > 64 * 1024 && pdse_lds_attr((const void*)gconv4_kernel<EPI, MT, BLK>, &attr_mask, "gconv4 lds attribute")) return 1;
   static const bool tracing = PDSE_DIAG_ENV("PDSE_G4_TRACE") != nullptr;
   static long long* tbuf = nullptr;
   const size_t nw = (size_t)grid.x * grid.y * grid.z * 8;
@@ -275,7 +322,7 @@ static int launch4(const pdse_gconv_desc* d, hipStream_t s, const int mtiles) {
     }
     (void)hipMemsetAsync(tbuf, 0, nw * 64, s);
   }
-  hipLaunchKernelGGL((gconv4_kernel<EPI, MT>), grid, block, lds, s, *d);
+  hipLaunchKernelGGL((gconv4_kernel<EPI, MT, BLK>), grid, block, lds, s, *d);
   if (tracing && nw * 64 <= ((size_t)1 << 24)) {   // diagnostic: per-wave averages in shader clocks
     (void)hipStreamSynchronize(s);
     long long* h = (long long*)malloc(nw * 64);
@@ -291,11 +338,24 @@ static int launch4(const pdse_gconv_desc* d, hipStream_t s, const int mtiles) {
   return pdse_check_launch("gconv4");
 }
 
+template <int EPI, int MT>
+static int launch4(const pdse_gconv_desc* d, hipStream_t s, const int mtiles) {
+  return d->in0.blk ? launch4b<EPI, MT, true>(d, s, mtiles) : launch4b<EPI, MT, false>(d, s, mtiles);
+}
+
 // korder 3: LINEAR / GLU, one or two sources of a multiple of 16 channels, no load transform; validated by pdse_gconv_launch
 int pdse_gconv4_launch(const pdse_gconv_desc* d, hipStream_t s) {
   const bool two = d->in1.C > 0;
   // lane offsets are 32-bit BYTE offsets from a scalar channel base
   const long long span0 = 4 * ((long long)d->B * d->in0.sb + 40ll * d->in0.sc), span1 = two ? 4 * ((long long)d->B * d->in1.sb + 40ll * d->in1.sc) : 0;
+  auto blk_ok = [](const pdse_src& x) {   // 16-byte loads: every stride a multiple of 4 floats, the base 16-byte aligned
+    return x.blk == 0 || (x.blk == 8 && !((x.sb | x.sc | x.st | x.sf) & 3) && (reinterpret_cast<uintptr_t>(x.ptr) & 15) == 0);
+  };
+  if (!blk_ok(d->in0) || (two && !blk_ok(d->in1)) || (two && d->in0.blk != d->in1.blk)) {
+    pdse_set_error("gconv4: a channel-blocked source has blk = 8, strides in multiples of 4 floats and a 16-byte aligned base; "
+                   "two sources are both blocked or both plain");
+    return 1;
+  }
   if (!(d->epi == PDSE_EPI_LINEAR || d->epi == PDSE_EPI_GLU) || (d->in0.C & 15) || (d->in1.C & 15) || d->in0.C == 0 || d->cin1 ||
       d->xf_mode != 0 || d->padrow != nullptr || d->ntaps > 12 || span0 >= (1ll << 32) || span1 >= (1ll << 32) ||
       (d->epi == PDSE_EPI_GLU && !d->w1)) {

@@ -225,6 +225,10 @@ __device__ __forceinline__ void gconv_epilogue_impl(const pdse_gconv_desc& d, co
     // constant block, and a full channel tile stores without per-element guards.  The straightforward form
     // (`switch (d.act)`, `if (bias)`, `if (co < Cout)` per element) compiled to ~20 branches per output element.
     const float* rbase = d.resid ? d.resid + (obase - d.out) : nullptr;
+    // 16-byte stores need every stride in multiples of 4 floats and an aligned base (else: the element-wise path below)
+    const bool blocked8 = !CR1 && d.out_cr == 8 && d.out_sc_lo == 1 &&
+                          !((d.out_sb | d.out_sc_hi | d.out_st | d.out_sf | d.out_off | extra_off) & 3) &&
+                          (reinterpret_cast<uintptr_t>(d.out) & 15) == 0;
     auto tiles = [&](auto act_tag, auto res_tag) {
       constexpr int ACT = decltype(act_tag)::value;
       constexpr bool RES = decltype(res_tag)::value;
@@ -242,7 +246,29 @@ __device__ __forceinline__ void gconv_epilogue_impl(const pdse_gconv_desc& d, co
           y = y * ps[PDSE_KR(r)] + pt[PDSE_KR(r)];
           return act_c<ACT>(y, d.act_slope);
         };
-        if (32 * (mt0 + m) + 32 <= d.Cout && CR1) {   // full tile, plain channel stride: one predicated region
+        if (!CR1 && !RES && blocked8 && 32 * (mt0 + m) + 32 <= d.Cout) {
+          // channel-blocked output [B][C/8][T][F][8] (out_cr = 8, out_sc_lo = 1; what pdse_src.blk = 8 reads): a lane's rows
+          // 4q..4q+3 are channels 8 (4 tile + q) + 4h..+3 = 16 contiguous bytes of block 4 tile + q
+          if (pvalid) {
+            float* po = obase + (int64_t)(4 * (mt0 + m)) * cstep + 4 * h;
+            f32x16 y = acc0[m];
+            if (d.bias0) y += ld16(pb0);
+            if constexpr (EPI == PDSE_EPI_GLU) {
+              f32x16 g = acc1[m];
+              if (d.bias1) g += ld16(pb1);
+#pragma unroll
+              for (int r = 0; r < 16; ++r) y[r] *= sigmoid_f(g[r]);
+            }
+            if (d.post_scale) y = y * ld16(ps) + ld16(pt);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              f32x4 v4;
+#pragma unroll
+              for (int i = 0; i < 4; ++i) v4[i] = act_c<ACT>(y[4 * q + i], d.act_slope);
+              *reinterpret_cast<f32x4*>(po + (int64_t)q * cstep) = v4;
+            }
+          }
+        } else if (32 * (mt0 + m) + 32 <= d.Cout && CR1) {   // full tile, plain channel stride: one predicated region
           if (pvalid) {
             float* po = obase + (int64_t)c0 * cstep;
             const float* pr = RES ? rbase + (int64_t)c0 * cstep : nullptr;

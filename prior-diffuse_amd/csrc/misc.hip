@@ -343,7 +343,8 @@ __global__ __launch_bounds__(256) void ln_kernel(const pdse_ln_desc d) {
     const int i = k * 64 + lane;
     if (i < d.N) {
       const float y = (v[k] - mean) * rstd * d.gamma[i] + d.beta[i];
-      d.out[ob + (int64_t)(i / d.r) * d.os_hi + (int64_t)(i % d.r) * d.os_lo] = y;
+      const int c = i / d.r;
+      d.out[ob + (d.blk ? (int64_t)(c >> 3) * d.os_hi + (c & 7) : (int64_t)c * d.os_hi) + (int64_t)(i % d.r) * d.os_lo] = y;
     }
   }
 }
@@ -351,6 +352,7 @@ __global__ __launch_bounds__(256) void ln_kernel(const pdse_ln_desc d) {
 int pdse_ln_launch(const pdse_ln_desc* d, hipStream_t s) {
   REQ(d && d->in && d->gamma && d->beta && d->out, "layernorm: null pointer");
   REQ(d->B > 0 && d->T > 0 && d->N > 0 && d->N <= 1024 && d->r > 0, "layernorm: bad sizes (N <= 1024)");
+  REQ(d->blk == 0 || d->blk == 8, "layernorm: blk is 0 or 8");
   const int64_t rows = (int64_t)d->B * d->T;
   hipLaunchKernelGGL(ln_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, *d);
   return pdse_check_launch("layernorm");

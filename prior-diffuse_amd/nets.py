@@ -130,8 +130,8 @@ class PlanBase:
             self.plan.keep(self.ctx.keep, self.ctx.bank)
 
     # ---- descriptor helpers -------------------------------------------------
-    def src(self, t, C_, sb, sc, st, sf, off=0, act=L.ACT_NONE):
-        return L.Src(Ctx.ptr(t, off), sb, sc, st, sf, C_, act)
+    def src(self, t, C_, sb, sc, st, sf, off=0, act=L.ACT_NONE, blk=0):
+        return L.Src(Ctx.ptr(t, off), sb, sc, st, sf, C_, act, blk, 0)
 
     def _gconv_weights_s3(self, w, ntaps, cin=32):
         """korder 2 (csrc/gconv3.hip): exact three-way bf16 splits of a BIGLU block's weights, MFMA bf16 fragment order.
@@ -323,6 +323,16 @@ def nchw(C_, T, F):
 def nchw_out(C_, T, F):
     """(out_sb, out_sc_hi, out_sc_lo, out_st, out_sf) of a contiguous [B, C, T, F] output."""
     return C_ * T * F, T * F, 0, F, 1
+
+
+def nc8(C_, T, F):
+    """(sb, sc, st, sf) of a channel-blocked [B, C/8, T, F, 8] tensor (pdse_src.blk = 8: sc is the stride of a block)."""
+    return C_ * T * F, T * F * 8, F * 8, 8
+
+
+def nc8_out(C_, T, F):
+    """(out_sb, out_sc_hi, out_sc_lo, out_st, out_sf) of the same tensor as an output (out_cr = 8)."""
+    return C_ * T * F, T * F * 8, 1, F * 8, 8
 
 
 # ==========================================================================
@@ -1098,13 +1108,14 @@ class GcrnPlan(PlanBase):
     fused_last = True       # last decoder stage + Linear(161,161) as one persistent launch (pdse_gcrnlast_desc)
     fused_glstm = True      # both LSTM layers + LayerNorm 1 as a layer wavefront, T + 2 launches (pdse_glstm_desc)
     split_bf16 = True       # gated (transposed) convolutions and the LSTM input projection as split-bf16 GEMMs (csrc/gconv4.hip)
+    block8 = True           # tensors between those GEMMs in blocks of 8 channels (16-byte gathers and stores)
     ENC_C = [2, 16, 32, 64, 128, 256]
     ENC_F = [161, 80, 39, 19, 9, 4]
 
     def __init__(self, ctx, sd, B, T, plan=None, split_bf16=None):
         if split_bf16 is not None:
             self.split_bf16 = bool(split_bf16)
-        super().__init__(ctx, plan, ns=(ctx.bank.token(sd), self.fused_last, self.fused_glstm, self.split_bf16))
+        super().__init__(ctx, plan, ns=(ctx.bank.token(sd), self.fused_last, self.fused_glstm, self.split_bf16, self.block8))
         self.sd, self.B, self.T = sd, B, T
         a = ctx.alloc
         self.Bp = Bp = (B + 31) // 32 * 32
@@ -1125,6 +1136,20 @@ class GcrnPlan(PlanBase):
 
     def w(self, k):
         return P._np(self.sd[k])
+
+    def _nchw(self, t, blocked):
+        if blocked and self.split_bf16 and not self.force_generic and self.block8:
+            B, C_, T, F = t.shape
+            return t.view(B, C_ // 8, T, F, 8).permute(0, 1, 4, 2, 3).reshape(B, C_, T, F)
+        return t
+
+    def enc_out(self, k):
+        """Encoder stage k's output (k = 1..5) as [B, C, T, F], whatever layout the plan keeps it in (build())."""
+        return self._nchw(self.e[k - 1], k >= 2)
+
+    def glstm_out(self):
+        """The grouped LSTM's output after LayerNorm 2 as [B, 256, T, 4]."""
+        return self._nchw(self.glstm, True)
 
     def _lstm_layer(self, layer, xproj_src_fn, y_su, y_sg):
         B, T, Bp = self.B, self.T, self.Bp
@@ -1192,8 +1217,9 @@ class GcrnPlan(PlanBase):
         d.B, d.Bp, d.T, d.H, d.G, d.eps = B, Bp, T, 512, 2, 1e-5
         self.add(d, TAG_LSTM)
 
-    def _ln(self, name, out_t, osb, os_hi, os_lo, os_t, r):
+    def _ln(self, name, out_t, osb, os_hi, os_lo, os_t, r, blk=0):
         d = L.LnDesc()
+        d.blk = blk
         d.in_, d.out = self.y.data_ptr(), out_t.data_ptr()
         d.gamma = self.upw(name + ".g", lambda: self.w(name + ".weight")).data_ptr()
         d.beta = self.upw(name + ".b", lambda: self.w(name + ".bias")).data_ptr()
@@ -1206,25 +1232,38 @@ class GcrnPlan(PlanBase):
         x = self.x if x is None else x
         out = self.out if out is None else out
         # encoder: GluConv2d k(1,3) s(1,2) + BN + ELU (gcrn.py:138-142)
+        # Tensors that only the split-bf16 GEMM kernel reads (e2..e5, the decoders' d5..d3) live in blocks of 8 channels,
+        # [B][C/8][T][F][8] (pdse_src.blk): its gather was bound by the texture addresser - eight 4-byte loads per lane and
+        # K block, 38 memory instructions per wave and chunk at ~12 cycles each - and is two 16-byte loads per K block now.
+        # e1 and d2 are also read by gcrnlast_kernel and stay [B][C][T][F].
+        blk = self.split_bf16 and not self.force_generic and self.block8
+
+        def lay(k_is_blocked, C_, Fq):
+            if k_is_blocked:
+                return nc8(C_, T, Fq), nc8_out(C_, T, Fq), 8
+            return nchw(C_, T, Fq), nchw_out(C_, T, Fq), 1
+
         src = self.src(x, 2, *nchw(2, T, F0))
+        e_lay = [lay(blk and k >= 2, self.ENC_C[k], self.ENC_F[k]) for k in range(1, 6)]
         for k in range(1, 6):
             ci, co, Fin, Fout = self.ENC_C[k - 1], self.ENC_C[k], self.ENC_F[k - 1], self.ENC_F[k]
             kk, taps = P.conv_taps(1, 3, 0)
             p = "conv%d" % k
+            ist, ost_, ocr = e_lay[k - 1]
             self.gconv(in0=src, Tin=T, Fin=Fin, taps=taps, sf_in=2, Cout=co, epi=L.EPI_GLU, act=L.ACT_ELU,
                        W=lambda p=p, k=k, kk=kk: dict(wk0=P.conv_kmat(self.sd[p + ".conv1.weight"], kk),
                                                       wk1=P.conv_kmat(self.sd[p + ".conv2.weight"], kk),
                                                       bias0=self.w(p + ".conv1.bias"), bias1=self.w(p + ".conv2.bias"),
                                                       post=P.bn_fold(self.sd, "bn%d" % k)),
-                       out=self.e[k - 1], out_strides=nchw_out(co, T, Fout), B=B, Tout=T, Fout=Fout, tag=TAG_PRIOR, label=p,
+                       out=self.e[k - 1], out_strides=ost_, out_cr=ocr, B=B, Tout=T, Fout=Fout, tag=TAG_PRIOR, label=p,
                        s3g=self.split_bf16)
-            src = self.src(self.e[k - 1], co, *nchw(co, T, Fout))
+            src = self.src(self.e[k - 1], co, *ist, blk=8 if ocr == 8 else 0)
 
         # grouped LSTM (gcrn.py:22-40)
         def proj1(g):
             # group g = channels 128g..128g+127 of e5 [B,256,T,4]; k = f*128 + c'  <->  W_ih column c'*4 + f
             wk = lambda Wih: np.concatenate([Wih[:, f::4].T for f in range(4)], axis=0)   # noqa: E731
-            s = self.src(self.e[4], 128, *nchw(256, T, 4), off=128 * g * T * 4)
+            s = self.src(self.e[4], 128, *e_lay[4][0], off=128 * g * T * 4, blk=8 if blk else 0)   # (same offset in both layouts)
             return s, T, 4, [(0, f) for f in range(4)], wk, T, 1, 2048 * Bp, 0
 
         if self.fused_glstm and not self.force_generic:
@@ -1238,13 +1277,16 @@ class GcrnPlan(PlanBase):
                 return s, 1, T, [(0, 0)], (lambda Wih: Wih.T), 1, T, 0, 2048 * Bp
 
             self._lstm_layer("lstm_list2", proj2, y_su=1, y_sg=512)          # cat: index g*512+u
-        self._ln("glstm.ln2", self.glstm, 256 * T * 4, T * 4, 1, 4, 4)       # j = c*4+f -> [B,256,T,4]
+        if blk:
+            self._ln("glstm.ln2", self.glstm, 256 * T * 4, T * 4 * 8, 8, 4 * 8, 4, blk=8)   # j = c*4+f -> [B,32,T,4,8]
+        else:
+            self._ln("glstm.ln2", self.glstm, 256 * T * 4, T * 4, 1, 4, 4)   # j = c*4+f -> [B,256,T,4]
 
         # two decoders (gcrn.py:150-164)
         dec = [(5, 512, 128), (4, 256, 64), (3, 128, 32), (2, 64, 16), (1, 32, 1)]
         for br in (1, 2):
-            in0 = self.src(self.glstm, 256, *nchw(256, T, 4))
-            in1 = self.src(self.e[4], 256, *nchw(256, T, 4))
+            in0 = self.src(self.glstm, 256, *(nc8(256, T, 4) if blk else nchw(256, T, 4)), blk=8 if blk else 0)
+            in1 = self.src(self.e[4], 256, *e_lay[4][0], blk=8 if blk else 0)
             Fin = 4
             for n, (k, ci, co) in enumerate(dec):
                 p = "conv%d_t_%d" % (k, br)
@@ -1268,7 +1310,8 @@ class GcrnPlan(PlanBase):
                     g.B, g.T = B, T
                     self.add(g, TAG_PRIOR)
                     break
-                osb, osc, _, ost, osf = nchw_out(co, T, Fout)
+                dblk = blk and k >= 3          # d5, d4, d3 (read by the next decoder stage only)
+                ist, (osb, osc, olo, ost, osf), ocr = lay(dblk, co, Fout)
                 for phase in (0, 1):
                     kk, taps = P.convT_phase_taps(1, 3, phase)
                     self.gconv(in0=in0, in1=in1, Tin=T, Fin=Fin, taps=taps, sf_in=1, Cout=co, epi=L.EPI_GLU, act=L.ACT_ELU,
@@ -1276,13 +1319,15 @@ class GcrnPlan(PlanBase):
                                    wk0=P.convT_kmat(self.sd[p + ".conv1.weight"], kk),
                                    wk1=P.convT_kmat(self.sd[p + ".conv2.weight"], kk), bias0=self.w(p + ".conv1.bias"),
                                    bias1=self.w(p + ".conv2.bias"), post=P.bn_fold(self.sd, "bn%d_t_%d" % (k, br))),
-                               out=self.d[n], out_strides=(osb, osc, 0, ost, 2 * osf), out_off=phase, B=B, Tout=T,
-                               Fout=(Fout - phase + 1) // 2, tag=TAG_PRIOR, label="%s.ph%d" % (p, phase), s3g=self.split_bf16)
+                               out=self.d[n], out_strides=(osb, osc, olo, ost, 2 * osf), out_off=phase * osf, out_cr=ocr, B=B,
+                               Tout=T, Fout=(Fout - phase + 1) // 2, tag=TAG_PRIOR, label="%s.ph%d" % (p, phase),
+                               s3g=self.split_bf16)
                 Fin = Fout
                 if k > 1:
-                    in0 = self.src(self.d[n], co, *nchw(co, T, Fout))
+                    in0 = self.src(self.d[n], co, *ist, blk=8 if dblk else 0)
                     skip = self.e[k - 2]
-                    in1 = self.src(skip, co, *nchw(co, T, Fout), act=L.ACT_ELU)   # elu(cat(.., skip)) re-applies ELU
+                    sblk = e_lay[k - 2][2] == 8
+                    in1 = self.src(skip, co, *e_lay[k - 2][0], act=L.ACT_ELU, blk=8 if sblk else 0)   # elu(cat(.., skip)) re-applies ELU
             else:   # (no break: the unfused form) Linear(161,161) over the bins (gcrn.py:162-163): taps enumerate the input bin
                 self.gconv(in0=self.src(self.d[4], 1, *nchw(1, T, F0)), Tin=T, Fin=F0, taps=[(0, f) for f in range(F0)],
                            sf_in=1, W=lambda br=br: dict(wk0=self.w("fc%d.weight" % br).T, bias0=self.w("fc%d.bias" % br)),

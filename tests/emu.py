@@ -143,7 +143,11 @@ def run_gconv(d, mem):
         for S, cbase in srcs:
             flat, off = mem.view(S.ptr)
             cI = np.arange(S.C)[None, :, None, None]
-            idx = off + bI * S.sb + cI * S.sc + tin * S.st + fin * S.sf
+            if S.blk:   # channel-blocked source (pdse_src.blk = 8, korder 3 only)
+                assert S.blk == 8 and d.korder == 3, "blocked sources are read by the korder 3 kernel only"
+                idx = off + bI * S.sb + (cI >> 3) * S.sc + (cI & 7) + tin * S.st + fin * S.sf
+            else:
+                idx = off + bI * S.sb + cI * S.sc + tin * S.st + fin * S.sf
             idx = np.where(inb, idx, 0)
             v = flat[np.broadcast_to(idx, (B, S.C, To, Fo))]
             v = _act(v, S.act)
@@ -360,7 +364,9 @@ def run_ln(d, mem):
     b = np.arange(d.B)[:, None, None]
     t = np.arange(d.T)[None, :, None]
     j = np.arange(d.N)[None, None, :]
-    flat[off + b * d.osb + (j // d.r) * d.os_hi + (j % d.r) * d.os_lo + t * d.os_t] = y
+    c = j // d.r
+    cpos = (c >> 3) * d.os_hi + (c & 7) if d.blk else c * d.os_hi          # blk 8: channels in blocks of 8 (pdse_src.blk)
+    flat[off + b * d.osb + cpos + (j % d.r) * d.os_lo + t * d.os_t] = y
 
 
 def run_lstm(d, mem):

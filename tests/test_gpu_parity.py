@@ -165,8 +165,8 @@ def test_gcrn_golden(L, weights):
     out = op(seeded((2, 2, 20, 161), g["seed_x"]).to(DEV))
     net = op._plans[(2, 20)]
     _sync()
-    assert rel_l2(net.e[4].cpu(), g["e5"]) < 2e-5
-    assert rel_l2(net.glstm.cpu(), g["glstm"]) < 2e-5
+    assert rel_l2(net.enc_out(5).cpu(), g["e5"]) < 2e-5
+    assert rel_l2(net.glstm_out().cpu(), g["glstm"]) < 2e-5
     assert rel_l2(out.cpu(), g["out"]) < 2e-5
     g = golden("gcrn_t401")
     out = op(seeded((1, 2, 401, 161), g["seed_x"]).to(DEV)).cpu()

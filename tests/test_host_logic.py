@@ -92,8 +92,8 @@ def test_gcrn_and_diffunet_prior_plans_vs_oracle(weights, fused_glstm, split, mo
     taps = {}
     with torch.no_grad():
         ref = R.gcrn_forward(weights("GCRN"), x, taps=taps)
-    assert rel_l2(net.e[4], taps["e5"]) < TOL
-    assert rel_l2(net.glstm, taps["glstm"]) < TOL
+    assert rel_l2(net.enc_out(5), taps["e5"]) < TOL
+    assert rel_l2(net.glstm_out(), taps["glstm"]) < TOL
     assert rel_l2(net.out, ref) < TOL
     ctx2 = nets.Ctx("cpu")
     p = nets.EpsNetPlan(ctx2, weights("DiffUNet"), B, T, time_cond=False)
