@@ -594,6 +594,10 @@ typedef struct pdse_bglu_desc {
   int32_t nx_Tp, nx_Fp, nx_t0, nx_f0;
   int32_t nx_row0;         /* 1: lanes of output frame 0 also write the tile's bias to frame -1 (encoder pad frame) */
   int32_t nx_pad_;
+  /* The fp32 skip halves (nx_add read by the decoders, nx_out written by the encoder) are kept in groups of four channels,
+     [B (+1)][8 groups][T][F][4]: channel c of (b, t, bin) lives at b*sb + (c >> 2)*sc + (c & 3) + t*st + bin*sf (every
+     stride a multiple of 4 floats, the base 16-byte aligned), so a lane moves its accumulator rows as four 16-byte
+     accesses (ABI 5; until then [B][32][T][F] with sixteen 4-byte accesses). */
   const float* nx_add;     /* fp32 addend at (b, c, t, bin) or NULL (decoders: the encoder's skip half) */
   int64_t add_sb, add_sc, add_st, add_sf;
   /* chained tiles 1, 2 (encoder: the decoders' skip halves): fp32 */

@@ -325,11 +325,16 @@ __global__ __launch_bounds__(PIPE ? 256 : 512, PIPE ? 1 : 2) void bglu_kernel(co
   };
   const __amdgpu_buffer_rsrc_t r_sk0 = make_rsrc(NXN > 1 ? d.nx_out[0] : nullptr, NXN > 1 ? (uint32_t)((d.B + 1) * d.nx_sb[0] * 4) : 0u);
   const __amdgpu_buffer_rsrc_t r_sk1 = make_rsrc(NXN > 2 ? d.nx_out[1] : nullptr, NXN > 2 ? (uint32_t)((d.B + 1) * d.nx_sb[1] * 4) : 0u);
-  auto store_skip = [&](const f32x16& z, const int i, const pos_t& ps) {   // fp32 [B + 1 (dump item), 32, T, F]
+  // fp32 skip halves in groups of four channels, [B + 1 (dump item)][8 groups][T][F][4]: accumulator rows 4q..4q+3 of lane
+  // half h are channels 8q + 4h..+3 = group 2q + h, 16 contiguous bytes - four 16-byte stores per tile where
+  // [B][32][T][F] took sixteen 4-byte ones (a 4-byte and a 16-byte wave access cost the addresser about the same)
+  auto store_skip = [&](const f32x16& z, const int i, const pos_t& ps) {
     const uint32_t o = (uint32_t)(((int64_t)(ps.valid ? b : d.B) * d.nx_sb[i] + (ps.valid ? (int64_t)ps.t * d.nx_st[i] + (int64_t)ps.j * d.nx_sf[i] : 0) +
-                                   (int64_t)(4 * h) * d.nx_sc[i]) << 2);
+                                   (int64_t)h * d.nx_sc[i]) << 2);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) bstore4(z[r], i == 0 ? r_sk0 : r_sk1, o, (int)((PDSE_KR(r) * d.nx_sc[i]) << 2));
+    for (int q = 0; q < 4; ++q)
+      bstore16(make_uint4(__float_as_uint(z[4 * q]), __float_as_uint(z[4 * q + 1]), __float_as_uint(z[4 * q + 2]), __float_as_uint(z[4 * q + 3])),
+               i == 0 ? r_sk0 : r_sk1, o, (int)((2 * q * d.nx_sc[i]) << 2));
   };
   auto stores_masked = [&](const pos_t& ps, const auto& o0, const auto& o1) {
     if (!ps.valid) return;
@@ -377,9 +382,12 @@ __global__ __launch_bounds__(PIPE ? 256 : 512, PIPE ? 1 : 2) void bglu_kernel(co
   auto zseed = [&](const pos_t& ps, const int ph, f32x16& z) {
     const bool two = ph == 0 || ps.j < d.Fout1;
     const int bin = 2 * ps.j + (two ? ph : 0);
-    const uint32_t o = (uint32_t)(((int64_t)b * d.add_sb + (int64_t)ps.t * d.add_st + (int64_t)bin * d.add_sf + (int64_t)(4 * h) * d.add_sc) << 2);
+    const uint32_t o = (uint32_t)(((int64_t)b * d.add_sb + (int64_t)ps.t * d.add_st + (int64_t)bin * d.add_sf + (int64_t)h * d.add_sc) << 2);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) z[r] = bload4(r_add, o, (int)((PDSE_KR(r) * d.add_sc) << 2));
+    for (int q = 0; q < 4; ++q) {   // groups of four channels (store_skip's layout): four 16-byte loads
+      const uint4 v = bload16(r_add, o, (int)((2 * q * d.add_sc) << 2));
+      z[4 * q] = __uint_as_float(v.x), z[4 * q + 1] = __uint_as_float(v.y), z[4 * q + 2] = __uint_as_float(v.z), z[4 * q + 3] = __uint_as_float(v.w);
+    }
   };
 
 #define FRAG(buf, ptr)                                         \
@@ -817,11 +825,23 @@ int pdse_bglu_launch(const pdse_bglu_desc* d, hipStream_t s) {
       pdse_set_error("bglu: addend exceeds 32-bit lane offsets");
       return 1;
     }
-    for (int i = 0; i + 1 < d->nx_n; ++i)
+    auto c4_ok = [](const void* p, const int64_t sb, const int64_t sc, const int64_t st, const int64_t sf) {
+      return ((sb | sc | st | sf) & 3) == 0 && (reinterpret_cast<uintptr_t>(p) & 15) == 0;
+    };
+    if (d->nx_add && !c4_ok(d->nx_add, d->add_sb, d->add_sc, d->add_st, d->add_sf)) {
+      pdse_set_error("bglu: the addend is kept in groups of four channels: strides in multiples of 4 floats, 16-byte aligned base");
+      return 1;
+    }
+    for (int i = 0; i + 1 < d->nx_n; ++i) {
       if ((long long)(d->B + 1) * d->nx_sb[i] * 4 >= (1ll << 32)) {
         pdse_set_error("bglu: skip tensor exceeds 32-bit lane offsets");
         return 1;
       }
+      if (!c4_ok(d->nx_out[i], d->nx_sb[i], d->nx_sc[i], d->nx_st[i], d->nx_sf[i])) {
+        pdse_set_error("bglu: skip tensors are kept in groups of four channels: strides in multiples of 4 floats, 16-byte aligned base");
+        return 1;
+      }
+    }
   }
   return d->np == 3 ? dispatch<3>(d, s) : dispatch<1>(d, s);
 }

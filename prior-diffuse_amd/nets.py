@@ -356,7 +356,7 @@ class EpsNetPlan(PlanBase):
     # (with split_bf16, chain_conv1, compose_stage1, DiffUNet1 only, PReLU slopes <= 1) the BIGLU blocks on PLANE tensors
     # (csrc/bglu.hip): the conv1 outputs travel between launches as bf16 split planes written once by their producer.
     # True: every stage (10-20 % faster than csrc/gconv3.hip per launch, profiles/r03_bglu_forms.txt; the only form of the
-    # bf16 mode); "auto": the encoder only; False: csrc/gconv3.hip throughout (fp32 conv1 tensors, split in every tap).
+    # bf16 mode); False: csrc/gconv3.hip throughout (fp32 conv1 tensors, split in every tap).
     plane_h = True
     planes = 3              # 3: exact three-way bf16 split (fp32-equivalent); 1: plain bf16 operands (the opt-in bf16 mode)
     NSLOT = 20  # 15 stages + en1 real-row bias + 4 composed encoder-stage-1 biases (l/r x frame >= 1 / frame 0)
@@ -372,7 +372,7 @@ class EpsNetPlan(PlanBase):
         if planes is not None:
             self.planes = int(planes)
         if plane_h is not None:
-            self.plane_h = plane_h
+            self.plane_h = bool(plane_h)
         if self.planes == 1:
             self.plane_h = True
         self.sd = sd
@@ -771,11 +771,9 @@ class EpsNetPlan(PlanBase):
 
     # ---- the plane path (csrc/bglu.hip) ------------------------------------------------------------------------
     def _plane_stage(self, kind):
-        """Does stage ``kind`` ("enc" / "dec") run on plane tensors?  "auto": the encoder (the faster kernel there,
-        profiles/r03_bglu_vs_gconv3.txt); the bf16 mode (planes 1) runs every stage on planes."""
-        if self.plane_h is True:
-            return True
-        return self.plane_h == "auto" and kind == "enc"
+        """Does stage ``kind`` ("enc" / "dec") run on plane tensors?  All or none: the encoder leaves the decoders' skip
+        halves in the layout of the kernel that reads them (csrc/bglu.hip: groups of four channels)."""
+        return self.plane_h is True
 
     def _bglu_weights(self, p, transposed, C2, bn_prefix, gather, nx_w):
         """Weight side of one pdse_bglu_desc: gather = dict(w0, w1[, w2, w3]) already packed; folds -log2 e into
@@ -894,7 +892,7 @@ class EpsNetPlan(PlanBase):
                 src = dict(hp=self.hp_en[k], F_in=Fin)
             kwargs = dict(taps=taps, sf_in=2, Fout=Fo, slope=self._slope("en.en%d.1.weight" % k), C2=64, **src)
             if chained:
-                sk = [(self.Pskip[di][k], 32 * T * Fo, T * Fo, Fo, 1) for di in range(2)]
+                sk = [(self.Pskip[di][k], 32 * T * Fo, 4 * T * Fo, 4 * Fo, 4) for di in range(2)]   # [B + 1][8 groups][T][F][4]
                 kwargs.update(nx_hp=self.hp_en[k + 1], nx_F=Fo, nx_row0=True, nx_out=sk,
                               nx_bias=[(tb, slot(k), sbb)] + [(tb, slot(5 + 5 * di + (5 - k)), sbb) for di in range(2)])
             else:
@@ -944,7 +942,7 @@ class EpsNetPlan(PlanBase):
                               slope=self._slope("%s.de%d.3.weight" % (de, k)) if k > 1 else 1.0, C2=C2,
                               bias=(None, 0, 0, None, None, 0))
                 if k > 1:
-                    kwargs.update(nx_hp=self.hp_de[k - 1], nx_F=Fo, nx_add=(self.Pskip[di][k - 1], 32 * T * Fo, T * Fo, Fo, 1),
+                    kwargs.update(nx_hp=self.hp_de[k - 1], nx_F=Fo, nx_add=(self.Pskip[di][k - 1], 32 * T * Fo, 4 * T * Fo, 4 * Fo, 4),
                                   nx_bias=[(self.zero32, 0, 0)])
                 else:
                     kwargs.update(out=out, out_strides=(2 * T * F0, T * F0, F0, 2), out_off=di * T * F0)

@@ -662,7 +662,7 @@ def run_bglu(d, mem):
                 bins = (2 * jI + ph) if d.p1mask else jI
                 if d.nx_add:
                     flat, off = mem.view(d.nx_add)
-                    idx = off + bI[:, None] * d.add_sb + co * d.add_sc + tI[:, None] * d.add_st + bins[:, None] * d.add_sf
+                    idx = off + bI[:, None] * d.add_sb + (co >> 2) * d.add_sc + (co & 3) + tI[:, None] * d.add_st + bins[:, None] * d.add_sf   # groups of 4 channels
                     idx = np.where(np.broadcast_to((jI < jmax)[:, None], Z.shape), np.broadcast_to(idx, Z.shape), off)
                     Z = Z + flat[idx]
                 Z = Z.astype(np.float32)
@@ -682,7 +682,7 @@ def run_bglu(d, mem):
             else:
                 flat, off = mem.view(d.nx_out[i - 1])
                 k_ = i - 1
-                idx = off + bI[:, None] * d.nx_sb[k_] + co * d.nx_sc[k_] + tI[:, None] * d.nx_st[k_] + jI[:, None] * d.nx_sf[k_]
+                idx = off + bI[:, None] * d.nx_sb[k_] + (co >> 2) * d.nx_sc[k_] + (co & 3) + tI[:, None] * d.nx_st[k_] + jI[:, None] * d.nx_sf[k_]
                 flat[np.broadcast_to(idx, Z.shape)] = Z.astype(np.float32)
 
 

@@ -493,7 +493,7 @@ def test_split_tcm_blocks_match_fp32_kernel_and_validate_descriptors(L, weights)
 
 
 # ------------------------------------------------------------------ BIGLU blocks on plane tensors (csrc/bglu.hip), round 3
-@pytest.mark.parametrize("plane_h", [False, "auto", True])
+@pytest.mark.parametrize("plane_h", [False, True])
 def test_plane_blocks_vs_goldens_and_gconv3(L, weights, plane_h, monkeypatch):
     """The eps-net with none / the encoder / every BiConv(Trans)GLU stage on plane tensors (conv1 outputs exchanged as exact
     bf16 split planes, software-pipelined 4-wave workgroups) against the reference's golden vectors - same tolerances as
@@ -508,7 +508,7 @@ def test_plane_blocks_vs_goldens_and_gconv3(L, weights, plane_h, monkeypatch):
     out = op(x.to(DEV), xi.to(DEV), torch.from_numpy(g["t"]).to(DEV))
     net = op._plans[(B, T)]
     torch.cuda.synchronize()
-    assert sum(1 for d, _ in net.descs if isinstance(d, L.BgluDesc)) == {False: 0, "auto": 5, True: 15}[plane_h]
+    assert sum(1 for d, _ in net.descs if isinstance(d, L.BgluDesc)) == {False: 0, True: 15}[plane_h]
     assert rel_l2(net.en[4].cpu().permute(0, 1, 3, 2), g["en5"]) < 2e-5
     e = rel_l2(out.cpu(), g["out"])
     print("plane_h %s: eps-net vs golden %.2e" % (plane_h, e))

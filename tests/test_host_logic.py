@@ -29,7 +29,7 @@ def test_pack_roundtrip():
 
 
 @pytest.mark.parametrize("chained,split,plane_h", [(True, False, False), (False, False, False), (True, True, False),
-                                                  (True, True, "auto"), (True, True, True)])
+                                                  (True, True, True)])
 def test_eps_net_plan_vs_oracle(weights, chained, split, plane_h, monkeypatch):
     """chained: every stage's conv1 rides on the previous stage's tail and the encoder/decoder block outputs are never
     stored (only en[4], the TCM input, is); unchained: the per-stage launches with all intermediates in memory.
@@ -45,7 +45,7 @@ def test_eps_net_plan_vs_oracle(weights, chained, split, plane_h, monkeypatch):
     net.build_time()
     net.build_step(0)
     n_conv1 = sum(1 for _, tag in net.descs if tag == nets.TAG_EPS_CONV1)
-    n_planes = {False: 0, "auto": 5, True: 15}[plane_h]   # stages on plane tensors: the encoder / every stage
+    n_planes = {False: 0, True: 15}[plane_h]   # stages on plane tensors: the encoder / every stage
     assert n_conv1 == (2 if chained else 16) + (2 if plane_h is True else 0)   # chained: only decoder stage 5 x 2 (+ its split into planes)
     n_split = sum(1 for d, _ in net.descs if isinstance(d, pkg("_lib").GconvDesc) and d.korder == 2)
     assert n_split == (15 - n_planes if split else 0)     # encoder stages 1-5 + 2 x 5 decoder stages

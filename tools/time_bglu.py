@@ -69,13 +69,13 @@ def bench(name, NT, p1mask, C2, nx_n, Fin, Fout, Fout1, sf_in, taps, NP=3, B=32,
         if p1mask:
             add = torch.randn(B, 32, T, Fo + 1, device=DEV)
             keep.append(add)
-            d.nx_add, d.add_sb, d.add_sc, d.add_st, d.add_sf = add.data_ptr(), add[0].numel(), T * (Fo + 1), Fo + 1, 1
+            d.nx_add, d.add_sb, d.add_sc, d.add_st, d.add_sf = add.data_ptr(), add[0].numel(), 4 * T * (Fo + 1), 4 * (Fo + 1), 4   # [B][8][T][F][4]
         for i in range(nx_n):
             d.nx_bias[i], d.nx_bias_sb[i] = Fv(32 * B), 32
         for i in range(nx_n - 1):
             sk = torch.empty(B + 1, 32, T, Fout, device=DEV)
             keep.append(sk)
-            d.nx_out[i], d.nx_sb[i], d.nx_sc[i], d.nx_st[i], d.nx_sf[i] = sk.data_ptr(), sk[0].numel(), T * Fout, Fout, 1
+            d.nx_out[i], d.nx_sb[i], d.nx_sc[i], d.nx_st[i], d.nx_sf[i] = sk.data_ptr(), sk[0].numel(), 4 * T * Fout, 4 * Fout, 4
     st = torch.cuda.current_stream().cuda_stream
     for _ in range(3):
         L.launch(d, st)
