@@ -726,13 +726,16 @@ __device__ __forceinline__ uint4 bload16(const __amdgpu_buffer_rsrc_t r, const u
 __device__ __forceinline__ float bload4(const __amdgpu_buffer_rsrc_t r, const uint32_t voff, const int soff) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, soff, 0));
 }
+// AUX: cache policy bits of the store (gfx950: 1 = sc0, 2 = nt, 16 = sc1)
+template <int AUX = 0>
 __device__ __forceinline__ void bstore16(const uint4& x, const __amdgpu_buffer_rsrc_t r, const uint32_t voff, const int soff) {
   v4i_t v;
   v.x = (int)x.x; v.y = (int)x.y; v.z = (int)x.z; v.w = (int)x.w;
-  __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff, soff, 0);
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff, soff, AUX);
 }
+template <int AUX = 0>
 __device__ __forceinline__ void bstore4(const float x, const __amdgpu_buffer_rsrc_t r, const uint32_t voff, const int soff) {
-  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, x), r, (int)voff, soff, 0);
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, x), r, (int)voff, soff, AUX);
 }
 
 #endif
