@@ -26,6 +26,13 @@
 
 #include "gconv_common.h"
 
+// Cache policy of the plane / skip stores (gconv_common.h: bstore16).  0 = write-back through the XCD's L2.  Measured: written
+// through (17 = sc0 sc1) or non-temporal (2) the same launches take 3-7 x as long (encoder 401x79: 183 -> 1203 / 1352 us;
+// decoder 401x40: 153 -> 566 / 1033 us) - the L2 assembling full lines before they go to HBM is worth that much here.
+#ifndef BGLU_ST_AUX
+#define BGLU_ST_AUX 0
+#endif
+
 namespace {
 
 #ifdef BGLU_DIAG   // diagnostic build only (tools/time_bglu.py --diag): shader-clock and 100 MHz stamps around the loop
@@ -321,7 +328,7 @@ __global__ __launch_bounds__(PIPE ? 256 : 512, PIPE ? 1 : 2) void bglu_kernel(co
 #pragma unroll
     for (int q = 0; q < 2; ++q)
 #pragma unroll
-      for (int pl = 0; pl < NP; ++pl) bstore16(zp[q][pl], r_nx, o, ((2 * q * NP + pl) * nFp) << 4);
+      for (int pl = 0; pl < NP; ++pl) bstore16<BGLU_ST_AUX>(zp[q][pl], r_nx, o, ((2 * q * NP + pl) * nFp) << 4);
   };
   const __amdgpu_buffer_rsrc_t r_sk0 = make_rsrc(NXN > 1 ? d.nx_out[0] : nullptr, NXN > 1 ? (uint32_t)((d.B + 1) * d.nx_sb[0] * 4) : 0u);
   const __amdgpu_buffer_rsrc_t r_sk1 = make_rsrc(NXN > 2 ? d.nx_out[1] : nullptr, NXN > 2 ? (uint32_t)((d.B + 1) * d.nx_sb[1] * 4) : 0u);
@@ -333,7 +340,7 @@ __global__ __launch_bounds__(PIPE ? 256 : 512, PIPE ? 1 : 2) void bglu_kernel(co
                                    (int64_t)h * d.nx_sc[i]) << 2);
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-      bstore16(make_uint4(__float_as_uint(z[4 * q]), __float_as_uint(z[4 * q + 1]), __float_as_uint(z[4 * q + 2]), __float_as_uint(z[4 * q + 3])),
+      bstore16<BGLU_ST_AUX>(make_uint4(__float_as_uint(z[4 * q]), __float_as_uint(z[4 * q + 1]), __float_as_uint(z[4 * q + 2]), __float_as_uint(z[4 * q + 3])),
                i == 0 ? r_sk0 : r_sk1, o, (int)((2 * q * d.nx_sc[i]) << 2));
   };
   auto stores_masked = [&](const pos_t& ps, const auto& o0, const auto& o1) {
