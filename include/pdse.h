@@ -388,7 +388,12 @@ typedef struct pdse_gru_desc {
   const float* whh;
   const float* bhh;
   float* y;
-  int32_t B, T, F, H, axis, pad_;
+  int32_t B, T, F, H, axis;
+  /* split 1 (ABI 5; fused H == 64 form only, csrc/gru3.hip): whh / wih hold the exact three-way bf16 splits of the
+     weights as v_mfma_f32_32x32x16_bf16 A fragments (packing.pack_s3_gather per 32-row gate tile),
+       whh [2 dirs][6 tiles][4 K blocks][3 planes][64 lanes][8 bf16],  wih [2][6][2][3][64][8];
+     six bf16 products per multiply-add, fp32 accumulation - fp32-level accuracy at a third of the matrix-pipe time. */
+  int32_t split;
   const float* x;
   const float* wih;
   const float* bih;

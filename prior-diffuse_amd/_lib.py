@@ -121,7 +121,7 @@ class AttnDesc(C.Structure):
 
 class GruDesc(C.Structure):
     _fields_ = [("gx", _fp), ("whh", _fp), ("bhh", _fp), ("y", _fp),
-                ("B", _i32), ("T", _i32), ("F", _i32), ("H", _i32), ("axis", _i32), ("pad_", _i32),
+                ("B", _i32), ("T", _i32), ("F", _i32), ("H", _i32), ("axis", _i32), ("split", _i32),
                 ("x", _fp), ("wih", _fp), ("bih", _fp)]
 
 

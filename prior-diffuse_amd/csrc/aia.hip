@@ -418,6 +418,8 @@ int pdse_gru_launch(const pdse_gru_desc* d, hipStream_t s) {
   const int nlines = d->B * (d->axis == 0 ? d->T : d->F);
   const bool fused = d->x != nullptr;
   REQ(!fused || (d->H == 64 && d->wih && d->bih), "bigru: the fused input projection needs H == 64, wih and bih");
+  REQ(d->split == 0 || d->split == 1, "bigru: split is 0 or 1");
+  if (d->split) return pdse_gru3_launch(d, s);   // split-bf16 operands (csrc/gru3.hip)
   REQ(fused || d->gx, "bigru: gx missing");
   const size_t lds = (size_t)(d->H * 32 + 3 * d->H * 33 + (fused ? d->H * 33 : 0)) * sizeof(float);
   const dim3 grid((nlines + 31) / 32, 2);

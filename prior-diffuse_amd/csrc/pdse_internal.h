@@ -50,4 +50,5 @@ int pdse_glstm_launch(const pdse_glstm_desc* d, hipStream_t s);
 int pdse_tcm2_launch(const pdse_tcm2_desc* d, hipStream_t s);
 int pdse_bglu_launch(const pdse_bglu_desc* d, hipStream_t s);
 int pdse_planes_launch(const pdse_planes_desc* d, hipStream_t s);
+int pdse_gru3_launch(const pdse_gru_desc* d, hipStream_t s);   /* csrc/gru3.hip, reached through pdse_gru_launch */
 #endif

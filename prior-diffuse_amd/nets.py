@@ -1421,13 +1421,14 @@ class AiaPlan(PlanBase):
 
     FH = 80  # bins after the stride-2 encoder conv
     fused_gru_input = True   # d_model 32: W_ih x inside the GRU kernel (csrc/aia.hip, gru_kernel<64, true>)
+    split_gru = True         # (with split_bf16 and the fused form) that recurrence on split-bf16 operands (csrc/gru3.hip)
     split_bf16 = True        # dilated dense blocks and the strided / sub-pixel convolutions as split-bf16 GEMMs (csrc/gconv4.hip)
 
     def __init__(self, ctx, sd, B, T, plan=None, d=32, split_bf16=None):
         """d: d_model of the transformer layers (32: AIA_Transformer(64, 64); 64: AIA_Transformer_merge(128, 64))."""
         if split_bf16 is not None:
             self.split_bf16 = bool(split_bf16)
-        super().__init__(ctx, plan, ns=(ctx.bank.token(sd), d, self.fused_gru_input, self.split_bf16))
+        super().__init__(ctx, plan, ns=(ctx.bank.token(sd), d, self.fused_gru_input, self.split_bf16, self.split_gru))
         self.sd, self.B, self.T, self.d = sd, B, T, d
         a = ctx.alloc
         FH = self.FH
@@ -1572,7 +1573,19 @@ class AiaPlan(PlanBase):
         else:
             gx_in, s2_out = self.n_b, self.s2
         gd = L.GruDesc()
-        if self.fused_gru_input and dm == 32:
+        split_gru = self.split_bf16 and self.split_gru and self.fused_gru_input and dm == 32
+        if split_gru:
+            # csrc/gru3.hip: the same fused recurrence on split-bf16 operands (six bf16 products per multiply-add)
+            def tiles(name, kin):   # [2 dirs][6 gate tiles][kin/16 K blocks][3 planes][64 lanes][8]
+                return np.stack([np.stack([P.pack_s3_gather(self.w(g + name + suf)[32 * m:32 * m + 32].T, 1, kin)
+                                           for m in range(6)], 0) for suf in ("", "_reverse")], 0)
+
+            gd.split = 1
+            gd.x = gx_in.data_ptr()
+            gd.wih = self.upw(g + "wih3", lambda: tiles("weight_ih_l0", dm).view(np.int16), np.int16).data_ptr()
+            gd.bih = self.upw(g + "bih", lambda: np.stack([self.w(g + "bias_ih_l0"),
+                                                           self.w(g + "bias_ih_l0_reverse")], 0)).data_ptr()
+        elif self.fused_gru_input and dm == 32:
             # the input projection runs inside the recurrence kernel: the 12x wider gx tensor never exists
             gd.x = gx_in.data_ptr()
             gd.wih = self.upw(g + "wih", lambda: np.stack([P.pack_a(self.w(g + "weight_ih_l0" + suf).T)
@@ -1585,8 +1598,11 @@ class AiaPlan(PlanBase):
                 bias0=np.concatenate([self.w(g + "bias_ih_l0"), self.w(g + "bias_ih_l0_reverse")], 0)),
                 self.gx, 12 * dm, FH, in_layout=lay, out_layout=lay, label=g + "ih")
         gd.gx, gd.y = self.gx.data_ptr(), self.gy.data_ptr()
-        gd.whh = self.upw(g + "whh", lambda: np.stack([P.pack_a(self.w(g + "weight_hh_l0" + suf).T)
-                                                       for suf in ("", "_reverse")], 0)).data_ptr()   # [2, 3H/32, H/2, 64]
+        if split_gru:
+            gd.whh = self.upw(g + "whh3", lambda: tiles("weight_hh_l0", 2 * dm).view(np.int16), np.int16).data_ptr()
+        else:
+            gd.whh = self.upw(g + "whh", lambda: np.stack([P.pack_a(self.w(g + "weight_hh_l0" + suf).T)
+                                                           for suf in ("", "_reverse")], 0)).data_ptr()   # [2, 3H/32, H/2, 64]
         gd.bhh = self.upw(g + "bhh", lambda: np.stack([self.w(g + "bias_hh_l0"), self.w(g + "bias_hh_l0_reverse")], 0)).data_ptr()
         gd.B, gd.H, gd.axis = B, 2 * dm, 1                            # lines on the innermost axis, sequence on the outer
         gd.T, gd.F = (FH, T) if gru_ft else (T, FH)

@@ -27,7 +27,7 @@ for i, (d, tag) in enumerate(net.descs):
     if k == "GconvDesc":
         k += ":nt%d:cin%d:cout%d" % (d.ntaps, d.in0.C, d.Cout)
     if k == "AttnDesc" or k == "GruDesc":
-        k += ":axis%d" % d.axis
+        k += ":axis%d:T%d:F%d" % (d.axis, d.T, d.F)
     a = tot.setdefault(k, [0, 0.0])
     a[0] += 1
     a[1] += med[i]
