@@ -47,6 +47,27 @@ def test_argument_errors_do_not_need_a_device(lib):
         lib.launch(lib.BgluDesc())
     with pytest.raises(lib.PdseError, match="planes"):
         lib.launch(lib.PlanesDesc())
+    # round 3 (ABI 5): channel-blocked sources are a feature of the korder-3 kernel; the split GRU is the fused H = 64 form
+    import ctypes as C
+
+    buf = (C.c_float * 64)()
+    ptr = C.addressof(buf)
+    g = lib.GconvDesc()
+    g.in0 = lib.Src(ptr, 64, 8, 8, 8, 16, 0, 8, 0)
+    g.out, g.w0, g.taps = ptr, ptr, ptr
+    g.B, g.Tout, g.Fout, g.Cout, g.ntaps, g.out_cr, g.korder, g.ksteps = 1, 1, 1, 32, 1, 1, 1, 8
+    with pytest.raises(lib.PdseError, match="channel-blocked"):
+        lib.launch(g)
+    r = lib.GruDesc()
+    r.whh, r.bhh, r.y, r.gx = ptr, ptr, ptr, ptr
+    r.B, r.T, r.F, r.H, r.axis, r.split = 1, 1, 1, 128, 1, 1
+    with pytest.raises(lib.PdseError, match="split-bf16"):
+        lib.launch(r)
+    n = lib.LnDesc()
+    n.in_, n.gamma, n.beta, n.out = ptr, ptr, ptr, ptr
+    n.B, n.T, n.N, n.r, n.blk = 1, 1, 8, 4, 3
+    with pytest.raises(lib.PdseError, match="blk"):
+        lib.launch(n)
     p = lib.Plan()
     assert len(p) == 0
     p.add(lib.EwDesc())
