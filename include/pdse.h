@@ -592,13 +592,16 @@ typedef struct pdse_bglu_desc {
   int32_t C2;              /* 64 or 1 */
   float* out;              /* C2 == 1: one channel; C2 == 64 and nx_n == 0: the 64-channel block output */
   int64_t out_sb, out_sc, out_st, out_sf, out_off;   /* dual phase: out_sf = stride of 2 bins */
-  int32_t pad0_, nx_n;
+  int32_t hp_par, nx_n; /* hp_par: see below */
   /* chained tile 0 (next stage's conv1): written as planes */
   uint16_t* nx_hp;
   int64_t nx_hp_sb;
   int32_t nx_Tp, nx_Fp, nx_t0, nx_f0;
   int32_t nx_row0;         /* 1: lanes of output frame 0 also write the tile's bias to frame -1 (encoder pad frame) */
-  int32_t nx_pad_;
+  /* hp_par / nx_par 1 (ABI 5): the bins of every (frame, group, plane) row of hp / nx_hp are stored split by parity - bin
+     index i (margin included) at (i & 1) * ((Fp + 1) >> 1) + (i >> 1) - so the stride-2 taps of the encoders (sf_in = 2)
+     read 512 contiguous bytes per 32 lanes like the stride-1 taps of the decoders do.  hp_par needs sf_in == 2. */
+  int32_t nx_par;
   /* The fp32 skip halves (nx_add read by the decoders, nx_out written by the encoder) are kept in groups of four channels,
      [B (+1)][8 groups][T][F][4]: channel c of (b, t, bin) lives at b*sb + (c >> 2)*sc + (c & 3) + t*st + bin*sf (every
      stride a multiple of 4 floats, the base 16-byte aligned), so a lane moves its accumulator rows as four 16-byte

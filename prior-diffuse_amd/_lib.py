@@ -172,9 +172,9 @@ class BgluDesc(C.Structure):
                 ("nx_w", _fp), ("bias0", _fp), ("bias1", _fp), ("bias0_t0", _fp), ("bias1_t0", _fp), ("bias_sb", _i64),
                 ("blc", _fp), ("brc", _fp), ("bc2", _fp), ("slope", _f32), ("C2", _i32),
                 ("out", _fp), ("out_sb", _i64), ("out_sc", _i64), ("out_st", _i64), ("out_sf", _i64), ("out_off", _i64),
-                ("pad0_", _i32), ("nx_n", _i32),
+                ("hp_par", _i32), ("nx_n", _i32),
                 ("nx_hp", _fp), ("nx_hp_sb", _i64), ("nx_Tp", _i32), ("nx_Fp", _i32), ("nx_t0", _i32), ("nx_f0", _i32),
-                ("nx_row0", _i32), ("nx_pad_", _i32),
+                ("nx_row0", _i32), ("nx_par", _i32),
                 ("nx_add", _fp), ("add_sb", _i64), ("add_sc", _i64), ("add_st", _i64), ("add_sf", _i64),
                 ("nx_out", _fp * 2), ("nx_sb", _i64 * 2), ("nx_sc", _i64 * 2), ("nx_st", _i64 * 2), ("nx_sf", _i64 * 2),
                 ("nx_bias", _fp * 3), ("nx_bias_sb", _i64 * 3)]

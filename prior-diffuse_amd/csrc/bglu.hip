@@ -224,12 +224,15 @@ __global__ __launch_bounds__(PIPE ? 256 : 512, PIPE ? 1 : 2) void bglu_kernel(co
     const int pp = ps.valid ? p : 0;   // branch-free: lanes without a position work on position 0
     ps.t = pp / d.Fout;
     ps.j = pp - ps.t * d.Fout;
-    ps.vin = (uint32_t)(ps.t * (4 * NP * Fp) + h * (NP * Fp) + ps.j * d.sf_in) << 4;
+    // hp_par (sf_in == 2, validated): bin 2 j + df + f0 lives at ((df + f0) & 1) * Fh + j + ((df + f0) >> 1) - the lane part is j
+    ps.vin = (uint32_t)(ps.t * (4 * NP * Fp) + h * (NP * Fp) + (d.hp_par ? ps.j : ps.j * d.sf_in)) << 4;
   };
+  const int Fh = (Fp + 1) >> 1;
   // (tap, K block q, plane pl) of a lane = buffer resource of this item's hp + the lane's byte offset (pos_t::vin) + a
   // wave-uniform byte offset in a scalar register
   auto soff_in = [&](const int tap, const int q, const int pl) -> int {
-    return (((d.tap_dt[tap] + d.hp_t0) * 4 + 2 * q) * (NP * Fp) + pl * Fp + d.tap_df[tap] + d.hp_f0) << 4;
+    const int bin0 = d.tap_df[tap] + d.hp_f0;
+    return (((d.tap_dt[tap] + d.hp_t0) * 4 + 2 * q) * (NP * Fp) + pl * Fp + (d.hp_par ? (bin0 & 1) * Fh + (bin0 >> 1) : bin0)) << 4;
   };
   // input operands of one tile: planes [tap][q][plane] (or, stage 1, the raw fp32 gathers [slot][4])
   struct in_t {
@@ -323,7 +326,9 @@ __global__ __launch_bounds__(PIPE ? 256 : 512, PIPE ? 1 : 2) void bglu_kernel(co
   const __amdgpu_buffer_rsrc_t r_nx = make_rsrc(NXN > 0 ? d.nx_hp : nullptr, NXN > 0 ? (uint32_t)(d.B + 1) * item_hp : 0u);
   auto store_planes = [&](const uint4 (&zp)[2][NP], const bool ok, const int t, const int bin) {
     // (frame t, bin) of the next stage's hp: lane half h owns groups g = 2q + h
-    const uint32_t o = ok ? (uint32_t)b * item_hp + ((uint32_t)(((t + d.nx_t0) * 4 + h) * (NP * nFp) + bin + d.nx_f0) << 4)
+    const int bi = bin + d.nx_f0;
+    const int bpos = d.nx_par ? (bi & 1) * ((nFp + 1) >> 1) + (bi >> 1) : bi;
+    const uint32_t o = ok ? (uint32_t)b * item_hp + ((uint32_t)(((t + d.nx_t0) * 4 + h) * (NP * nFp) + bpos) << 4)
                           : (uint32_t)d.B * item_hp + ((uint32_t)(h * (NP * nFp)) << 4);
 #pragma unroll
     for (int q = 0; q < 2; ++q)
@@ -804,6 +809,10 @@ int pdse_bglu_launch(const pdse_bglu_desc* d, hipStream_t s) {
     const long long frame = 4ll * d->np * d->hp_Fp;
     if ((long long)d->hp_Tp * frame * 16 >= (1ll << 32)) {
       pdse_set_error("bglu: hp item exceeds 32-bit lane offsets");
+      return 1;
+    }
+    if (d->hp_par && (d->hp_par != 1 || d->sf_in != 2)) {
+      pdse_set_error("bglu: parity-split input planes (hp_par = 1) are for stride-2 taps (sf_in == 2)");
       return 1;
     }
     for (int i = 0; i < d->ntaps; ++i) {

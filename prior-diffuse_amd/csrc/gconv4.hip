@@ -223,8 +223,16 @@ __global__ __launch_bounds__(512, 2) void gconv4_kernel(const pdse_gconv_desc d)
       if (DUAL) acc1[m][r] = 0.f;
     }
   }
+  // One chunk.  The ring reads of K block i+1 are issued fragment by fragment right behind the six MFMAs that were the last
+  // readers of that fragment's registers in block i, so they fly under the remaining MFMAs of block i instead of in front of
+  // block i+1's (an MFMA reads its A / B operands when it issues; the LDS data returns ~100 cycles later).  Before round 3's
+  // end every block waited for its twelve ring reads with an idle matrix pipe: 5.3k cycles per chunk for 3.1k of MFMAs.
   auto compute = [&](const g4_chunk& c, const g4_raw<BLK>& raw, const bool inb, const int buf) {
     const bool elu = uni((c.s ? d.in1.act : d.in0.act) == PDSE_ACT_ELU) != 0;   // GCRN re-applies ELU to the skip half (gcrn.py:152-155)
+    u32x4 af[FR][3];
+    const unsigned wa0 = ring_base + (unsigned)((((buf * G4_CH) * FR) * 192 + lane) * 16);
+#pragma unroll
+    for (int f = 0; f < FR; ++f) g4_lds_read3(wa0 + f * (192 * 16), af[f]);
 #pragma unroll
     for (int i = 0; i < G4_CH; ++i) {
       if (i < c.n) {
@@ -235,18 +243,17 @@ __global__ __launch_bounds__(512, 2) void gconv4_kernel(const pdse_gconv_desc d)
 #pragma unroll
           for (int e = 0; e < 8; ++e) x[e] = x[e] < 0.f ? fast_exp(x[e]) - 1.0f : x[e];
         }
-        // the block's fragments are requested first; the split runs under their LDS latency
-        u32x4 af[FR][3];
-        const unsigned wa = ring_base + (unsigned)((((buf * G4_CH + i) * FR) * 192 + lane) * 16);
-#pragma unroll
-        for (int f = 0; f < FR; ++f) g4_lds_read3(wa + f * (192 * 16), af[f]);
         uint4 b1, b2, b3;
-        split8(x, b1, b2, b3);
+        split8(x, b1, b2, b3);   // runs under the LDS latency of the block's fragments
         g4_lds_wait(af);
+        const bool more = i + 1 < c.n;   // wave-uniform
+        const unsigned wn = ring_base + (unsigned)((((buf * G4_CH + i + 1) * FR) * 192 + lane) * 16);
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          acc0[m] = g4_mfma6(af[m], b1, b2, b3, acc0[m]);
-          if constexpr (DUAL) acc1[m] = g4_mfma6(af[MT + m], b1, b2, b3, acc1[m]);
+        for (int f = 0; f < FR; ++f) {
+          const int m = f % MT;
+          if (f < MT) acc0[m] = g4_mfma6(af[f], b1, b2, b3, acc0[m]);
+          else acc1[m] = g4_mfma6(af[f], b1, b2, b3, acc1[m]);
+          if (more) g4_lds_read3(wn + f * (192 * 16), af[f]);
         }
       }
     }

@@ -358,6 +358,7 @@ class EpsNetPlan(PlanBase):
     # True: every stage (10-20 % faster than csrc/gconv3.hip per launch, profiles/r03_bglu_forms.txt; the only form of the
     # bf16 mode); False: csrc/gconv3.hip throughout (fp32 conv1 tensors, split in every tap).
     plane_h = True
+    parity_planes = True    # the encoders' plane tensors with their bins split by parity (contiguous stride-2 taps; pdse_bglu_desc.hp_par)
     planes = 3              # 3: exact three-way bf16 split (fp32-equivalent); 1: plain bf16 operands (the opt-in bf16 mode)
     NSLOT = 20  # 15 stages + en1 real-row bias + 4 composed encoder-stage-1 biases (l/r x frame >= 1 / frame 0)
 
@@ -384,7 +385,7 @@ class EpsNetPlan(PlanBase):
             self.plane_h = False
         super().__init__(ctx, plan, ns=(ctx.bank.token(sd), bool(time_cond), bool(with_pre), self.fused_tcm, self.chain_conv1,
                                         self.compose_stage1, self.split_bf16, self.split_tcm,
-                                        ctx.bank.token(table), str(self.plane_h), self.planes))
+                                        ctx.bank.token(table), str(self.plane_h), self.planes, self.parity_planes))
         self.sd, self.B, self.T, self.time_cond, self.nsteps = sd, B, T, time_cond, nsteps
         self.with_pre = with_pre
         a = ctx.alloc
@@ -802,7 +803,7 @@ class EpsNetPlan(PlanBase):
 
     def _bglu(self, label, make, *, hp=None, F_in=None, x0=None, x1=None, taps, sf_in, Fout, p1mask=0, Fout1=0, slope, C2,
               bias, out=None, out_strides=None, out_off=0, nx_hp=None, nx_F=None, nx_row0=False, nx_add=None,
-              nx_out=(), nx_bias=()):
+              nx_out=(), nx_bias=(), hp_par=False, nx_par=False):
         """Record one pdse_bglu_desc.  make(): -> dict of packed device pointers (memoised in the weight bank)."""
         B, T, npl = self.B, self.T, self.planes
         d = L.BgluDesc()
@@ -811,6 +812,7 @@ class EpsNetPlan(PlanBase):
         if hp is not None:
             shp = P.hp_shape(B + 1, T, F_in, npl)
             d.hp, d.hp_sb, d.hp_Tp, d.hp_Fp, d.hp_t0, d.hp_f0 = hp.data_ptr(), int(np.prod(shp[1:])), shp[1], shp[4], P.HP_T0, P.HP_F0
+            d.hp_par = 1 if hp_par else 0
         else:
             d.x0, d.x1 = x0, x1
         d.Tin, d.Fin = T, (F_in if F_in is not None else F0)
@@ -835,6 +837,7 @@ class EpsNetPlan(PlanBase):
             d.nx_hp, d.nx_hp_sb, d.nx_Tp, d.nx_Fp, d.nx_t0, d.nx_f0 = (nx_hp.data_ptr(), int(np.prod(shp[1:])), shp[1], shp[4],
                                                                       P.HP_T0, P.HP_F0)
             d.nx_row0 = 1 if nx_row0 else 0
+            d.nx_par = 1 if nx_par else 0
         if nx_add is not None:
             t_, sb_, sc_, st_, sf_ = nx_add
             d.nx_add, d.add_sb, d.add_sc, d.add_st, d.add_sf = Ctx.ptr(t_), sb_, sc_, st_, sf_
@@ -889,11 +892,11 @@ class EpsNetPlan(PlanBase):
                     f["bias0"], f["bias1"] = self.ctx.up(self.w(p + ".l.bias")).data_ptr(), self.ctx.up(self.w(p + ".r.bias")).data_ptr()
                     return f
                 bias = None
-                src = dict(hp=self.hp_en[k], F_in=Fin)
+                src = dict(hp=self.hp_en[k], F_in=Fin, hp_par=self.parity_planes)
             kwargs = dict(taps=taps, sf_in=2, Fout=Fo, slope=self._slope("en.en%d.1.weight" % k), C2=64, **src)
             if chained:
                 sk = [(self.Pskip[di][k], 32 * T * Fo, 4 * T * Fo, 4 * Fo, 4) for di in range(2)]   # [B + 1][8 groups][T][F][4]
-                kwargs.update(nx_hp=self.hp_en[k + 1], nx_F=Fo, nx_row0=True, nx_out=sk,
+                kwargs.update(nx_hp=self.hp_en[k + 1], nx_F=Fo, nx_row0=True, nx_out=sk, nx_par=self.parity_planes,
                               nx_bias=[(tb, slot(k), sbb)] + [(tb, slot(5 + 5 * di + (5 - k)), sbb) for di in range(2)])
             else:
                 kwargs.update(out=self.en[4], out_strides=(64 * 4 * T, 4 * T, 1, T))          # [B,64,4,T]

@@ -491,6 +491,13 @@ def hp_shape(B, T, F, npl):
     return (B, T + HP_T0, 4, npl, F + 2 * HP_F0, 8)
 
 
+def hp_par_pos(Fp):
+    """Parity-split row order of an hp tensor (pdse_bglu_desc.hp_par / nx_par): bin index i (margin included) is stored at
+    pos[i] = (i & 1) * ((Fp + 1) >> 1) + (i >> 1)."""
+    i = np.arange(Fp)
+    return (i & 1) * ((Fp + 1) >> 1) + (i >> 1)
+
+
 def hp_split(x, npl):
     """[B, 32, T, F] float -> hp uint16 (margins zero)."""
     x = np.asarray(x, np.float32)

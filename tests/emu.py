@@ -593,6 +593,9 @@ def run_bglu(d, mem):
     else:
         hpf, hoff = mem.view(d.hp, np.int16)
         hp = hpf.view(np.uint16)[hoff:hoff + B * d.hp_sb].reshape(B, d.hp_Tp, 4, npl, d.hp_Fp, 8)
+        if d.hp_par:                                                                         # rows stored split by parity
+            assert d.sf_in == 2
+            hp = hp[:, :, :, :, P.hp_par_pos(d.hp_Fp), :]                                     # natural[i] = stored[pos[i]]
         H = P.hp_join(hp, with_margins=True)                                                 # [B, 32, Tp, Fp]
         W = [P.unpack_bglu_gather(unp(p_, 2 * nt), nt) for p_ in (d.w0, d.w1)]
         ph_taps = [list(range(nt))]
@@ -670,15 +673,17 @@ def run_bglu(d, mem):
                 nhp = hpf.view(np.uint16)[hoff:hoff + B * d.nx_hp_sb].reshape(B, d.nx_Tp, 4, npl, d.nx_Fp, 8)
                 new = P.hp_split(np.zeros((B, 32, d.nx_Tp - d.nx_t0, d.nx_Fp - 2 * d.nx_f0), np.float32), npl)   # shape helper
                 assert new.shape == nhp.shape and d.nx_t0 == P.HP_T0 and d.nx_f0 == P.HP_F0
+                pos = P.hp_par_pos(d.nx_Fp) if d.nx_par else np.arange(d.nx_Fp)          # stored index of bin index i
                 for bb in range(B):
                     for tt in range(T):
                         cols = np.arange(jmax)
                         fb = (2 * cols + ph) if d.p1mask else cols
                         piece = P.hp_split(Z[bb:bb + 1, :, tt:tt + 1, :jmax], npl)[0, P.HP_T0, :, :, P.HP_F0:P.HP_F0 + jmax, :]
-                        nhp[bb, tt + d.nx_t0, :, :, fb + d.nx_f0, :] = piece.transpose(2, 0, 1, 3)
+                        nhp[bb, tt + d.nx_t0, :, :, pos[fb + d.nx_f0], :] = piece.transpose(2, 0, 1, 3)
                 if d.nx_row0:
                     bz = np.broadcast_to(vec(d.nx_bias[0], d.nx_bias_sb[0], 32), (B, 32, 1, Fo)).astype(np.float32)
-                    nhp[:, d.nx_t0 - 1, :, :, d.nx_f0:d.nx_f0 + Fo, :] = P.hp_split(bz, npl)[:, P.HP_T0, :, :, P.HP_F0:P.HP_F0 + Fo, :]
+                    row = nhp[:, d.nx_t0 - 1]                                           # view [B, 4, npl, Fp, 8]
+                    row[:, :, :, pos[d.nx_f0:d.nx_f0 + Fo], :] = P.hp_split(bz, npl)[:, P.HP_T0, :, :, P.HP_F0:P.HP_F0 + Fo, :]
             else:
                 flat, off = mem.view(d.nx_out[i - 1])
                 k_ = i - 1

@@ -517,7 +517,10 @@ def test_plane_blocks_vs_goldens_and_gconv3(L, weights, plane_h, monkeypatch):
         Pk = pkg("packing")
         tensors = [(hp, True) for hp in net.hp_en.values()] + ([(hp, False) for hp in net.hp_de.values()] if plane_h is True else [])
         for hp, enc in tensors:                                           # margins untouched by every launch
-            full = Pk.hp_join(hp.cpu().numpy().view(np.uint16)[:B], with_margins=True)
+            raw = hp.cpu().numpy().view(np.uint16)[:B]
+            if enc and net.parity_planes:                                 # rows stored split by parity: back to bin order
+                raw = raw[:, :, :, :, Pk.hp_par_pos(raw.shape[4]), :]
+            full = Pk.hp_join(raw, with_margins=True)
             assert not full[:, :, :, :2].any() and not full[:, :, :, -2:].any() and (enc or not full[:, :, 0].any())
     g4 = golden("diffunet1_t401")
     x4 = seeded((1, 2, 401, 161), g4["seed_x"])

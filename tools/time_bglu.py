@@ -25,6 +25,7 @@ def bench(name, NT, p1mask, C2, nx_n, Fin, Fout, Fout1, sf_in, taps, NP=3, B=32,
     hp = rnd16(B, Tp, 4, NP, Fp, 8)
     d.hp, d.hp_sb, d.hp_Tp, d.hp_Fp, d.hp_t0, d.hp_f0 = hp.data_ptr(), hp[0].numel(), Tp, Fp, 1, 2
     d.ntaps, d.sf_in = NT, sf_in
+    d.hp_par = 1 if (sf_in == 2 and not os.environ.get("NOPAR")) else 0   # encoders: rows split by parity (synthetic data: timing only)
     for i, (dt, df) in enumerate(taps):
         d.tap_dt[i], d.tap_df[i] = dt, df
     d.p1mask, d.Fout1 = p1mask, Fout1
