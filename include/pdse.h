@@ -613,6 +613,10 @@ typedef struct pdse_bglu_desc {
   int64_t nx_sb[2], nx_sc[2], nx_st[2], nx_sf[2];
   const float* nx_bias[3]; /* [B or 1][32] per tile */
   int64_t nx_bias_sb[3];
+  /* skip_Fh > 0 (ABI 5): the bins of the skip halves (nx_out written by the encoder at bin j; nx_add read by the dual-phase
+     decoders at bins 2j and 2j+1) are stored split by parity, bin i at (i & 1) * skip_Fh + (i >> 1) (skip_Fh = ceil(F / 2) of the
+     tensor): each decoder phase then reads whole lines instead of every other 16 bytes of them.  0: bin i at i. */
+  int32_t skip_Fh, pad1_;
 } pdse_bglu_desc;
 
 /* fp32 [B, 32, T, F] -> hp planes (the standalone conv1 of the first decoder stage) */

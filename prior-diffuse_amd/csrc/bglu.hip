@@ -37,6 +37,7 @@ namespace {
 
 #ifdef BGLU_DIAG   // diagnostic build only (tools/time_bglu.py --diag): shader-clock and 100 MHz stamps around the loop
 __device__ unsigned long long g_bglu_diag[4];
+__device__ unsigned long long g_bglu_slots[97];   // BGLU_SLOTSTAMP: shader cycles per slot of the 8-wave form, summed over waves and tiles; [96]: tiles
 #endif
 
 constexpr int popc(int m) { return m ? (m & 1) + popc(m >> 1) : 0; }
@@ -241,6 +242,15 @@ __global__ __launch_bounds__(PIPE ? 256 : 512, PIPE ? 1 : 2) void bglu_kernel(co
     unsigned live;
   };
   auto request_tap = [&](const pos_t& ps, in_t& in, const int tap) {
+#if defined(BGLU_DIAG) && defined(BGLU_HALF_REQ)   // timing ablation (results wrong): every other tap re-uses its neighbour's registers
+    if (tap & 1) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) in.pl[tap][q][pl] = in.pl[tap - 1][q][pl];
+      return;
+    }
+#endif
     const __amdgpu_buffer_rsrc_t r_in = make_rsrc(d.hp + (int64_t)b * d.hp_sb, (uint32_t)d.hp_Tp * 4u * NP * (uint32_t)Fp * 16u);
 #pragma unroll
     for (int q = 0; q < 2; ++q)
@@ -341,7 +351,8 @@ __global__ __launch_bounds__(PIPE ? 256 : 512, PIPE ? 1 : 2) void bglu_kernel(co
   // half h are channels 8q + 4h..+3 = group 2q + h, 16 contiguous bytes - four 16-byte stores per tile where
   // [B][32][T][F] took sixteen 4-byte ones (a 4-byte and a 16-byte wave access cost the addresser about the same)
   auto store_skip = [&](const f32x16& z, const int i, const pos_t& ps) {
-    const uint32_t o = (uint32_t)(((int64_t)(ps.valid ? b : d.B) * d.nx_sb[i] + (ps.valid ? (int64_t)ps.t * d.nx_st[i] + (int64_t)ps.j * d.nx_sf[i] : 0) +
+    const int jp = d.skip_Fh ? (ps.j & 1) * d.skip_Fh + (ps.j >> 1) : ps.j;   // bins split by parity (pdse_bglu_desc.skip_Fh)
+    const uint32_t o = (uint32_t)(((int64_t)(ps.valid ? b : d.B) * d.nx_sb[i] + (ps.valid ? (int64_t)ps.t * d.nx_st[i] + (int64_t)jp * d.nx_sf[i] : 0) +
                                    (int64_t)h * d.nx_sc[i]) << 2);
 #pragma unroll
     for (int q = 0; q < 4; ++q)
@@ -393,7 +404,8 @@ __global__ __launch_bounds__(PIPE ? 256 : 512, PIPE ? 1 : 2) void bglu_kernel(co
   const __amdgpu_buffer_rsrc_t r_add = make_rsrc((DUAL && NXN > 0) ? d.nx_add : nullptr, (DUAL && NXN > 0) ? (uint32_t)(d.B * d.add_sb * 4) : 0u);
   auto zseed = [&](const pos_t& ps, const int ph, f32x16& z) {
     const bool two = ph == 0 || ps.j < d.Fout1;
-    const int bin = 2 * ps.j + (two ? ph : 0);
+    const int bin0 = 2 * ps.j + (two ? ph : 0);
+    const int bin = d.skip_Fh ? (two ? ph : 0) * d.skip_Fh + ps.j : bin0;   // parity-split bins: phase ph reads a contiguous run
     const uint32_t o = (uint32_t)(((int64_t)b * d.add_sb + (int64_t)ps.t * d.add_st + (int64_t)bin * d.add_sf + (int64_t)h * d.add_sc) << 2);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {   // groups of four channels (store_skip's layout): four 16-byte loads
@@ -529,6 +541,16 @@ __global__ __launch_bounds__(PIPE ? 256 : 512, PIPE ? 1 : 2) void bglu_kernel(co
 #define V_DOT(S, ph)
 #define V_KSPLIT(q)
 #endif
+#if defined(BGLU_DIAG) && defined(BGLU_NO_ST)   // timing ablation: no plane / skip stores
+#undef V_ST0
+#undef V_STSKIP
+#define V_ST0(S, ph) if (d.slope == 12345.f) { store_planes(S.zp, pc.valid, pc.t, DUAL ? 2 * pc.j + (ph) : pc.j); }
+#define V_STSKIP(S, i) if (d.slope == 12345.f) { store_skip(S.Z##i, (i)-1, pc); }
+#endif
+#if defined(BGLU_DIAG) && defined(BGLU_NO_ZSEED)   // timing ablation: no addend loads
+#undef V_ZSEED
+#define V_ZSEED(S, ph)
+#endif
 #if defined(BGLU_DIAG) && defined(BGLU_NO_REQ)
 #undef REQ
 #undef REQ_CUR
@@ -554,7 +576,24 @@ __global__ __launch_bounds__(PIPE ? 256 : 512, PIPE ? 1 : 2) void bglu_kernel(co
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                             \
   }                                                                                \
   __builtin_amdgcn_sched_barrier(0);                                               \
+  DG_SLOT(__COUNTER__)                                                             \
   }
+#if defined(BGLU_DIAG) && defined(BGLU_SLOTSTAMP)
+  // per-slot shader-clock stamps (s_memtime waits for lgkmcnt(0): the slot's own LDS reads have been consumed by then)
+  unsigned dg_slot[96];
+#pragma unroll
+  for (int k_ = 0; k_ < 96; ++k_) dg_slot[k_] = 0;
+  unsigned long long dg_prev = 0;
+  unsigned dg_tiles = 0;
+#define DG_SLOT(c_)                                                                 \
+  if constexpr (!PIPE) {                                                            \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();                     \
+    dg_slot[(c_) - dg_base - 1] += (unsigned)(t_ - dg_prev);                        \
+    dg_prev = t_;                                                                   \
+  }
+#else
+#define DG_SLOT(c_)
+#endif
 
   // ---- the software pipeline over this workgroup's rounds r_k = blockIdx.x + k gridDim.x
   const int stride = gridDim.x;
@@ -606,22 +645,27 @@ __global__ __launch_bounds__(PIPE ? 256 : 512, PIPE ? 1 : 2) void bglu_kernel(co
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (SCHED == 1) {
 #define BGLU_SCHED 1
+      [[maybe_unused]] constexpr int dg_base = __COUNTER__;
 #include "bglu_sched.inc"
 #undef BGLU_SCHED
     } else if constexpr (SCHED == 2) {
 #define BGLU_SCHED 2
+      [[maybe_unused]] constexpr int dg_base = __COUNTER__;
 #include "bglu_sched.inc"
 #undef BGLU_SCHED
     } else if constexpr (SCHED == 3) {
 #define BGLU_SCHED 3
+      [[maybe_unused]] constexpr int dg_base = __COUNTER__;
 #include "bglu_sched.inc"
 #undef BGLU_SCHED
     } else if constexpr (SCHED == 4) {
 #define BGLU_SCHED 4
+      [[maybe_unused]] constexpr int dg_base = __COUNTER__;
 #include "bglu_sched.inc"
 #undef BGLU_SCHED
     } else {
 #define BGLU_SCHED 5
+      [[maybe_unused]] constexpr int dg_base = __COUNTER__;
 #include "bglu_sched.inc"
 #undef BGLU_SCHED
     }
@@ -666,24 +710,33 @@ __global__ __launch_bounds__(PIPE ? 256 : 512, PIPE ? 1 : 2) void bglu_kernel(co
       uint4 kb[IN4 ? 3 : 1][NP];
       seed(pc, acc);
       __builtin_amdgcn_sched_barrier(0);
+#if defined(BGLU_DIAG) && defined(BGLU_SLOTSTAMP)
+      dg_prev = __builtin_amdgcn_s_memtime();
+      ++dg_tiles;
+#endif
       if constexpr (SCHED == 11) {
 #define BGLU_SCHED 11
+      [[maybe_unused]] constexpr int dg_base = __COUNTER__;
 #include "bglu_sched.inc"
 #undef BGLU_SCHED
       } else if constexpr (SCHED == 12) {
 #define BGLU_SCHED 12
+      [[maybe_unused]] constexpr int dg_base = __COUNTER__;
 #include "bglu_sched.inc"
 #undef BGLU_SCHED
       } else if constexpr (SCHED == 13) {
 #define BGLU_SCHED 13
+      [[maybe_unused]] constexpr int dg_base = __COUNTER__;
 #include "bglu_sched.inc"
 #undef BGLU_SCHED
       } else if constexpr (SCHED == 14) {
 #define BGLU_SCHED 14
+      [[maybe_unused]] constexpr int dg_base = __COUNTER__;
 #include "bglu_sched.inc"
 #undef BGLU_SCHED
       } else {
 #define BGLU_SCHED 15
+      [[maybe_unused]] constexpr int dg_base = __COUNTER__;
 #include "bglu_sched.inc"
 #undef BGLU_SCHED
       }
@@ -692,6 +745,14 @@ __global__ __launch_bounds__(PIPE ? 256 : 512, PIPE ? 1 : 2) void bglu_kernel(co
       if (rd >= nrounds) break;
       pc = pn;
     }
+#if defined(BGLU_DIAG) && defined(BGLU_SLOTSTAMP)
+    if (lane == 0) {
+#pragma unroll
+      for (int k_ = 0; k_ < 96; ++k_)
+        if (dg_slot[k_]) atomicAdd(&g_bglu_slots[k_], (unsigned long long)dg_slot[k_]);
+      atomicAdd(&g_bglu_slots[96], (unsigned long long)dg_tiles);
+    }
+#endif
   }
 }
 
@@ -738,11 +799,25 @@ int launch_(const pdse_bglu_desc* d, hipStream_t s) {
 #ifdef BGLU_DIAG
   unsigned long long z[4] = {0, 0, 0, 0};
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bglu_diag), z, sizeof(z));
+  static unsigned long long zs[97];
+  for (int k = 0; k < 97; ++k) zs[k] = 0;
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bglu_slots), zs, sizeof(zs));
 #endif
   hipLaunchKernelGGL((bglu_kernel<NT, P1MASK, C2, NXN, IN4, NP, PIPE>), dim3(gx, d->B, 1), dim3(64 * CF::WV), CF::lds_bytes, s, *d);
 #ifdef BGLU_DIAG
   (void)hipStreamSynchronize(s);
   (void)hipMemcpyFromSymbol(z, HIP_SYMBOL(g_bglu_diag), sizeof(z));
+  (void)hipMemcpyFromSymbol(zs, HIP_SYMBOL(g_bglu_slots), sizeof(zs));
+  if (zs[96]) {
+    fprintf(stderr, "bglu slots NT %d P1 %d C2 %d NXN %d NP %d (cycles per slot and tile, %llu tiles):", NT, P1MASK, C2, NXN, NP, zs[96]);
+    double tot = 0;
+    for (int k = 0; k < 96; ++k)
+      if (zs[k]) {
+        fprintf(stderr, " %d:%.0f", k, (double)zs[k] / (double)zs[96]);
+        tot += (double)zs[k] / (double)zs[96];
+      }
+    fprintf(stderr, " | sum %.0f\n", tot);
+  }
   if (z[3]) fprintf(stderr, "bglu diag NT %d P1 %d C2 %d NXN %d NP %d: %.0f cycles per iteration, %.2f iterations per wave, clock %.0f MHz\n", NT, P1MASK, C2, NXN, NP,
                     (double)z[0] / (double)z[2], (double)z[2] / (double)z[3], (double)z[0] / (double)z[1] * 100.0);
 #endif

@@ -803,7 +803,7 @@ class EpsNetPlan(PlanBase):
 
     def _bglu(self, label, make, *, hp=None, F_in=None, x0=None, x1=None, taps, sf_in, Fout, p1mask=0, Fout1=0, slope, C2,
               bias, out=None, out_strides=None, out_off=0, nx_hp=None, nx_F=None, nx_row0=False, nx_add=None,
-              nx_out=(), nx_bias=(), hp_par=False, nx_par=False):
+              nx_out=(), nx_bias=(), hp_par=False, nx_par=False, skip_F=0):
         """Record one pdse_bglu_desc.  make(): -> dict of packed device pointers (memoised in the weight bank)."""
         B, T, npl = self.B, self.T, self.planes
         d = L.BgluDesc()
@@ -831,6 +831,7 @@ class EpsNetPlan(PlanBase):
             d.out = Ctx.ptr(out)
             d.out_sb, d.out_sc, d.out_st, d.out_sf = out_strides
             d.out_off = out_off
+        d.skip_Fh = (skip_F + 1) // 2 if (skip_F and self.parity_planes) else 0   # bins of the skip halves split by parity
         d.nx_n = (1 if nx_hp is not None else 0) + len(nx_out)
         if nx_hp is not None:
             shp = P.hp_shape(B + 1, T, nx_F, npl)
@@ -896,7 +897,7 @@ class EpsNetPlan(PlanBase):
             kwargs = dict(taps=taps, sf_in=2, Fout=Fo, slope=self._slope("en.en%d.1.weight" % k), C2=64, **src)
             if chained:
                 sk = [(self.Pskip[di][k], 32 * T * Fo, 4 * T * Fo, 4 * Fo, 4) for di in range(2)]   # [B + 1][8 groups][T][F][4]
-                kwargs.update(nx_hp=self.hp_en[k + 1], nx_F=Fo, nx_row0=True, nx_out=sk, nx_par=self.parity_planes,
+                kwargs.update(nx_hp=self.hp_en[k + 1], nx_F=Fo, nx_row0=True, nx_out=sk, nx_par=self.parity_planes, skip_F=Fo,
                               nx_bias=[(tb, slot(k), sbb)] + [(tb, slot(5 + 5 * di + (5 - k)), sbb) for di in range(2)])
             else:
                 kwargs.update(out=self.en[4], out_strides=(64 * 4 * T, 4 * T, 1, T))          # [B,64,4,T]
@@ -945,7 +946,7 @@ class EpsNetPlan(PlanBase):
                               slope=self._slope("%s.de%d.3.weight" % (de, k)) if k > 1 else 1.0, C2=C2,
                               bias=(None, 0, 0, None, None, 0))
                 if k > 1:
-                    kwargs.update(nx_hp=self.hp_de[k - 1], nx_F=Fo, nx_add=(self.Pskip[di][k - 1], 32 * T * Fo, 4 * T * Fo, 4 * Fo, 4),
+                    kwargs.update(nx_hp=self.hp_de[k - 1], nx_F=Fo, nx_add=(self.Pskip[di][k - 1], 32 * T * Fo, 4 * T * Fo, 4 * Fo, 4), skip_F=Fo,
                                   nx_bias=[(self.zero32, 0, 0)])
                 else:
                     kwargs.update(out=out, out_strides=(2 * T * F0, T * F0, F0, 2), out_off=di * T * F0)

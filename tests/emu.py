@@ -665,7 +665,8 @@ def run_bglu(d, mem):
                 bins = (2 * jI + ph) if d.p1mask else jI
                 if d.nx_add:
                     flat, off = mem.view(d.nx_add)
-                    idx = off + bI[:, None] * d.add_sb + (co >> 2) * d.add_sc + (co & 3) + tI[:, None] * d.add_st + bins[:, None] * d.add_sf   # groups of 4 channels
+                    bpos = ((bins & 1) * d.skip_Fh + (bins >> 1)) if d.skip_Fh else bins                     # bins split by parity
+                    idx = off + bI[:, None] * d.add_sb + (co >> 2) * d.add_sc + (co & 3) + tI[:, None] * d.add_st + bpos[:, None] * d.add_sf   # groups of 4 channels
                     idx = np.where(np.broadcast_to((jI < jmax)[:, None], Z.shape), np.broadcast_to(idx, Z.shape), off)
                     Z = Z + flat[idx]
                 Z = Z.astype(np.float32)
@@ -687,7 +688,8 @@ def run_bglu(d, mem):
             else:
                 flat, off = mem.view(d.nx_out[i - 1])
                 k_ = i - 1
-                idx = off + bI[:, None] * d.nx_sb[k_] + (co >> 2) * d.nx_sc[k_] + (co & 3) + tI[:, None] * d.nx_st[k_] + jI[:, None] * d.nx_sf[k_]
+                jp = ((jI & 1) * d.skip_Fh + (jI >> 1)) if d.skip_Fh else jI
+                idx = off + bI[:, None] * d.nx_sb[k_] + (co >> 2) * d.nx_sc[k_] + (co & 3) + tI[:, None] * d.nx_st[k_] + jp[:, None] * d.nx_sf[k_]
                 flat[np.broadcast_to(idx, Z.shape)] = Z.astype(np.float32)
 
 

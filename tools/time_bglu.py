@@ -71,6 +71,8 @@ def bench(name, NT, p1mask, C2, nx_n, Fin, Fout, Fout1, sf_in, taps, NP=3, B=32,
             add = torch.randn(B, 32, T, Fo + 1, device=DEV)
             keep.append(add)
             d.nx_add, d.add_sb, d.add_sc, d.add_st, d.add_sf = add.data_ptr(), add[0].numel(), 4 * T * (Fo + 1), 4 * (Fo + 1), 4   # [B][8][T][F][4]
+        if not os.environ.get("NOPAR"):   # skip halves with their bins split by parity (both the encoder's stores and the decoder's loads)
+            d.skip_Fh = (Fo + 2) // 2 if p1mask else (Fout + 1) // 2
         for i in range(nx_n):
             d.nx_bias[i], d.nx_bias_sb[i] = Fv(32 * B), 32
         for i in range(nx_n - 1):

@@ -46,6 +46,10 @@ def run(split, B=32, T=401, plane_h=None, planes=None):
 
 
 if __name__ == "__main__":
+    if os.environ.get("BSWEEP"):          # batch-size sweep of the default form (does a smaller working set run faster per item?)
+        for B_ in (32, 16, 8, 4):
+            run(True, B=B_)
+        sys.exit(0)
     run(False)
     run(True, plane_h=False)
     run(True)
