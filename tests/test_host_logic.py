@@ -28,9 +28,9 @@ def test_pack_roundtrip():
     assert sorted(P.RHO.reshape(-1).tolist()) == list(range(32))
 
 
-@pytest.mark.parametrize("chained,split,plane_h", [(True, False, False), (False, False, False), (True, True, False),
-                                                  (True, True, True)])
-def test_eps_net_plan_vs_oracle(weights, chained, split, plane_h, monkeypatch):
+@pytest.mark.parametrize("chained,split,plane_h,parity", [(True, False, False, True), (False, False, False, True), (True, True, False, True),
+                                                         (True, True, True, True), (True, True, True, False)])
+def test_eps_net_plan_vs_oracle(weights, chained, split, plane_h, parity, monkeypatch):
     """chained: every stage's conv1 rides on the previous stage's tail and the encoder/decoder block outputs are never
     stored (only en[4], the TCM input, is); unchained: the per-stage launches with all intermediates in memory.
     split: the BIGLU blocks' weights as exact three-way bf16 splits in bf16 MFMA fragment order (korder 2)."""
@@ -38,6 +38,8 @@ def test_eps_net_plan_vs_oracle(weights, chained, split, plane_h, monkeypatch):
     monkeypatch.setattr(nets.EpsNetPlan, "chain_conv1", chained)
     monkeypatch.setattr(nets.EpsNetPlan, "split_bf16", split)
     monkeypatch.setattr(nets.EpsNetPlan, "plane_h", plane_h)      # csrc/bglu.hip: conv1 outputs as bf16 split planes
+    monkeypatch.setattr(nets.EpsNetPlan, "parity_planes", parity)  # encoder planes / skip halves with their bins split by parity
+    lib = pkg("_lib")
     B, T = 2, 12
     sd = weights("DiffUNet1")
     ctx = nets.Ctx("cpu")
@@ -50,6 +52,10 @@ def test_eps_net_plan_vs_oracle(weights, chained, split, plane_h, monkeypatch):
     n_split = sum(1 for d, _ in net.descs if isinstance(d, pkg("_lib").GconvDesc) and d.korder == 2)
     assert n_split == (15 - n_planes if split else 0)     # encoder stages 1-5 + 2 x 5 decoder stages
     assert sum(1 for d, _ in net.descs if isinstance(d, pkg("_lib").BgluDesc)) == n_planes
+    if plane_h:   # encoders 2-5 read parity-split planes, encoders 1-4 write them and the skip halves, decoders 5-2 read those
+        bg = [d for d, _ in net.descs if isinstance(d, lib.BgluDesc)]
+        assert sum(d.hp_par for d in bg) == (4 if parity else 0) and sum(d.nx_par for d in bg) == (4 if parity else 0)
+        assert sum(1 for d in bg if d.skip_Fh) == (12 if parity else 0)
     n_tcm2 = sum(1 for d, _ in net.descs if isinstance(d, pkg("_lib").Tcm2Desc))
     assert n_tcm2 == (19 if split else 0)             # the first block's conv1 + 18 residual blocks (csrc/tcm2.hip)
     x, xi = seeded((B, 2, T, 161), 3), seeded((B, 2, T, 161), 4) * 0.3
@@ -72,14 +78,15 @@ def test_eps_net_plan_vs_oracle(weights, chained, split, plane_h, monkeypatch):
             Pk.tcm2_join_h(hs.numpy().view(np.uint16), B, T)
 
 
-@pytest.mark.parametrize("fused_glstm,split", [(True, True), (False, True), (True, False)])
-def test_gcrn_and_diffunet_prior_plans_vs_oracle(weights, fused_glstm, split, monkeypatch):
+@pytest.mark.parametrize("fused_glstm,split,block8", [(True, True, True), (False, True, True), (True, False, True), (True, True, False)])
+def test_gcrn_and_diffunet_prior_plans_vs_oracle(weights, fused_glstm, split, block8, monkeypatch):
     """fused_glstm: both LSTM layers + LayerNorm 1 as one layer-wavefront operator (LayerNorm folded into the layer-2
     input projection, permuted K order); False: two per-frame LSTM operators with the LayerNorm and projections between.
     split: the gated convolutions / input projections packed for the split-bf16 GEMM kernel (korder 3)."""
     nets = pkg("nets")
     monkeypatch.setattr(nets.GcrnPlan, "fused_glstm", fused_glstm)
     monkeypatch.setattr(nets.GcrnPlan, "split_bf16", split)
+    monkeypatch.setattr(nets.GcrnPlan, "block8", block8)          # tensors between the GEMM convolutions in blocks of 8 channels
     B, T = 2, 10
     x = seeded((B, 2, T, 161), 5)
     ctx = nets.Ctx("cpu")
@@ -87,6 +94,8 @@ def test_gcrn_and_diffunet_prior_plans_vs_oracle(weights, fused_glstm, split, mo
     net.build()
     n3 = sum(1 for d, _ in net.descs if isinstance(d, pkg("_lib").GconvDesc) and d.korder == 3)
     assert n3 == ((4 + 16 + (2 if fused_glstm else 4)) if split else 0)   # encoder 2-5, 2 x 4 x 2 decoder phases, projections
+    nblk = sum(1 for d, _ in net.descs if isinstance(d, pkg("_lib").GconvDesc) and d.in0.blk)
+    assert nblk == (3 + 2 + 16 if (split and block8) else 0)               # encoders 3-5, the layer-1 projections, every decoder launch
     net.x.copy_(x)
     emu.run(net.descs, ctx.all_tensors())
     taps = {}
