@@ -135,22 +135,25 @@ int pdse_chln_launch(const pdse_chln_desc* d, hipStream_t s) {
 // rows), each thread owns (query position, head) pairs and runs an online softmax over the keys.
 // E = 32, 4 heads of 8 (dbaiat.py:123-126); sequence 80 (bins) or T (frames).
 // ---------------------------------------------------------------------------------------
-// 1024 threads (4 waves per SIMD hide the LDS latency of the serial key loop); keys are taken
-// four at a time so the running maximum is rescaled once per block instead of once per key.
+// One workgroup per (line, batch item, HEAD) since round 3: K and V of one head are 2 x S x HD floats (25.7 KB at S = 401,
+// HD = 8), so four to five workgroups share a CU and every thread owns ONE query; keys are taken four at a time so the
+// running maximum is rescaled once per block instead of once per key.  (Until then a workgroup of 1024 threads held all four
+// heads of a line - 100 KB of LDS, one workgroup per CU - and walked its 4 S (query, head) items in rounds of 1024: the
+// second round of a 401-position line ran 56 % full.  Measured at B=32: S = 401 1.45 -> see profiles/r03_prior_per_launch.txt.)
 #define ATTN_THREADS 1024
-// HD = head dimension (8: d_model 32, 16: d_model 64; always 4 heads).  A workgroup handles one 32-channel window
-// of one line (32 / HD heads), so K and V of the window fit LDS for sequences up to 640 positions.
-// Sequences longer than one LDS image (S > 640: 10 s utterances, T = 1001) are walked in key chunks of CH positions:
-// K and V of a chunk are staged, every thread advances the online softmax of its (query, head) items over the chunk
+// HD = head dimension (8: d_model 32, 16: d_model 64; always 4 heads).
+// Sequences longer than one LDS image (S > 2048: never on this path) would be walked in key chunks of CH positions:
+// K and V of a chunk are staged, every thread advances the online softmax of its query over the chunk
 // and keeps (m, l, acc) in registers across chunks.  Chunks are multiples of four keys, so the rescale grouping - and
 // with it every rounding - is the one a single image would give.
 template <int HD>
 __global__ __launch_bounds__(ATTN_THREADS) void attn_kernel(const pdse_attn_desc d, const int CH) {
-  extern __shared__ float kv[];  // [CH][32] keys, then [CH][32] values
-  constexpr int W = 32, HW = W / HD;
+  extern __shared__ float kv[];  // [CH][HD] keys, then [CH][HD] values
+  constexpr int W = HD;
   const int E = d.E;
-  const int b = blockIdx.y, line = blockIdx.x, c0 = blockIdx.z * W;
+  const int b = blockIdx.y, line = blockIdx.x, c0 = blockIdx.z * W;   // blockIdx.z: head
   const int S = d.axis == 0 ? d.F : d.T;
+  const int NT = blockDim.x;
   const int64_t plane = (int64_t)d.T * d.F;
   const int64_t base = (int64_t)b * 3 * E * plane + (d.axis == 0 ? (int64_t)line * d.F : (int64_t)line);
   const int64_t ss = d.axis == 0 ? 1 : d.F;
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(ATTN_THREADS) void attn_kernel(const pdse_attn_desc
   float* vs = kv + (size_t)CH * W;
   const bool single = CH >= S;
   auto stage = [&](const int k0, const int n) {
-    for (int i = threadIdx.x; i < n * W; i += ATTN_THREADS) {
+    for (int i = threadIdx.x; i < n * W; i += NT) {
       const int e = i / n, sp = i - e * n;  // consecutive threads -> consecutive sequence positions
       ks[sp * W + e] = d.qkv[base + (int64_t)(E + c0 + e) * plane + (int64_t)(k0 + sp) * ss];
       vs[sp * W + e] = d.qkv[base + (int64_t)(2 * E + c0 + e) * plane + (int64_t)(k0 + sp) * ss];
@@ -169,20 +172,20 @@ __global__ __launch_bounds__(ATTN_THREADS) void attn_kernel(const pdse_attn_desc
     __syncthreads();
   }
   const int64_t obase = (int64_t)b * E * plane + (d.axis == 0 ? (int64_t)line * d.F : (int64_t)line);
-  const int rounds = (S * HW + ATTN_THREADS - 1) / ATTN_THREADS;   // uniform trip count: the chunk loop holds barriers
+  const int rounds = (S + NT - 1) / NT;   // uniform trip count: the chunk loop holds barriers
   for (int round = 0; round < rounds; ++round) {
-    const int idx = round * ATTN_THREADS + threadIdx.x;
-    const bool valid = idx < S * HW;
-    const int hd = valid ? idx / S : 0, sq = valid ? idx - hd * S : 0;
+    const int idx = round * NT + threadIdx.x;
+    const bool valid = idx < S;
+    const int sq = valid ? idx : 0;
     float q[HD], acc[HD];
 #pragma unroll
     for (int e = 0; e < HD; ++e) {
-      q[e] = valid ? d.qkv[base + (int64_t)(c0 + hd * HD + e) * plane + (int64_t)sq * ss] : 0.f;
+      q[e] = valid ? d.qkv[base + (int64_t)(c0 + e) * plane + (int64_t)sq * ss] : 0.f;
       acc[e] = 0.f;
     }
     float m = -1e30f, l = 0.f;
-    const float* kh = ks + hd * HD;
-    const float* vh = vs + hd * HD;
+    const float* kh = ks;
+    const float* vh = vs;
     for (int k0 = 0; k0 < S; k0 += CH) {
       const int n = min(CH, S - k0);
       if (!single) {
@@ -238,7 +241,7 @@ __global__ __launch_bounds__(ATTN_THREADS) void attn_kernel(const pdse_attn_desc
     if (valid) {
       const float inv = 1.0f / l;
 #pragma unroll
-      for (int e = 0; e < HD; ++e) d.out[obase + (int64_t)(c0 + hd * HD + e) * plane + (int64_t)sq * ss] = acc[e] * inv;
+      for (int e = 0; e < HD; ++e) d.out[obase + (int64_t)(c0 + e) * plane + (int64_t)sq * ss] = acc[e] * inv;
     }
   }
 }
@@ -249,18 +252,20 @@ int pdse_attn_launch(const pdse_attn_desc* d, hipStream_t s) {
       "attention: 4 heads, d_model 32 or 64 (dbaiat.py:123-126, :186-189)");
   REQ(d->axis == 0 || d->axis == 1, "attention: axis 0 (bins) or 1 (frames)");
   const int S = d->axis == 0 ? d->F : d->T, lines = d->axis == 0 ? d->T : d->F;
-  // one LDS image when the sequence fits (S <= 640), else key chunks of 512 positions (128 KB; a multiple of four keys)
-  const int CH = S <= 640 ? S : 512;
-  const size_t lds = (size_t)2 * CH * 32 * sizeof(float);
+  const int HD = d->E / 4;
+  // one LDS image of the head's K and V when the sequence fits (S <= 2048), else key chunks of 2048 positions (a multiple of four keys)
+  const int CH = S <= 2048 ? S : 2048;
+  const size_t lds = (size_t)2 * CH * HD * sizeof(float);
   const void* fn = d->E == 32 ? (const void*)attn_kernel<8> : (const void*)attn_kernel<16>;
   if (lds > 64 * 1024)
     if (pdse_check_hip(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "attention lds attribute"))
       return 1;
-  const dim3 grid(lines, d->B, d->E / 32);
+  const int nt = S >= ATTN_THREADS ? ATTN_THREADS : (S + 63) / 64 * 64;   // one query per thread, whole waves
+  const dim3 grid(lines, d->B, 4);
   if (d->E == 32)
-    hipLaunchKernelGGL(attn_kernel<8>, grid, dim3(ATTN_THREADS), lds, s, *d, CH);
+    hipLaunchKernelGGL(attn_kernel<8>, grid, dim3(nt), lds, s, *d, CH);
   else
-    hipLaunchKernelGGL(attn_kernel<16>, grid, dim3(ATTN_THREADS), lds, s, *d, CH);
+    hipLaunchKernelGGL(attn_kernel<16>, grid, dim3(nt), lds, s, *d, CH);
   return pdse_check_launch("attention");
 }
 
