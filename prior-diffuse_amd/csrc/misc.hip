@@ -407,8 +407,8 @@ __device__ __forceinline__ float gl_exp(float x) { return __builtin_amdgcn_exp2f
 __global__ __launch_bounds__(512, 2) void gcrnlast_kernel(const pdse_gcrnlast_desc d) {
   __shared__ float xs[32 * GL_FI];          // inputs of the current row (ELU already applied to the skip)
   __shared__ __attribute__((aligned(16))) float ys[164];   // gated, normalised, activated bins (padded to a multiple of 4)
-  __shared__ float wl[192];                 // [32][3] main, then [32][3] gate
   __shared__ float pm[2][GL_F], pg[2][GL_F], pf[GL_F];   // partial sums of the second thread half
+  __shared__ __attribute__((aligned(16))) float4 wl4[2][32];
   const int tid = threadIdx.x;
   const int o = tid & 255, half = tid >> 8;  // output bin, K half (conv: channels 16*half.., Linear: inputs 84*half..)
   const bool act = o < GL_F;
@@ -425,11 +425,14 @@ __global__ __launch_bounds__(512, 2) void gcrnlast_kernel(const pdse_gcrnlast_de
   }
   if (tid < 3) ys[GL_F + tid] = 0.f;
   if (tid < 4) ys[160 + tid] = 0.f;
-  if (tid < 96) {
-    wl[tid] = d.w1[tid];
-    wl[96 + tid] = d.w2[tid];
-  }
   const float fcb = (act && half == 0) ? d.fcb[o] : 0.f;
+  // wl4[parity][c] = (main weight of x[j], of x[j-1], gate weight of x[j], of x[j-1]) of channel c for even / odd output bins
+  // (even bin 2j <- tap 0 at j, tap 2 at j-1; odd bin 2j+1 <- tap 1 at j): one 16-byte LDS read per channel instead of two to four
+  const bool odd = (o & 1) != 0;
+  if (tid < 64) {
+    const int c = tid & 31, par = tid >> 5;
+    wl4[par][c] = par ? make_float4(d.w1[3 * c + 1], 0.f, d.w2[3 * c + 1], 0.f) : make_float4(d.w1[3 * c], d.w1[3 * c + 2], d.w2[3 * c], d.w2[3 * c + 2]);
+  }
   const int64_t plane = (int64_t)d.T * GL_FI;
   const int rows = d.B * d.T;
   // this thread's five (channel, bin) items of a row: element e = tid + 512*i, channel e / 80
@@ -458,23 +461,17 @@ __global__ __launch_bounds__(512, 2) void gcrnlast_kernel(const pdse_gcrnlast_de
     __syncthreads();
     float m = 0.f, g = 0.f;
     if (act) {
-      // ConvTranspose (1,3) stride 2: even bin 2j <- tap 0 at j, tap 2 at j-1; odd bin 2j+1 <- tap 1 at j
+      // ConvTranspose (1,3) stride 2: even bin 2j <- tap 0 at j, tap 2 at j-1; odd bin 2j+1 <- tap 1 at j.  The thread's
+      // weights come as one float4 per channel (wl4)
       const int j = o >> 1, c0 = 16 * half;
-      if (o & 1) {
+      const bool has0 = odd || j < GL_FI, has2 = !odd && j >= 1;     // bin 160 = 2 * 80 has no tap 0, bin 0 no tap 2
+      const int j0 = has0 ? j : GL_FI - 1, j2 = has2 ? j - 1 : 0;
 #pragma unroll
-        for (int c = c0; c < c0 + 16; ++c) {
-          const float x = xs[c * GL_FI + j];
-          m += x * wl[3 * c + 1];
-          g += x * wl[96 + 3 * c + 1];
-        }
-      } else {
-        const bool a = j < GL_FI, p = j >= 1;
-#pragma unroll
-        for (int c = c0; c < c0 + 16; ++c) {
-          const float x0 = a ? xs[c * GL_FI + j] : 0.f, x2 = p ? xs[c * GL_FI + j - 1] : 0.f;
-          m += x0 * wl[3 * c] + x2 * wl[3 * c + 2];
-          g += x0 * wl[96 + 3 * c] + x2 * wl[96 + 3 * c + 2];
-        }
+      for (int k = 0; k < 16; ++k) {
+        const float4 w = wl4[odd ? 1 : 0][c0 + k];
+        const float x0 = has0 ? xs[(c0 + k) * GL_FI + j0] : 0.f, x2 = has2 ? xs[(c0 + k) * GL_FI + j2] : 0.f;
+        m += x0 * w.x + x2 * w.y;
+        g += x0 * w.z + x2 * w.w;
       }
       if (half) {
         pm[1][o] = m;
