@@ -364,6 +364,23 @@ def test_aia_prior_golden_and_oracle(L, weights, R):
     assert rel_l2(big, golden("full_aia_seed61_t401")["out"]) < 1e-4       # the reference module at T = 401
 
 
+def test_split_gru_matches_fp32_gru_kernel(L, weights, monkeypatch):
+    """csrc/gru3.hip (the fused H = 64 GRU on exact three-way bf16 operand splits, fast tanh) against the fp32 MFMA kernel it
+    replaces (csrc/aia.hip gru_kernel<64, true>, tanhf): same prior, T = 401 and a ragged line count, fp32-level agreement."""
+    nets = pkg("nets")
+    x = seeded((3, 2, 401, 161), 71)
+    outs = {}
+    for split in (True, False):
+        monkeypatch.setattr(nets.AiaPlan, "split_gru", split)
+        op = pkg("ops").AiaOp(weights("aia_complex_trans_ri"), DEV)
+        outs[split] = op(x.to(DEV)).cpu()
+        net = op._plans[(3, 401)]
+        assert sum(1 for d, _ in net.descs if isinstance(d, L.GruDesc) and d.split) == (8 if split else 0)
+    e = rel_l2(outs[True], outs[False])
+    print("split-bf16 GRU vs fp32 GRU kernel: %.2e" % e)
+    assert e < 5e-6
+
+
 def test_dual_branch_aia_prior_golden_and_oracle(L, weights, R):
     """Dual-branch DB-AIAT prior (dual_aia_trans_merge_crm, d_model 64): golden vectors of the reference module
     at T=12 with intermediates, then the oracle at T=401 (attention and GRU over 401 frames)."""
