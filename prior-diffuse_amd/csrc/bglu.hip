@@ -340,6 +340,16 @@ __global__ __launch_bounds__(PIPE ? 256 : 512, PIPE ? 1 : 2) void bglu_kernel(co
     const int bpos = d.nx_par ? (bi & 1) * ((nFp + 1) >> 1) + (bi >> 1) : bi;
     const uint32_t o = ok ? (uint32_t)b * item_hp + ((uint32_t)(((t + d.nx_t0) * 4 + h) * (NP * nFp) + bpos) << 4)
                           : (uint32_t)d.B * item_hp + ((uint32_t)(h * (NP * nFp)) << 4);
+#if defined(BGLU_DIAG) && defined(BGLU_ONE_STORER)   // timing ablation (results wrong): wave 7 issues the plane stores of all eight waves
+    if (wave != 7) return;
+#pragma unroll
+    for (int k_ = 0; k_ < 8; ++k_)
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) bstore16<BGLU_ST_AUX>(zp[q][pl], r_nx, o + (uint32_t)(k_ * 4 * NP * nFp * 16), ((2 * q * NP + pl) * nFp) << 4);
+    return;
+#endif
 #pragma unroll
     for (int q = 0; q < 2; ++q)
 #pragma unroll
