@@ -99,6 +99,9 @@ def main():
                     help="the opt-in bf16 mode (BASELINE configs 2/4/5): plain bf16 operands and bf16 conv1 tensors in the "
                          "eps-net's BiConv(Trans)GLU blocks (SamplerPipeline(dtype='bf16')); own tolerance (3e-2), dtype 'bf16' "
                          "in the line - never the graded default")
+    ap.add_argument("--no-file-loop", action="store_true",
+                    help="skip the B = 1 generate_wav file loop reported as file_loop_b1 (profiling runs: keeps its B = 1 launches "
+                         "out of the kernel trace, so that per-kernel averages of the trace are B = 32 launches only)")
     ap.add_argument("--no-fp32-compare", action="store_true",
                     help="skip the extra exact-fp32 pass reported as fp32_exact (profiling runs: keeps its kernels out of the trace)")
     ap.add_argument("--dry-run", action="store_true",
@@ -371,7 +374,7 @@ def main():
         roofline["peak_note"] = "bf16 mode: blocks issue ONE bf16 MFMA product per multiply-add: roof of their algorithmic FLOP rate = dense bf16 peak"
     # ---- the reference's own entry point: generate_wav, B = 1, one 4 s file after the other (wav read -> enhance -> wav write)
     file_loop = None
-    if fast and args.prior == "GCRN" and not args.bf16:
+    if fast and args.prior == "GCRN" and not args.bf16 and not args.no_file_loop:
         import argparse as _ap
         import tempfile
 
@@ -408,6 +411,7 @@ def main():
     if not args.no_cpu_baseline:
         from oracle import restate as R
 
+        t_cpu0 = time.perf_counter()
         params = importlib.import_module("prior-diffuse_amd.params").params
         # the GPU box gives one GPU a 16-core share of the host; never oversubscribe it
         nthreads = max(1, min(16, len(os.sched_getaffinity(0))))
@@ -427,6 +431,7 @@ def main():
                 R.enhance(args.prior, gs, ds, w_cpu, x_cpu, params.noise_schedule, params.inference_noise_schedule, fast)
                 runs.append(time.perf_counter() - tc)
         tc = sorted(runs)[1]
+        cpu_leg_s = time.perf_counter() - t_cpu0
         model = "unknown"
         try:
             with open("/proc/cpuinfo") as f:
@@ -434,7 +439,7 @@ def main():
         except OSError:
             pass
         cpu = {"value": round(cb * args.seconds / tc, 3), "unit": "audio_s/s", "cores": nthreads, "kind": "port",
-               "cpu_model": model,
+               "cpu_model": model, "leg_wall_s": round(cpu_leg_s, 1),
                "sample": "oracle (torch-CPU fp32 restatement), %d of the %d utterances in one batch, full path incl. "
                          "STFT/ISTFT, 1-utterance warm-up + median of 3 timed runs (%s s)" % (
                              cb, B, " / ".join("%.1f" % r for r in runs))}

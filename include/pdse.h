@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define PDSE_ABI_VERSION 5
+#define PDSE_ABI_VERSION 6
 
 typedef void* pdse_stream_t; /* hipStream_t */
 
@@ -338,6 +338,34 @@ typedef struct pdse_glstm_desc {
   int32_t B, Bp, T, H, G;
   float eps;
 } pdse_glstm_desc;
+
+/* The same grouped LSTM (both layers + LayerNorm 1, gcrn.py:22-35) as ONE persistent launch for small batches
+ * (1 <= B <= 8; ABI 6, csrc/lstmp.hip): 256 co-resident workgroups keep their gate rows in registers for all frames and
+ * exchange the state of a frame through 8-byte {tag, value} granules.  The caller must own the device while it runs
+ * (one batch in flight): workgroups wait for each other.  Every wait is bounded; a launch that could not complete
+ * leaves the step it gave up at (+1) in *status, which the caller zeroes once and reads after synchronising.
+ *   gx1   [G][T][Bp][4H]     as pdse_glstm_desc.gx1
+ *   w1    [G][H][4][H]       W_hh of layer 1: w1[g][u][q][k] = weight_hh_l0[q*H + u][k] (gate order i,f,g,o)
+ *   w2i   [G][H][4][H]       W_ih of layer 2 times diag(gamma_ln1), chunk g of the interleaved layer-1 output: k = feature
+ *                            2 u' + g' - H g of the LayerNorm input (natural column order of weight_ih_l0)
+ *   w2h   [G][H][4][H]       W_hh of layer 2
+ *   r2, c2 [G][4H]           as pdse_glstm_desc
+ *   gran  [4][2H][Bq] 8-byte granules (Bq = B rounded up to 1, 2, 4, 8), 16-byte aligned; zeroed by every launch
+ *   y     layer-2 output, y[b*y_sb + t*y_st + u*y_su + g*y_sg] */
+typedef struct pdse_glstmp_desc {
+  const float* gx1;
+  const float* w1;
+  const float* w2i;
+  const float* w2h;
+  const float* r2;
+  const float* c2;
+  unsigned long long* gran;
+  int32_t* status;
+  float* y;
+  int64_t y_sb, y_st, y_su, y_sg;
+  int32_t B, Bp, T, H, G;
+  float eps;
+} pdse_glstmp_desc;
 
 /* ---- DB-AIAT prior (model/dbaiat.py), channel-major [B,C,T,F] tensors ------------------- */
 
@@ -654,7 +682,8 @@ enum pdse_op_kind {
   PDSE_OP_GLSTM = 21,
   PDSE_OP_TCM2 = 22,
   PDSE_OP_BGLU = 23,
-  PDSE_OP_PLANES = 24
+  PDSE_OP_PLANES = 24,
+  PDSE_OP_GLSTMP = 25
 };
 
 int pdse_abi_version(void);
@@ -685,6 +714,7 @@ int pdse_crm_f32(const pdse_crm_desc* d, pdse_stream_t s);
 int pdse_gcrnlast_f32(const pdse_gcrnlast_desc* d, pdse_stream_t s);
 int pdse_masked_mse_f32(const pdse_maskloss_desc* d, pdse_stream_t s);
 int pdse_glstm_f32(const pdse_glstm_desc* d, pdse_stream_t s);
+int pdse_glstm_persistent_f32(const pdse_glstmp_desc* d, pdse_stream_t s);
 int pdse_tcm2_bf16x3(const pdse_tcm2_desc* d, pdse_stream_t s);
 int pdse_bglu_planes(const pdse_bglu_desc* d, pdse_stream_t s);
 int pdse_split_planes(const pdse_planes_desc* d, pdse_stream_t s);

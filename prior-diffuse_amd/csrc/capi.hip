@@ -56,6 +56,7 @@ union pdse_any_desc {
   pdse_gcrnlast_desc gcrnlast;
   pdse_maskloss_desc maskloss;
   pdse_glstm_desc glstm;
+  pdse_glstmp_desc glstmp;
   pdse_bglu_desc bglu;
   pdse_planes_desc planes;
 };
@@ -115,6 +116,7 @@ static int op_size(int kind) {
     case PDSE_OP_GCRNLAST: return (int)sizeof(pdse_gcrnlast_desc);
     case PDSE_OP_MASKLOSS: return (int)sizeof(pdse_maskloss_desc);
     case PDSE_OP_GLSTM: return (int)sizeof(pdse_glstm_desc);
+    case PDSE_OP_GLSTMP: return (int)sizeof(pdse_glstmp_desc);
     case PDSE_OP_BGLU: return (int)sizeof(pdse_bglu_desc);
     case PDSE_OP_PLANES: return (int)sizeof(pdse_planes_desc);
     default: return -1;
@@ -145,6 +147,7 @@ static int launch_op(const pdse_op& op, hipStream_t s) {
     case PDSE_OP_GCRNLAST: return pdse_gcrnlast_launch(&op.d.gcrnlast, s);
     case PDSE_OP_MASKLOSS: return pdse_maskloss_launch(&op.d.maskloss, s);
     case PDSE_OP_GLSTM: return pdse_glstm_launch(&op.d.glstm, s);
+    case PDSE_OP_GLSTMP: return pdse_glstmp_launch(&op.d.glstmp, s);
     case PDSE_OP_TCM2: return pdse_tcm2_launch(&op.d.tcm2, s);
     case PDSE_OP_BGLU: return pdse_bglu_launch(&op.d.bglu, s);
     case PDSE_OP_PLANES: return pdse_planes_launch(&op.d.planes, s);
@@ -180,6 +183,7 @@ int pdse_crm_f32(const pdse_crm_desc* d, pdse_stream_t s) { return pdse_crm_laun
 int pdse_gcrnlast_f32(const pdse_gcrnlast_desc* d, pdse_stream_t s) { return pdse_gcrnlast_launch(d, (hipStream_t)s); }
 int pdse_masked_mse_f32(const pdse_maskloss_desc* d, pdse_stream_t s) { return pdse_maskloss_launch(d, (hipStream_t)s); }
 int pdse_glstm_f32(const pdse_glstm_desc* d, pdse_stream_t s) { return pdse_glstm_launch(d, (hipStream_t)s); }
+int pdse_glstm_persistent_f32(const pdse_glstmp_desc* d, pdse_stream_t s) { return pdse_glstmp_launch(d, (hipStream_t)s); }
 int pdse_tcm2_bf16x3(const pdse_tcm2_desc* d, pdse_stream_t s) { return pdse_tcm2_launch(d, (hipStream_t)s); }
 int pdse_bglu_planes(const pdse_bglu_desc* d, pdse_stream_t s) { return pdse_bglu_launch(d, (hipStream_t)s); }
 int pdse_split_planes(const pdse_planes_desc* d, pdse_stream_t s) { return pdse_planes_launch(d, (hipStream_t)s); }

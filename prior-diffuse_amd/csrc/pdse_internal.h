@@ -47,6 +47,7 @@ int pdse_crm_launch(const pdse_crm_desc* d, hipStream_t s);
 int pdse_gcrnlast_launch(const pdse_gcrnlast_desc* d, hipStream_t s);
 int pdse_maskloss_launch(const pdse_maskloss_desc* d, hipStream_t s);
 int pdse_glstm_launch(const pdse_glstm_desc* d, hipStream_t s);
+int pdse_glstmp_launch(const pdse_glstmp_desc* d, hipStream_t s);   /* csrc/lstmp.hip */
 int pdse_tcm2_launch(const pdse_tcm2_desc* d, hipStream_t s);
 int pdse_bglu_launch(const pdse_bglu_desc* d, hipStream_t s);
 int pdse_planes_launch(const pdse_planes_desc* d, hipStream_t s);

@@ -1111,16 +1111,25 @@ class GcrnPlan(PlanBase):
     fused_glstm = True      # both LSTM layers + LayerNorm 1 as a layer wavefront, T + 2 launches (pdse_glstm_desc)
     split_bf16 = True       # gated (transposed) convolutions and the LSTM input projection as split-bf16 GEMMs (csrc/gconv4.hip)
     block8 = True           # tensors between those GEMMs in blocks of 8 channels (16-byte gathers and stores)
+    persist_lstm = True     # B <= PERSIST_MAX_B and a plan that owns the GPU while it runs: the grouped LSTM as ONE persistent
+                            # launch with register-resident weights (pdse_glstmp_desc, csrc/lstmp.hip) instead of T + 2 launches
+    PERSIST_MAX_B = 4       # measured (tools/time_glstm.py --persist): 3.9 / 6.0 / 9.0 / 21.8 us per step at B = 1 / 2 / 4 / 8 against 11.4-12.0 for the wavefront
     ENC_C = [2, 16, 32, 64, 128, 256]
     ENC_F = [161, 80, 39, 19, 9, 4]
 
-    def __init__(self, ctx, sd, B, T, plan=None, split_bf16=None):
+    def __init__(self, ctx, sd, B, T, plan=None, split_bf16=None, exclusive=False):
+        """exclusive: nothing else runs on the GPU beside this plan (one batch in flight) - the condition under which the
+        persistent LSTM may be used (its 256 workgroups wait for each other and must all be resident).  Off by default: a
+        plan built with it takes another LSTM kernel at B <= PERSIST_MAX_B than at larger B, so an utterance's result is
+        within 1e-5 of, not bit-identical to, the same utterance in a larger batch or shard."""
         if split_bf16 is not None:
             self.split_bf16 = bool(split_bf16)
-        super().__init__(ctx, plan, ns=(ctx.bank.token(sd), self.fused_last, self.fused_glstm, self.split_bf16, self.block8))
+        self.persist = bool(self.persist_lstm and self.fused_glstm and exclusive and B <= self.PERSIST_MAX_B and not self.force_generic)
+        super().__init__(ctx, plan, ns=(ctx.bank.token(sd), self.fused_last, self.fused_glstm, self.split_bf16, self.block8, self.persist))
         self.sd, self.B, self.T = sd, B, T
         a = ctx.alloc
         self.Bp = Bp = (B + 31) // 32 * 32
+        self.status = None
         self.x = a(B, 2, T, F0)
         self.out = a(B, 2, T, F0)
         self.e = [a(B, self.ENC_C[i + 1], T, self.ENC_F[i + 1]) for i in range(5)]
@@ -1128,7 +1137,12 @@ class GcrnPlan(PlanBase):
         self.hT = a(2, 2, 512, Bp, zero=True)
         self.cst = a(2, 512, Bp, zero=True)
         self.y = a(B, T, 1024)
-        if self.fused_glstm and not self.force_generic:
+        if self.persist:
+            bq = 1 << (B - 1).bit_length()
+            self.gran = torch.zeros(4 * 1024 * bq, dtype=torch.int64, device=ctx.device)   # {tag, value} granules, zeroed by every launch
+            self.status = torch.zeros(4, dtype=torch.int32, device=ctx.device)             # [0]: 0 = completed, s + 1 = gave up at step s
+            ctx.keep += [self.gran, self.status]
+        elif self.fused_glstm and not self.force_generic:
             self.hT2, self.cst2 = a(2, 2, 512, Bp, zero=True), a(2, 512, Bp, zero=True)
             self.gx2, self.part = a(2, 2, 2048, Bp, zero=True), a(2, 2, 64, Bp, 2, zero=True)
         else:
@@ -1219,6 +1233,43 @@ class GcrnPlan(PlanBase):
         d.B, d.Bp, d.T, d.H, d.G, d.eps = B, Bp, T, 512, 2, 1e-5
         self.add(d, TAG_LSTM)
 
+    def _glstm_persistent(self, proj1):
+        """gcrn.py:22-35 as ONE persistent launch (csrc/lstmp.hip, pdse_glstmp_desc): layer 1 at frame s, LayerNorm 1 +
+        layer 2 at frame s - 1, weights in registers, the state exchanged between the 256 workgroups every step."""
+        B, T, Bp = self.B, self.T, self.Bp
+        for g in range(2):
+            p = "glstm.lstm_list1.%d." % g
+            in0, Tin, Fin, taps, wk_fn, Tout, Fout, ost, osf = proj1(g)
+            self.gconv(in0=in0, Tin=Tin, Fin=Fin, taps=taps, sf_in=1, Cout=2048,
+                       W=lambda p=p, wk_fn=wk_fn: dict(wk0=wk_fn(self.w(p + "weight_ih_l0")),
+                                                       bias0=self.w(p + "bias_ih_l0") + self.w(p + "bias_hh_l0")),
+                       out=self.gx, out_strides=(2048, 1, 0, ost, osf), out_off=g * T * 2048 * Bp, B=B, Tout=Tout, Fout=Fout,
+                       tag=TAG_PRIOR, label=p + "ih", s3g=self.split_bf16)      # gx1 [G][T][Bp][4H]
+
+        def pack():
+            up = lambda a: self.ctx.up(a).data_ptr()   # noqa: E731
+            gam, bet = self.w("glstm.ln1.weight"), self.w("glstm.ln1.bias")
+            rows = lambda W: np.ascontiguousarray(np.asarray(W, np.float32).reshape(4, 512, 512).transpose(1, 0, 2))   # noqa: E731  [u][q][k]
+            w1 = np.stack([rows(self.w("glstm.lstm_list1.%d.weight_hh_l0" % g)) for g in range(2)], 0)
+            w2h = np.stack([rows(self.w("glstm.lstm_list2.%d.weight_hh_l0" % g)) for g in range(2)], 0)
+            w2i, r2, c2 = [], [], []
+            for g in range(2):
+                p = "glstm.lstm_list2.%d." % g
+                Wih = self.w(p + "weight_ih_l0")                                     # [2048, 512] over chunk g of LN1's output
+                Wf = Wih * gam[512 * g:512 * g + 512][None, :]                       # LayerNorm scale folded in
+                w2i.append(rows(Wf))
+                r2.append(Wf.sum(1))
+                c2.append(Wih @ bet[512 * g:512 * g + 512] + self.w(p + "bias_ih_l0") + self.w(p + "bias_hh_l0"))
+            return dict(w1=up(w1), w2h=up(w2h), w2i=up(np.stack(w2i, 0)), r2=up(np.stack(r2, 0)), c2=up(np.stack(c2, 0)))
+
+        d = L.GlstmpDesc()
+        for k, v in self.memo("glstm.persistent", pack).items():
+            setattr(d, k, v)
+        d.gx1, d.gran, d.status = self.gx.data_ptr(), self.gran.data_ptr(), self.status.data_ptr()
+        d.y, d.y_sb, d.y_st, d.y_su, d.y_sg = self.y.data_ptr(), T * 1024, 1024, 1, 512     # cat: index g*512 + u
+        d.B, d.Bp, d.T, d.H, d.G, d.eps = B, Bp, T, 512, 2, 1e-5
+        self.add(d, TAG_LSTM)
+
     def _ln(self, name, out_t, osb, os_hi, os_lo, os_t, r, blk=0):
         d = L.LnDesc()
         d.blk = blk
@@ -1268,7 +1319,9 @@ class GcrnPlan(PlanBase):
             s = self.src(self.e[4], 128, *e_lay[4][0], off=128 * g * T * 4, blk=8 if blk else 0)   # (same offset in both layouts)
             return s, T, 4, [(0, f) for f in range(4)], wk, T, 1, 2048 * Bp, 0
 
-        if self.fused_glstm and not self.force_generic:
+        if self.persist:
+            self._glstm_persistent(proj1)
+        elif self.fused_glstm and not self.force_generic:
             self._glstm_wavefront(proj1)
         else:
             self._lstm_layer("lstm_list1", proj1, y_su=2, y_sg=1)           # stack(dim=-1)+flatten: index u*2+g

@@ -18,7 +18,12 @@ from . import nets
 class _PlannedOp:
     MAX_PLANS = 3   # recorded (B, T) geometries kept (least recently used first out); packed weights are shared
 
-    def __init__(self, state_dict, device="cuda:0", bank=None):
+    def __init__(self, state_dict, device="cuda:0", bank=None, exclusive=False):
+        """exclusive: the caller runs nothing else on the GPU beside this operator (one batch in flight), which allows
+        launches whose workgroups wait for each other - the persistent LSTM of the GCRN prior at B <= 4 (csrc/lstmp.hip).
+        Off by default: with it a small batch takes another kernel than a large one, so an utterance's result is no longer
+        bit-identical across batch compositions (it stays within 1e-5)."""
+        self.exclusive = bool(exclusive)
         self.sd = state_dict
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -143,7 +148,7 @@ class GCRNOp(_PlannedOp):
         B, _, T, _ = x.shape
 
         def build(ctx):
-            net = nets.GcrnPlan(ctx, self.sd, B, T)
+            net = nets.GcrnPlan(ctx, self.sd, B, T, exclusive=self.exclusive)
             net.build()
             return net
 

@@ -32,7 +32,7 @@ def _expect(t, like, name):
 class SamplerPipeline:
     def __init__(self, device, prior_name, prior_sd, ddpm_sd, B, T=None, L_=None, fast_sampling=True,
                  use_sigma=False, params=default_params, with_signal=None, deltamu=False, cond="init", bank=None,
-                 split_bf16=None, xT_plus_init=None, dtype="f32"):
+                 split_bf16=None, xT_plus_init=None, dtype="f32", exclusive=False):
         """deltamu: the alternative parameterisation of utils/params.py:36 — ddpm_sd is a ``Nocon`` state_dict,
         x_T = noise + X_init/11 (:947-948), eps = Nocon(x, t) (:970-971), no final ``+ X_init`` (:995).
         cond (deltamu False): what conditions DiffUNet1 — "init": X_init/11 (pirorgrad, :967-969, + X_init at the end,
@@ -47,6 +47,10 @@ class SamplerPipeline:
         tests/test_gpu_round2.py::test_bf16_mode_tolerance), it is never the default and never the graded bench line.
         bank: a ``nets.WeightBank`` shared with other pipelines built from the same state_dicts (packed weights are
         uploaded once, every further (B, T) only records descriptors).
+        exclusive: this pipeline is the only work on the GPU while it runs (one batch in flight - ``ComplexDDPMTrainer``
+        passes True): small batches may then use persistent launches whose workgroups wait for each other (the GCRN
+        prior's LSTM at B <= 4, csrc/lstmp.hip; 1e-5 from, not bit-identical to, the kernels large batches take).
+        ``ConcurrentSampler`` / ``PipelinedSampler`` and the sharded path keep False.
         split_bf16: the eps-net's BIGLU blocks and the priors' GEMM-shaped convolutions on the bf16 matrix cores with exact three-way
         operand splits - fp32-level accuracy at 16/6 of the fp32 MFMA rate (csrc/gconv3.hip); None: on for fast sampling,
         off (exact fp32 MFMA) for the full 50-step schedule."""
@@ -86,7 +90,7 @@ class SamplerPipeline:
 
         self.stft = adopt(nets.StftPlan(ctx, B, L_, plan=self.plan, split_bf16=split_bf16)) if with_signal else None
         if prior_name == "GCRN":
-            self.prior = adopt(nets.GcrnPlan(ctx, prior_sd, B, T, plan=self.plan, split_bf16=split_bf16))
+            self.prior = adopt(nets.GcrnPlan(ctx, prior_sd, B, T, plan=self.plan, split_bf16=split_bf16, exclusive=exclusive))
         elif prior_name == "DiffUNet":
             self.prior = adopt(nets.EpsNetPlan(ctx, prior_sd, B, T, time_cond=False, plan=self.plan, split_bf16=split_bf16))
         elif prior_name == "aia_complex_trans_ri":
@@ -195,6 +199,17 @@ class SamplerPipeline:
         e = self.ranges[last][1] if last else len(self.descs)
         self.plan.run_range(b, e, self._stream())
 
+    def check(self):
+        """Synchronises and raises if a persistent launch of the last run gave up (its workgroups wait for each other
+        with bounded polls: another workload on the GPU can keep them from all being resident)."""
+        st = getattr(self.prior, "status", None)
+        if st is not None:
+            code = int(st[0].item())
+            if code:
+                st.zero_()
+                raise L.PdseError("persistent LSTM gave up at step %d: its 256 workgroups were not all resident (is another "
+                                  "workload sharing the GPU?); build the pipeline with exclusive=False" % (code - 1))
+
     def sample(self, feat, x_T, graph=False):
         """feat, x_T [B,2,T,161] -> (enhanced compressed spectrogram, X_init); the
         spectrogram-level body of generate_wav (:939-998)."""
@@ -243,6 +258,7 @@ class ConcurrentSampler:
         self.B, self.nsplit = B, max(1, min(nsplit, B))
         self.spans = [shard_range(B, self.nsplit, r) for r in range(self.nsplit)]
         kw.setdefault("bank", nets.WeightBank())    # one packed copy of the weights for all sub-batch pipelines
+        kw["exclusive"] = False                     # the sub-batches share the GPU: no launch may wait for its own workgroups
         self.pipes = [SamplerPipeline(device, prior_name, prior_sd, ddpm_sd, hi - lo, T=T, L_=L_, **kw)
                       for lo, hi in self.spans]
         self.T, self.L = self.pipes[0].T, self.pipes[0].L
@@ -301,6 +317,7 @@ class PipelinedSampler:
         self.device = torch.device(device)
         self.depth, self.by_batch, self.graph = depth, by_batch, graph
         kw.setdefault("bank", nets.WeightBank())    # the in-flight buffer sets share one packed copy of the weights
+        kw["exclusive"] = False                     # batches in flight share the GPU: no launch may wait for its own workgroups
         self.pipes = [SamplerPipeline(device, prior_name, prior_sd, ddpm_sd, B, L_=L_, **kw) for _ in range(depth)]
         self.s_prior = torch.cuda.Stream(self.device, priority=-1)   # tiny dependent launches: schedule them first
         self.s_loop = torch.cuda.Stream(self.device)

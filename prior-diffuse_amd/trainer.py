@@ -31,11 +31,20 @@ from .schedule import inference_schedule as _inference_schedule
 class ComplexDDPMTrainer(object):
     MAX_PLANS = 3   # recorded (B, T) geometries kept alive (least recently used first out); weights are shared by all
 
-    def __init__(self, args, config, device=None, prior_state_dict=None, ddpm_state_dict=None, params=None):
+    def __init__(self, args, config, device=None, prior_state_dict=None, ddpm_state_dict=None, params=None, exclusive=None):
         """args: .retrain .joint .draw .sigma .checkpoint .generated_wav
         config: .model.name, .train.{fft_num, win_size, win_shift, feat_type}
         Weights come from ``<args.checkpoint>/best_checkpoint.pth`` under the reference's
-        rules (:91-97) or from the two state_dict arguments (synthetic runs)."""
+        rules (:91-97) or from the two state_dict arguments (synthetic runs).
+        exclusive: this trainer is the only work on its GPU (the reference's situation: one process, one batch at a
+        time), so small batches may take the persistent LSTM launch (csrc/lstmp.hip).  None: True unless the process is
+        one rank of a torch.distributed job - a sharded run keeps the kernels that make an utterance's result
+        bit-identical whatever the number of ranks (prior-diffuse_amd/shard.py)."""
+        if exclusive is None:
+            import torch.distributed as dist
+
+            exclusive = not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+        self.exclusive = bool(exclusive)
         self.c = PRIOR_SCALE_C                                        # :30
         self.args = deepcopy(args)
         self.config = deepcopy(config)
@@ -66,7 +75,7 @@ class ComplexDDPMTrainer(object):
         if self.prior_sd is None or self.ddpm_sd is None:
             raise ValueError("no weights: pass state_dicts or use --retrain with a best_checkpoint.pth")
         self.bank = nets.WeightBank()     # packed weights in HBM: uploaded once, shared by every plan of this trainer
-        self.model = ops.PRIOR_OPS[self.prior_name](self.prior_sd, self.device, bank=self.bank)       # :69
+        self.model = ops.PRIOR_OPS[self.prior_name](self.prior_sd, self.device, bank=self.bank, exclusive=self.exclusive)       # :69
         self.model_ddpm = (ops.NoconOp if self.deltamu else ops.DiffUNet1Op)(self.ddpm_sd, self.device, bank=self.bank)   # :70-73
         self._pipes = OrderedDict()
         self._hits = {}                   # uses of a recorded geometry after the first
@@ -85,7 +94,7 @@ class ComplexDDPMTrainer(object):
             self._pipes.clear()
             self._hits.clear()
             self.bank = nets.WeightBank()
-            self.model = ops.PRIOR_OPS[self.prior_name](self.prior_sd, self.device, bank=self.bank)
+            self.model = ops.PRIOR_OPS[self.prior_name](self.prior_sd, self.device, bank=self.bank, exclusive=self.exclusive)
             self.model_ddpm = (ops.NoconOp if self.deltamu else ops.DiffUNet1Op)(self.ddpm_sd, self.device, bank=self.bank)
         logging.info("loaded %s", path)
 
@@ -107,7 +116,7 @@ class ComplexDDPMTrainer(object):
             pipe = self._pipes[key] = SamplerPipeline(
                 self.device, self.prior_name, self.prior_sd, self.ddpm_sd, B, T=T, L_=L_,
                 fast_sampling=self.params.fast_sampling, use_sigma=key[3], params=self.params, deltamu=self.deltamu,
-                cond=self.cond, bank=self.bank, xT_plus_init=self.xT_plus_init)
+                cond=self.cond, bank=self.bank, xT_plus_init=self.xT_plus_init, exclusive=self.exclusive)
         else:
             self._pipes.move_to_end(key)
         return pipe
@@ -147,7 +156,9 @@ class ComplexDDPMTrainer(object):
         batch = torch.nn.utils.rnn.pad_sequence(wavs, batch_first=True).to(self.device)
         B, L_ = batch.shape
         T = 1 + L_ // 160
-        out, _ = self._pipe(B, L_=L_).enhance(batch, self._x_T((B, 2, T, 161), x_T), lens=lens)
+        pipe = self._pipe(B, L_=L_)
+        out, _ = pipe.enhance(batch, self._x_T((B, 2, T, 161), x_T), lens=lens)
+        pipe.check()
         cut = [(n // 160) * 160 if trim_to_frames else n for n in lens]
         return [out[i, :cut[i]].clone() for i in range(B)]
 
@@ -173,6 +184,7 @@ class ComplexDDPMTrainer(object):
                     logging.warning("skipping %s: %s", path, e)
                     continue
                 out = self.enhance(wav)[0].cpu().numpy()
+                self._pipes[next(reversed(self._pipes))].check()
                 if rng_fidelity:
                     shape = (1, 2, 1 + wav.shape[1] // 160, 161)
                     for _ in range(len(self._pipes[next(reversed(self._pipes))].schedule[0]) - 1):

@@ -28,7 +28,31 @@ def golden(name):
 def rel_l2(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
-    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+    v = float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+    _record_margin(v)
+    return v
+
+
+def _record_margin(v):
+    """PDSE_MARGINS=<file>: every rel-L2 a test evaluates is appended with the test's id and the source line that holds
+    the comparison (so the tolerance stands beside the measured value): the archive of how far inside its bound every
+    parity check sits on the hardware it ran on (profiles/rNN_parity_margins.txt)."""
+    path = os.environ.get("PDSE_MARGINS")
+    if not path:
+        return
+    import inspect
+    import linecache
+
+    fr = inspect.currentframe().f_back.f_back
+    while fr is not None and os.path.basename(fr.f_code.co_filename) == "conftest.py":
+        fr = fr.f_back
+    where = "?"
+    if fr is not None:
+        where = "%s:%d: %s" % (os.path.basename(fr.f_code.co_filename), fr.f_lineno,
+                               linecache.getline(fr.f_code.co_filename, fr.f_lineno).strip())
+    test = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0]
+    with open(path, "a") as f:
+        f.write("%-95s %.3e   %s\n" % (test, v, where[:150]))
 
 
 def seeded(shape, seed):

@@ -446,6 +446,40 @@ def run_glstm(d, mem):
             yflat[idx] = h2[g]
 
 
+def run_glstmp(d, mem):
+    """pdse_glstmp_desc (csrc/lstmp.hip): the persistent form - the same recurrence from its own operand layout
+    (w1 / w2i / w2h [G][H][4][H], natural K order), frame by frame."""
+    H, G, T, Bp, B = d.H, d.G, d.T, d.Bp, d.B
+    gx1 = mem.arr(d.gx1, G * T * 4 * H * Bp).reshape(G, T, Bp, 4 * H)
+    n = G * H * 4 * H
+    unp = lambda p_: mem.arr(p_, n).reshape(G, H, 4, H).transpose(0, 2, 1, 3).reshape(G, 4 * H, H)   # noqa: E731  rows q*H + u
+    W1, Wi, W2 = unp(d.w1), unp(d.w2i), unp(d.w2h)
+    r2, c2 = mem.arr(d.r2, G * 4 * H).reshape(G, 4 * H), mem.arr(d.c2, G * 4 * H).reshape(G, 4 * H)
+    yflat, yoff = mem.view(d.y)
+
+    def cell(gate, c):
+        i_, f_, g_, o_ = np.split(gate, 4, axis=1)
+        c = _sig(f_) * c + _sig(i_) * np.tanh(g_)
+        return (_sig(o_) * np.tanh(c)).astype(np.float32), c
+
+    h1 = np.zeros((G, B, H), np.float32)
+    c1 = np.zeros((G, B, H), np.float32)
+    h2 = np.zeros((G, B, H), np.float32)
+    c2s = np.zeros((G, B, H), np.float32)
+    for t in range(T):
+        for g in range(G):
+            h1[g], c1[g] = cell(gx1[g, t, :B, :] + h1[g] @ W1[g].T, c1[g])
+        allh = np.stack([h1[0], h1[1]], -1).reshape(B, -1)                           # feature 2u + g'
+        mu, var = allh.astype(np.float64).mean(1), allh.astype(np.float64).var(1)
+        rs = 1.0 / np.sqrt(var + d.eps)
+        for g in range(G):
+            xk = allh[:, H * g:H * g + H]
+            gx2 = rs[:, None] * (xk @ Wi[g].T - mu[:, None] * r2[g][None, :]) + c2[g][None, :]
+            h2[g], c2s[g] = cell(gx2.astype(np.float32) + h2[g] @ W2[g].T, c2s[g])
+            idx = (yoff + np.arange(B)[:, None] * d.y_sb + t * d.y_st + np.arange(H)[None, :] * d.y_su + g * d.y_sg)
+            yflat[idx] = h2[g]
+
+
 def run_tcm(d, mem):
     """pdse_tcm_desc: fused TCM residual block + the next block's conv1, from the packed operands."""
     B, T, dil = d.B, d.T, d.dil
@@ -695,7 +729,7 @@ def run_bglu(d, mem):
 
 RUNNERS = {L.BgluDesc: run_bglu, L.PlanesDesc: run_planes, L.GcrnLastDesc: run_gcrnlast, L.TcmDesc: run_tcm, L.Tcm2Desc: run_tcm2, L.GconvDesc: run_gconv, L.TimeDesc: run_time, L.EwDesc: run_ew, L.CompandDesc: run_compand,
            L.WavprepDesc: run_wavprep, L.OlaDesc: run_ola, L.SigmaDesc: run_sigma, L.LnDesc: run_ln,
-           L.LstmDesc: run_lstm, L.GlstmDesc: run_glstm}
+           L.LstmDesc: run_lstm, L.GlstmDesc: run_glstm, L.GlstmpDesc: run_glstmp}
 
 
 def run(descs, keep, begin=0, end=None):

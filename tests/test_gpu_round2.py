@@ -40,12 +40,12 @@ def L():
     return lib
 
 
-def _trainer(weights, prior="GCRN", ddpm="DiffUNet1", sigma=False, params=None, out="y"):
+def _trainer(weights, prior="GCRN", ddpm="DiffUNet1", sigma=False, params=None, out="y", **kw):
     ns = argparse.Namespace
     return pkg("trainer").ComplexDDPMTrainer(
         ns(retrain=False, joint=True, draw=False, sigma=sigma, checkpoint="x", generated_wav=out),
         ns(model=ns(name=prior), train=ns(fft_num=320, win_size=320, win_shift=160, feat_type="sqrt")),
-        device=DEV, prior_state_dict=weights(prior), ddpm_state_dict=weights(ddpm), params=params)
+        device=DEV, prior_state_dict=weights(prior), ddpm_state_dict=weights(ddpm), params=params, **kw)
 
 
 def _errors_vs_fp32_and_exact(fixture, got):
@@ -158,7 +158,7 @@ def test_generate_wav_many_lengths_shared_weights(L, weights, tmp_path):
         wav = torch.from_numpy(wavio.read_wav(str(data / ("f%02d.wav" % i))))[None].to(DEV)
         T = 1 + n // 160
         x_T = torch.randn(1, 2, T, 161, device=DEV)
-        pipe = P.SamplerPipeline(DEV, "GCRN", weights("GCRN"), weights("DiffUNet1"), 1, L_=n)
+        pipe = P.SamplerPipeline(DEV, "GCRN", weights("GCRN"), weights("DiffUNet1"), 1, L_=n, exclusive=True)   # as the trainer builds it
         out, _ = pipe.enhance(wav, x_T)
         for _ in range(5):
             torch.randn(1, 2, T, 161, device=DEV)
@@ -196,7 +196,7 @@ def test_real_sharded_path_two_ranks_equals_single_rank(L, weights, tmp_path):
                                        str(tmp_path)], env=env))
     assert [p.wait(timeout=600) for p in procs] == [0, 0]
     wav, x_T = pkg("synth").synthetic_waveforms(5, 4000, seed=21)
-    t = _trainer(weights)
+    t = _trainer(weights, exclusive=False)      # as the ranks of a distributed job build it: the kernels that do not depend on the batch size
     ref = t.enhance(wav, x_T=x_T).cpu()
     for r in range(2):
         got = torch.load(os.path.join(str(tmp_path), "out%d.pt" % r))

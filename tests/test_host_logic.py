@@ -78,20 +78,24 @@ def test_eps_net_plan_vs_oracle(weights, chained, split, plane_h, parity, monkey
             Pk.tcm2_join_h(hs.numpy().view(np.uint16), B, T)
 
 
-@pytest.mark.parametrize("fused_glstm,split,block8", [(True, True, True), (False, True, True), (True, False, True), (True, True, False)])
-def test_gcrn_and_diffunet_prior_plans_vs_oracle(weights, fused_glstm, split, block8, monkeypatch):
+@pytest.mark.parametrize("fused_glstm,split,block8,persist", [(True, True, True, True), (True, True, True, False), (False, True, True, False),
+                                                              (True, False, True, False), (True, True, False, False)])
+def test_gcrn_and_diffunet_prior_plans_vs_oracle(weights, fused_glstm, split, block8, persist, monkeypatch):
     """fused_glstm: both LSTM layers + LayerNorm 1 as one layer-wavefront operator (LayerNorm folded into the layer-2
     input projection, permuted K order); False: two per-frame LSTM operators with the LayerNorm and projections between.
-    split: the gated convolutions / input projections packed for the split-bf16 GEMM kernel (korder 3)."""
+    split: the gated convolutions / input projections packed for the split-bf16 GEMM kernel (korder 3).
+    persist: the small-batch form of the wavefront - one persistent launch, its own operand layout (pdse_glstmp_desc)."""
     nets = pkg("nets")
+    monkeypatch.setattr(nets.GcrnPlan, "persist_lstm", persist)
     monkeypatch.setattr(nets.GcrnPlan, "fused_glstm", fused_glstm)
     monkeypatch.setattr(nets.GcrnPlan, "split_bf16", split)
     monkeypatch.setattr(nets.GcrnPlan, "block8", block8)          # tensors between the GEMM convolutions in blocks of 8 channels
     B, T = 2, 10
     x = seeded((B, 2, T, 161), 5)
     ctx = nets.Ctx("cpu")
-    net = nets.GcrnPlan(ctx, weights("GCRN"), B, T)
+    net = nets.GcrnPlan(ctx, weights("GCRN"), B, T, exclusive=True)
     net.build()
+    assert sum(1 for d, _ in net.descs if isinstance(d, pkg("_lib").GlstmpDesc)) == (1 if persist else 0)
     n3 = sum(1 for d, _ in net.descs if isinstance(d, pkg("_lib").GconvDesc) and d.korder == 3)
     assert n3 == ((4 + 16 + (2 if fused_glstm else 4)) if split else 0)   # encoder 2-5, 2 x 4 x 2 decoder phases, projections
     nblk = sum(1 for d, _ in net.descs if isinstance(d, pkg("_lib").GconvDesc) and d.in0.blk)

@@ -17,9 +17,10 @@ synth = importlib.import_module("prior-diffuse_amd.synth")
 L = importlib.import_module("prior-diffuse_amd._lib")
 
 
-def run(fused, B=32, T=401, reps=5):
+def run(fused, B=32, T=401, reps=5, persist=False):
     nets.GcrnPlan.fused_glstm = fused
-    p = nets.GcrnPlan(nets.Ctx("cuda:0"), synth.make_state_dict("GCRN"), B, T)
+    nets.GcrnPlan.persist_lstm = persist
+    p = nets.GcrnPlan(nets.Ctx("cuda:0"), synth.make_state_dict("GCRN"), B, T, exclusive=True)
     p.build()
     p.finish()
     p.x.normal_()
@@ -43,11 +44,16 @@ def run(fused, B=32, T=401, reps=5):
     lstm = sum(m for (d, tag), m in zip(p.descs, ms) if tag == nets.TAG_LSTM)
     proj = sum(m for (d, tag), m in zip(p.descs, ms) if isinstance(d, L.GconvDesc) and d.Cout == 2048)
     ln = sum(m for (d, tag), m in zip(p.descs, ms) if isinstance(d, L.LnDesc))
-    print("fused=%s  B=%d T=%d: prior %.2f ms | recurrent ops %.3f ms (%.2f us/step) | input projections %.3f ms | LayerNorm %.3f ms"
-          % (fused, B, T, tot, lstm, lstm * 1e3 / ((T + 2) if fused else 2 * T), proj, ln))
+    print("fused=%s persistent=%s  B=%d T=%d: prior %.2f ms | recurrent ops %.3f ms (%.2f us/step) | input projections %.3f ms | LayerNorm %.3f ms"
+          % (fused, bool(getattr(p, "persist", False)), B, T, tot, lstm, lstm * 1e3 / ((T + 1) if getattr(p, "persist", False) else (T + 2) if fused else 2 * T), proj, ln), flush=True)
 
 
 if __name__ == "__main__":
+    if "--persist" in sys.argv:      # the small-batch persistent form (csrc/lstmp.hip) beside the wavefront
+        for B, T in ((1, 401), (2, 401), (4, 401), (8, 401), (1, 1001)):
+            run(True, B, T)
+            run(True, B, T, persist=True)
+        sys.exit(0)
     for B, T in ((32, 401), (1, 401), (16, 1001)):
         run(False, B, T)
         run(True, B, T)
