@@ -718,6 +718,12 @@ int pdse_glstm_persistent_f32(const pdse_glstmp_desc* d, pdse_stream_t s);
 int pdse_tcm2_bf16x3(const pdse_tcm2_desc* d, pdse_stream_t s);
 int pdse_bglu_planes(const pdse_bglu_desc* d, pdse_stream_t s);
 int pdse_split_planes(const pdse_planes_desc* d, pdse_stream_t s);
+/* Kernel form of pdse_bglu_planes (ABI 6; process-wide, tuning only): -1 / 0 = 8 waves with the generated slot schedule
+ * (the product kernel).  A library built with -DBGLU_FORMS also holds the forms that were measured and not kept
+ * (profiles/r03_bglu_forms.txt, r04_bglu_forms.txt): 1 = 4 waves software-pipelined, 2 / 3 = 16 / 12 waves with strictly
+ * sequential tiles, 4 = 8 waves with the vector-memory instructions spread over the slots.  Every form reads the same
+ * descriptor and computes the same block.  Returns the previous setting, or -2 for a form this library does not hold. */
+int pdse_bglu_set_form(int form);
 
 /* plans: a recorded operator sequence replayed by one call (and capturable in a hipGraph) */
 typedef struct pdse_plan pdse_plan;

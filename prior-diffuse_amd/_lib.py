@@ -214,7 +214,7 @@ EXPORTS = [
     "pdse_ola_f32", "pdse_sigma_mask_f32", "pdse_layernorm_f32", "pdse_lstm_f32",
     "pdse_rowln_prelu_f32", "pdse_chln_f32", "pdse_attention_f32", "pdse_bigru_f32", "pdse_gn_combine_f32",
     "pdse_aham_f32", "pdse_qsample_f32", "pdse_transpose_f32", "pdse_tcm_f32", "pdse_crm_f32", "pdse_gcrnlast_f32",
-    "pdse_masked_mse_f32", "pdse_glstm_f32", "pdse_glstm_persistent_f32", "pdse_tcm2_bf16x3", "pdse_bglu_planes", "pdse_split_planes",
+    "pdse_masked_mse_f32", "pdse_glstm_f32", "pdse_glstm_persistent_f32", "pdse_tcm2_bf16x3", "pdse_bglu_planes", "pdse_split_planes", "pdse_bglu_set_form",
     "pdse_plan_create", "pdse_plan_add", "pdse_plan_size", "pdse_plan_set_device", "pdse_plan_clear", "pdse_plan_run",
     "pdse_plan_run_range",
     "pdse_plan_build_graph", "pdse_plan_launch_graph", "pdse_plan_time_ops", "pdse_plan_time_tag",

@@ -157,7 +157,7 @@ struct bglu_cfg {
 // PIPE true: 4 waves (one per SIMD, 512 registers), the K loop of tile i+1 interleaved with the tail of tile i.
 // PIPE false: 8 waves (two per SIMD, 256 registers), K loop and tail of the same tile one after the other - a wave issues at
 // most one instruction per four cycles, so two waves per SIMD double the issue rate and cover each other's stalls.
-template <int NT, int P1MASK, int C2, int NXN, bool IN4, int NP, bool PIPE>
+template <int NT, int P1MASK, int C2, int NXN, bool IN4, int NP, bool PIPE, bool SPR = false>
 __global__ __launch_bounds__(PIPE ? 256 : 512, PIPE ? 1 : 2) void bglu_kernel(const pdse_bglu_desc d) {
   using CF = bglu_cfg<NT, P1MASK, C2, NXN, IN4, NP, PIPE>;
   constexpr int WV = CF::WV, NB = CF::NB, NB1 = CF::NB1, BS = CF::BS;
@@ -257,6 +257,10 @@ __global__ __launch_bounds__(PIPE ? 256 : 512, PIPE ? 1 : 2) void bglu_kernel(co
 #pragma unroll
       for (int pl = 0; pl < NP; ++pl) in.pl[tap][q][pl] = bload16(r_in, ps.vin, soff_in(tap, q, pl));
   };
+  auto request_one = [&](const pos_t& ps, in_t& in, const int tap, const int q, const int pl) {   // one 16-byte load (spread schedules)
+    const __amdgpu_buffer_rsrc_t r_in = make_rsrc(d.hp + (int64_t)b * d.hp_sb, (uint32_t)d.hp_Tp * 4u * NP * (uint32_t)Fp * 16u);
+    in.pl[tap][q][pl] = bload16(r_in, ps.vin, soff_in(tap, q, pl));
+  };
   auto request_in4 = [&](const pos_t& ps, in_t& in) {
     // slot s = 2q + w: tap 4q + 2h + w of the ten (2,5) taps, channels (x 0, x 1, x_init 0, x_init 1); taps >= 10: zero
     in.live = 0;
@@ -355,6 +359,16 @@ __global__ __launch_bounds__(PIPE ? 256 : 512, PIPE ? 1 : 2) void bglu_kernel(co
 #pragma unroll
       for (int pl = 0; pl < NP; ++pl) bstore16<BGLU_ST_AUX>(zp[q][pl], r_nx, o, ((2 * q * NP + pl) * nFp) << 4);
   };
+  auto plane_off = [&](const bool ok, const int t, const int bin) -> uint32_t {
+    const int bi = bin + d.nx_f0;
+    const int bpos = d.nx_par ? (bi & 1) * ((nFp + 1) >> 1) + (bi >> 1) : bi;
+    return ok ? (uint32_t)b * item_hp + ((uint32_t)(((t + d.nx_t0) * 4 + h) * (NP * nFp) + bpos) << 4)
+              : (uint32_t)d.B * item_hp + ((uint32_t)(h * (NP * nFp)) << 4);
+  };
+  auto store_planes_q = [&](const uint4 (&zq)[NP], const uint32_t o, const int q) {   // K block q of a tile: its NP planes
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl) bstore16<BGLU_ST_AUX>(zq[pl], r_nx, o, ((2 * q * NP + pl) * nFp) << 4);
+  };
   const __amdgpu_buffer_rsrc_t r_sk0 = make_rsrc(NXN > 1 ? d.nx_out[0] : nullptr, NXN > 1 ? (uint32_t)((d.B + 1) * d.nx_sb[0] * 4) : 0u);
   const __amdgpu_buffer_rsrc_t r_sk1 = make_rsrc(NXN > 2 ? d.nx_out[1] : nullptr, NXN > 2 ? (uint32_t)((d.B + 1) * d.nx_sb[1] * 4) : 0u);
   // fp32 skip halves in groups of four channels, [B + 1 (dump item)][8 groups][T][F][4]: accumulator rows 4q..4q+3 of lane
@@ -402,6 +416,7 @@ __global__ __launch_bounds__(PIPE ? 256 : 512, PIPE ? 1 : 2) void bglu_kernel(co
     f32x16 L, R, mL, mR, G, O0, O1, Z0, Z1, Z2;
     uint4 lp[2][NP], rp[2][NP], gp[2][NP], yp[2][2][NP], zp[2][NP];
     float v;
+    uint32_t zo, so;   // spread schedules: byte offsets of the addend loads / the plane stores of this phase
   };
   auto split_half = [&](const f32x16& X, const int s_, uint4 (&p)[NP]) {
     float x[8];
@@ -422,6 +437,17 @@ __global__ __launch_bounds__(PIPE ? 256 : 512, PIPE ? 1 : 2) void bglu_kernel(co
       const uint4 v = bload16(r_add, o, (int)((2 * q * d.add_sc) << 2));
       z[4 * q] = __uint_as_float(v.x), z[4 * q + 1] = __uint_as_float(v.y), z[4 * q + 2] = __uint_as_float(v.z), z[4 * q + 3] = __uint_as_float(v.w);
     }
+  };
+
+  auto zoff = [&](const pos_t& ps, const int ph) -> uint32_t {
+    const bool two = ph == 0 || ps.j < d.Fout1;
+    const int bin0 = 2 * ps.j + (two ? ph : 0);
+    const int bin = d.skip_Fh ? (two ? ph : 0) * d.skip_Fh + ps.j : bin0;
+    return (uint32_t)(((int64_t)b * d.add_sb + (int64_t)ps.t * d.add_st + (int64_t)bin * d.add_sf + (int64_t)h * d.add_sc) << 2);
+  };
+  auto zload = [&](const uint32_t o, const int q, f32x16& z) {
+    const uint4 v = bload16(r_add, o, (int)((2 * q * d.add_sc) << 2));
+    z[4 * q] = __uint_as_float(v.x), z[4 * q + 1] = __uint_as_float(v.y), z[4 * q + 2] = __uint_as_float(v.z), z[4 * q + 3] = __uint_as_float(v.w);
   };
 
 #define FRAG(buf, ptr)                                         \
@@ -494,6 +520,20 @@ __global__ __launch_bounds__(PIPE ? 256 : 512, PIPE ? 1 : 2) void bglu_kernel(co
     }                                                                                                  \
   }
 #define V_STSKIP(S, i) store_skip(S.Z##i, (i)-1, pc);
+#define V_ZOFF(S, ph) S.zo = zoff(pc, ph);
+#define V_ZLD(S, q) zload(S.zo, q, S.Z0);
+#define V_ST0Q(S, ph, q)                                                                                \
+  {                                                                                                    \
+    if ((q) == 0) S.so = DUAL ? plane_off(pc.valid && ((ph) == 0 || pc.j < d.Fout1), pc.t, 2 * pc.j + (ph)) : plane_off(pc.valid, pc.t, pc.j); \
+    store_planes_q(S.zp[q], S.so, q);                                                                  \
+    if constexpr (!DUAL) {                                                                             \
+      if ((q) == 1 && d.nx_row0) {                                                                     \
+        uint4 bp_[2][NP];                                                                              \
+        split16p<NP>(ld16(fop + F_NXB + 4 * h), bp_);                                                  \
+        store_planes(bp_, pc.valid && pc.t == 0, -1, pc.j);                                            \
+      }                                                                                                \
+    }                                                                                                  \
+  }
 #define V_DOT(S, ph)                                                              \
   {                                                                               \
     const f32x16 vw_ = ld16(fop + F_WC2V + 4 * h);                                \
@@ -512,6 +552,8 @@ __global__ __launch_bounds__(PIPE ? 256 : 512, PIPE ? 1 : 2) void bglu_kernel(co
 #define REQ(tap) request_tap(p_req, in, tap);
 #define REQ_CUR(tap) request_tap(pc, in, tap);
 #define REQ_IN4() request_in4(p_req, in);
+#define REQ1(tap, q, pl) request_one(p_req, in, tap, q, pl);
+#define REQ_CUR1(tap, q, pl) request_one(pc, in, tap, q, pl);
 #define V_TAKE()          \
   {                       \
     SA.L = acc.L;         \
@@ -546,6 +588,12 @@ __global__ __launch_bounds__(PIPE ? 256 : 512, PIPE ? 1 : 2) void bglu_kernel(co
 #define V_SZ(S, s_)
 #undef V_ZSEED
 #define V_ZSEED(S, ph)
+#undef V_ZOFF
+#undef V_ZLD
+#undef V_ST0Q
+#define V_ZOFF(S, ph)
+#define V_ZLD(S, q)
+#define V_ST0Q(S, ph, q)
 #define V_ST0(S, ph)
 #define V_STSKIP(S, i)
 #define V_DOT(S, ph)
@@ -656,27 +704,37 @@ __global__ __launch_bounds__(PIPE ? 256 : 512, PIPE ? 1 : 2) void bglu_kernel(co
     if constexpr (SCHED == 1) {
 #define BGLU_SCHED 1
       [[maybe_unused]] constexpr int dg_base = __COUNTER__;
-#include "bglu_sched.inc"
+#ifdef BGLU_FORMS
+#include "bglu_sched_forms.inc"
+#endif
 #undef BGLU_SCHED
     } else if constexpr (SCHED == 2) {
 #define BGLU_SCHED 2
       [[maybe_unused]] constexpr int dg_base = __COUNTER__;
-#include "bglu_sched.inc"
+#ifdef BGLU_FORMS
+#include "bglu_sched_forms.inc"
+#endif
 #undef BGLU_SCHED
     } else if constexpr (SCHED == 3) {
 #define BGLU_SCHED 3
       [[maybe_unused]] constexpr int dg_base = __COUNTER__;
-#include "bglu_sched.inc"
+#ifdef BGLU_FORMS
+#include "bglu_sched_forms.inc"
+#endif
 #undef BGLU_SCHED
     } else if constexpr (SCHED == 4) {
 #define BGLU_SCHED 4
       [[maybe_unused]] constexpr int dg_base = __COUNTER__;
-#include "bglu_sched.inc"
+#ifdef BGLU_FORMS
+#include "bglu_sched_forms.inc"
+#endif
 #undef BGLU_SCHED
     } else {
 #define BGLU_SCHED 5
       [[maybe_unused]] constexpr int dg_base = __COUNTER__;
-#include "bglu_sched.inc"
+#ifdef BGLU_FORMS
+#include "bglu_sched_forms.inc"
+#endif
 #undef BGLU_SCHED
     }
     if constexpr (C2 == 1 || NXN == 0) stores_masked(pc, SA, SB);
@@ -711,7 +769,7 @@ __global__ __launch_bounds__(PIPE ? 256 : 512, PIPE ? 1 : 2) void bglu_kernel(co
       request_tap(pc, in, 0);
       request_tap(pc, in, 1);
     }
-    constexpr int SCHED = 10 + (IN4 ? 5 : (DUAL ? (C2 == 64 ? 1 : 2) : (NXN == 3 ? 3 : 4)));
+    constexpr int SCHED = ((SPR && !IN4) ? 20 : 10) + (IN4 ? 5 : (DUAL ? (C2 == 64 ? 1 : 2) : (NXN == 3 ? 3 : 4)));
     while (true) {
       locate(rd + stride, pn);
       const pos_t& p_req = pn;
@@ -744,10 +802,38 @@ __global__ __launch_bounds__(PIPE ? 256 : 512, PIPE ? 1 : 2) void bglu_kernel(co
       [[maybe_unused]] constexpr int dg_base = __COUNTER__;
 #include "bglu_sched.inc"
 #undef BGLU_SCHED
-      } else {
+      } else if constexpr (SCHED == 15) {
 #define BGLU_SCHED 15
       [[maybe_unused]] constexpr int dg_base = __COUNTER__;
 #include "bglu_sched.inc"
+#undef BGLU_SCHED
+      } else if constexpr (SCHED == 21) {
+#define BGLU_SCHED 21
+      [[maybe_unused]] constexpr int dg_base = __COUNTER__;
+#ifdef BGLU_FORMS
+#include "bglu_sched_forms.inc"
+#endif
+#undef BGLU_SCHED
+      } else if constexpr (SCHED == 22) {
+#define BGLU_SCHED 22
+      [[maybe_unused]] constexpr int dg_base = __COUNTER__;
+#ifdef BGLU_FORMS
+#include "bglu_sched_forms.inc"
+#endif
+#undef BGLU_SCHED
+      } else if constexpr (SCHED == 23) {
+#define BGLU_SCHED 23
+      [[maybe_unused]] constexpr int dg_base = __COUNTER__;
+#ifdef BGLU_FORMS
+#include "bglu_sched_forms.inc"
+#endif
+#undef BGLU_SCHED
+      } else {
+#define BGLU_SCHED 24
+      [[maybe_unused]] constexpr int dg_base = __COUNTER__;
+#ifdef BGLU_FORMS
+#include "bglu_sched_forms.inc"
+#endif
 #undef BGLU_SCHED
       }
       if constexpr (C2 == 1 || NXN == 0) stores_masked(pc, SA, SB);
@@ -763,6 +849,365 @@ __global__ __launch_bounds__(PIPE ? 256 : 512, PIPE ? 1 : 2) void bglu_kernel(co
       atomicAdd(&g_bglu_slots[96], (unsigned long long)dg_tiles);
     }
 #endif
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 16-wave form (round 4).  What round 3 measured on the 8-wave form (profiles/r03_bglu_forms.txt): every unit of the CU busy
+// a quarter to a third of the time and the launch taking about the SUM - a wave spends 70 % of a tile queueing at the
+// vector-memory pipeline (loads 7k cycles away under load, stores sharing the in-order vmcnt), and with two waves per SIMD
+// nothing runs meanwhile.  The remedy named there was more independent waves per CU; what stood in the way was the
+// 256-register tail of the slot schedule, which keeps both phases' tails and all taps of a tile live at once to feed one
+// wave's matrix pipe.  This form trades that instruction-level overlap for thread-level overlap: 16 waves (four per SIMD,
+// <= 128 registers) share the same LDS weight image, and each wave runs a tile strictly in sequence - K loop of phase 0
+// (two taps in a register ring), tail of phase 0 with its values consumed as soon as they exist (one half-tile split
+// live at a time), then the same for phase 1 - so a wave that waits for memory, for LDS fragments or for an MFMA result
+// leaves the SIMD to three others.  Same descriptor, same image, same plane tensors, same roundings per element
+// (identical mm / split / gate expressions): results are bit-identical to the 8-wave form.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int nth_tap(int m, int k) { return (m & 1) ? (k == 0 ? 0 : 1 + nth_tap(m >> 1, k - 1)) : 1 + nth_tap(m >> 1, k); }
+
+template <int NT, int P1MASK, int C2, int NXN, bool IN4, int NP, int WV>
+__global__ __launch_bounds__(64 * WV) void bglu16_kernel(const pdse_bglu_desc d) {
+  using CF = bglu_cfg<NT, P1MASK, C2, NXN, IN4, NP, false>;
+  constexpr int NB = CF::NB, NB1 = CF::NB1, NT1 = CF::NT1, BS = CF::BS;
+  constexpr bool DUAL = CF::DUAL;
+  static_assert(IN4 || (NT % 2 == 0 && NT1 % 2 == 0), "the two-slot tap ring assumes an even number of taps per phase");
+  extern __shared__ uint4 img[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, h = lane >> 5;
+  const int b = blockIdx.y;
+  const int P = d.Tout * d.Fout;
+
+  // ---- the LDS image (as bglu_kernel)
+  {
+    const uint4* const srcs[8] = {reinterpret_cast<const uint4*>(d.w0), reinterpret_cast<const uint4*>(d.w1),
+                                  reinterpret_cast<const uint4*>(d.w2), reinterpret_cast<const uint4*>(d.w3),
+                                  reinterpret_cast<const uint4*>(d.wlc), reinterpret_cast<const uint4*>(d.wrc),
+                                  reinterpret_cast<const uint4*>(d.wc2), reinterpret_cast<const uint4*>(d.nx_w)};
+    const int cnt[8] = {NB * NP, NB * NP, NB1 * NP, NB1 * NP, 2 * NP, 2 * NP, C2 == 64 ? 4 * NP : 0, NXN * 4 * NP};
+    constexpr int total = CF::o_f >> 6;
+    for (int c = __builtin_amdgcn_readfirstlane(wave); c < total; c += WV) {
+      int cc = c;
+      const uint4* src = nullptr;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (src == nullptr) {
+          if (cc < cnt[k]) src = srcs[k] + cc * 64;
+          else cc -= cnt[k];
+        }
+      }
+      glds16(src + lane, img + c * 64);
+    }
+    float* const fo = reinterpret_cast<float*>(img + CF::o_f);
+    for (int s = tid; s < BGLU_FLOATS; s += 64 * WV) {
+      const int k = s & 31;
+      float v = 0.f;
+      if (s < 32) v = d.bias0[(int64_t)b * d.bias_sb + k];
+      else if (s < 64) v = d.bias1[(int64_t)b * d.bias_sb + k];
+      else if (s < 96) v = (d.bias0_t0 ? d.bias0_t0 : d.bias0)[(int64_t)b * d.bias_sb + k];
+      else if (s < 128) v = (d.bias1_t0 ? d.bias1_t0 : d.bias1)[(int64_t)b * d.bias_sb + k];
+      else if (s < 160) v = d.blc[k];
+      else if (s < 192) v = d.brc[k];
+      else if (s < 256) v = (s - 192) < C2 ? d.bc2[s - 192] : 0.f;
+      else if (s < 352) {
+        const int i = (s - 256) >> 5;
+        v = (i < NXN && d.nx_bias[i]) ? d.nx_bias[i][(int64_t)b * d.nx_bias_sb[i] + k] : 0.f;
+      } else if (s < 384) v = (C2 == 1) ? d.wc2v[k] : 0.f;
+      fo[s] = v;
+    }
+  }
+  __syncthreads();
+  const float* const fop = reinterpret_cast<const float*>(img + CF::o_f);
+  const int ntiles = (P + 31) >> 5;
+  const int nrounds = (ntiles + WV - 1) / WV;
+
+  struct pos_t {
+    int t, j;
+    bool valid;
+    uint32_t vin;
+  };
+  const int Fp = d.hp_Fp;
+  auto locate = [&](const int rd, pos_t& ps) {
+    const int p = (rd * WV + wave) * 32 + col;
+    ps.valid = p < P;
+    const int pp = ps.valid ? p : 0;
+    ps.t = pp / d.Fout;
+    ps.j = pp - ps.t * d.Fout;
+    ps.vin = (uint32_t)(ps.t * (4 * NP * Fp) + h * (NP * Fp) + (d.hp_par ? ps.j : ps.j * d.sf_in)) << 4;
+  };
+  const int Fh = (Fp + 1) >> 1;
+  // byte offset of (tap, K block q, plane pl) = a per-tap base + a per-(q, pl) part, added where the load is issued: kept as
+  // one loop-invariant scalar per load (36 of them in the six-tap kernels) they overflow the scalar registers into vector lanes
+  auto tap_base = [&](const int tap) -> int {
+    const int bin0 = d.tap_df[tap] + d.hp_f0;
+    int tb = __builtin_amdgcn_readfirstlane((((d.tap_dt[tap] + d.hp_t0) * 4) * (NP * Fp) + (d.hp_par ? (bin0 & 1) * Fh + (bin0 >> 1) : bin0)) << 4);
+    asm volatile("" : "+s"(tb));   // opaque: the sums below stay inside the tile loop
+    return tb;
+  };
+  // one tap's planes [q][plane] into a ring slot
+  auto request_tap = [&](const pos_t& ps, uint4 (&sl)[2][NP], const int tap) {
+    const __amdgpu_buffer_rsrc_t r_in = make_rsrc(d.hp + (int64_t)b * d.hp_sb, (uint32_t)d.hp_Tp * 4u * NP * (uint32_t)Fp * 16u);
+    const int tb = tap_base(tap);
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl) sl[q][pl] = bload16(r_in, ps.vin, tb + (((2 * q) * NP + pl) * Fp << 4));
+  };
+  struct raw_t {
+    float raw[IN4 ? 6 : 1][4];
+    unsigned live;
+  };
+  auto request_in4 = [&](const pos_t& ps, raw_t& in) {
+    in.live = 0;
+    const __amdgpu_buffer_rsrc_t r_x0 = make_rsrc(d.x0.ptr, 0xfffffffcu), r_x1 = make_rsrc(d.x1.ptr, 0xfffffffcu);
+#pragma unroll
+    for (int s_ = 0; s_ < 6; ++s_) {
+      const int ta = 4 * (s_ >> 1) + (s_ & 1), tb = ta + 2;
+      const bool has_b = tb < 10, has_a = ta < 10;
+      const int dt = h ? (has_b ? d.tap_dt[tb < 10 ? tb : 0] : 0) : (has_a ? d.tap_dt[ta < 10 ? ta : 0] : 0);
+      const int df = h ? (has_b ? d.tap_df[tb < 10 ? tb : 0] : 0) : (has_a ? d.tap_df[ta < 10 ? ta : 0] : 0);
+      const bool has = h ? has_b : has_a;
+      const int tin = ps.t + dt, fin = ps.j * d.sf_in + df;
+      const bool inb = has && ps.valid && fin >= 0 && fin < d.Fin && tin >= 0 && tin < d.Tin;
+      if (inb) in.live |= 1u << s_;
+      const uint32_t o0 = inb ? (unsigned)((int64_t)b * d.x0.sb + (int64_t)tin * d.x0.st + (int64_t)fin * d.x0.sf) : 0u;
+      const uint32_t o1 = inb ? (unsigned)((int64_t)b * d.x1.sb + (int64_t)tin * d.x1.st + (int64_t)fin * d.x1.sf) : 0u;
+      in.raw[s_][0] = bload4(r_x0, o0 << 2, 0);
+      in.raw[s_][1] = bload4(r_x0, o0 << 2, (int)(d.x0.sc << 2));
+      in.raw[s_][2] = bload4(r_x1, o1 << 2, 0);
+      in.raw[s_][3] = bload4(r_x1, o1 << 2, (int)(d.x1.sc << 2));
+    }
+  };
+  auto seed = [&](const pos_t& ps, f32x16& L, f32x16& R) {
+    const bool f0 = ps.t == 0;
+    L = ld16(fop + (f0 ? F_BL0 : F_BL) + 4 * h);
+    R = ld16(fop + (f0 ? F_BR0 : F_BR) + 4 * h);
+  };
+
+  // ---- stores (as bglu_kernel)
+  const int nFp = d.nx_Fp;
+  const uint32_t item_hp = NXN > 0 ? (uint32_t)(d.nx_hp_sb * 2) : 0u;
+  const __amdgpu_buffer_rsrc_t r_nx = make_rsrc(NXN > 0 ? d.nx_hp : nullptr, NXN > 0 ? (uint32_t)(d.B + 1) * item_hp : 0u);
+  auto store_planes = [&](const uint4 (&zp)[2][NP], const bool ok, const int t, const int bin) {
+    const int bi = bin + d.nx_f0;
+    const int bpos = d.nx_par ? (bi & 1) * ((nFp + 1) >> 1) + (bi >> 1) : bi;
+    const uint32_t o = ok ? (uint32_t)b * item_hp + ((uint32_t)(((t + d.nx_t0) * 4 + h) * (NP * nFp) + bpos) << 4)
+                          : (uint32_t)d.B * item_hp + ((uint32_t)(h * (NP * nFp)) << 4);
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl) bstore16<BGLU_ST_AUX>(zp[q][pl], r_nx, o, ((2 * q * NP + pl) * nFp) << 4);
+  };
+  const __amdgpu_buffer_rsrc_t r_sk0 = make_rsrc(NXN > 1 ? d.nx_out[0] : nullptr, NXN > 1 ? (uint32_t)((d.B + 1) * d.nx_sb[0] * 4) : 0u);
+  const __amdgpu_buffer_rsrc_t r_sk1 = make_rsrc(NXN > 2 ? d.nx_out[1] : nullptr, NXN > 2 ? (uint32_t)((d.B + 1) * d.nx_sb[1] * 4) : 0u);
+  auto store_skip = [&](const f32x16& z, const int i, const pos_t& ps) {
+    const int jp = d.skip_Fh ? (ps.j & 1) * d.skip_Fh + (ps.j >> 1) : ps.j;
+    // 32-bit arithmetic: pdse_bglu_launch validates (B + 1) * nx_sb * 4 < 2^32
+    const uint32_t o = ((uint32_t)(ps.valid ? b : d.B) * (uint32_t)d.nx_sb[i] + (ps.valid ? (uint32_t)ps.t * (uint32_t)d.nx_st[i] + (uint32_t)jp * (uint32_t)d.nx_sf[i] : 0u) +
+                        (uint32_t)h * (uint32_t)d.nx_sc[i]) << 2;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      bstore16<BGLU_ST_AUX>(make_uint4(__float_as_uint(z[4 * q]), __float_as_uint(z[4 * q + 1]), __float_as_uint(z[4 * q + 2]), __float_as_uint(z[4 * q + 3])),
+               i == 0 ? r_sk0 : r_sk1, o, (int)((2 * q * (uint32_t)d.nx_sc[i]) << 2));
+  };
+  const __amdgpu_buffer_rsrc_t r_add = make_rsrc((DUAL && NXN > 0) ? d.nx_add : nullptr, (DUAL && NXN > 0) ? (uint32_t)(d.B * d.add_sb * 4) : 0u);
+  auto zseed = [&](const pos_t& ps, const int ph, f32x16& z) {
+    const bool two = ph == 0 || ps.j < d.Fout1;
+    const int bin0 = 2 * ps.j + (two ? ph : 0);
+    const int bin = d.skip_Fh ? (two ? ph : 0) * d.skip_Fh + ps.j : bin0;
+    const uint32_t o = ((uint32_t)b * (uint32_t)d.add_sb + (uint32_t)ps.t * (uint32_t)d.add_st + (uint32_t)bin * (uint32_t)d.add_sf + (uint32_t)h * (uint32_t)d.add_sc) << 2;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint4 v = bload16(r_add, o, (int)((2 * q * (uint32_t)d.add_sc) << 2));
+      z[4 * q] = __uint_as_float(v.x), z[4 * q + 1] = __uint_as_float(v.y), z[4 * q + 2] = __uint_as_float(v.z), z[4 * q + 3] = __uint_as_float(v.w);
+    }
+  };
+  auto split_half = [&](const f32x16& X, const int s_, uint4 (&p)[NP]) {
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = X[8 * s_ + j];
+    split8p<NP>(x, p);
+  };
+  const float slope = d.slope;
+
+  // ---- the tail of one output phase, values consumed as soon as they exist.  Returns the phase's output value for C2 == 1.
+  auto tail = [&](const pos_t& pc, auto PH, const f32x16& L, const f32x16& R) __attribute__((always_inline)) -> float {
+    constexpr int ph = decltype(PH)::value;
+    f32x16 mL = ld16(fop + F_BLC + 4 * h), mR = ld16(fop + F_BRC + 4 * h);
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) {
+      uint4 p[NP];
+      split_half(L, s_, p);
+      mL = mm<NP>(img + CF::o_lc + s_ * BS + lane, p, mL);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) {
+      uint4 p[NP];
+      split_half(R, s_, p);
+      mR = mm<NP>(img + CF::o_rc + s_ * BS + lane, p, mR);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    f32x16 G;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) G[r] = L[r] * sigm2(mR[r]) + R[r] * sigm2(mL[r]);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (C2 == 1) {
+      const f32x16 vw_ = ld16(fop + F_WC2V + 4 * h);
+      float part_ = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) part_ += vw_[r] * G[r];
+      const float v_ = part_ + __shfl_xor(part_, 32) + fop[F_BC2];
+      return vmax(v_, slope * v_);
+    } else {
+      f32x16 Z0;
+      if constexpr (DUAL && NXN > 0) zseed(pc, ph, Z0);           // the addend: in flight during conv2
+      f32x16 O0 = ld16(fop + F_BC2 + 4 * h), O1 = ld16(fop + F_BC2 + 32 + 4 * h);
+#pragma unroll
+      for (int s_ = 0; s_ < 2; ++s_) {
+        uint4 p[NP];
+        split_half(G, s_, p);
+        O0 = mm<NP>(img + CF::o_c2 + s_ * BS + lane, p, O0);
+        __builtin_amdgcn_sched_barrier(0);
+        O1 = mm<NP>(img + CF::o_c2 + (2 + s_) * BS + lane, p, O1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        O0[r] = vmax(O0[r], slope * O0[r]);
+        O1[r] = vmax(O1[r], slope * O1[r]);
+      }
+      if constexpr (NXN == 0) {
+        // the 64-channel block output itself (encoder stage 5 -> TCM): lane offset + a scalar channel offset per store
+        const __amdgpu_buffer_rsrc_t r_out = make_rsrc(d.out, pc.valid ? 0xfffffffcu : 0u);   // lanes without a position: out of range, dropped
+        const uint32_t o = (uint32_t)(((int64_t)b * d.out_sb + (int64_t)pc.t * d.out_st + (int64_t)pc.j * d.out_sf + d.out_off + (int64_t)(4 * h) * d.out_sc) << 2);
+#pragma unroll
+        for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) bstore4<0>((m2 ? O1 : O0)[r], r_out, o, (int)(((32 * m2 + PDSE_KR(r)) * d.out_sc) << 2));
+      } else {
+        uint4 yp[2][2][NP];
+        split_half(O0, 0, yp[0][0]);
+        split_half(O0, 1, yp[0][1]);
+        split_half(O1, 0, yp[1][0]);
+        split_half(O1, 1, yp[1][1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NXN; ++i) {
+          f32x16 Z;
+          if constexpr (DUAL) Z = Z0;                              // DUAL: one chained tile, seeded by the encoder's skip half
+          else Z = ld16(fop + F_NXB + 32 * i + 4 * h);
+#pragma unroll
+          for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+            for (int s_ = 0; s_ < 2; ++s_) {
+              Z = mm<NP>(img + CF::o_nx + (i * 4 + m2 * 2 + s_) * BS + lane, yp[m2][s_], Z);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          if (i == 0) {
+            uint4 zp[2][NP];
+            split16p<NP>(Z, zp);
+            if constexpr (DUAL) {
+              store_planes(zp, pc.valid && (ph == 0 || pc.j < d.Fout1), pc.t, 2 * pc.j + ph);
+            } else {
+              store_planes(zp, pc.valid, pc.t, pc.j);
+              if (d.nx_row0) {   // uniform: the explicit pad frame of the next encoder stage = the folded bias
+                uint4 bp_[2][NP];
+                split16p<NP>(ld16(fop + F_NXB + 4 * h), bp_);
+                store_planes(bp_, pc.valid && pc.t == 0, -1, pc.j);
+              }
+            }
+          } else {
+            store_skip(Z, i - 1, pc);
+          }
+        }
+      }
+      return 0.f;
+    }
+  };
+
+  const int stride = gridDim.x;
+  int rd = blockIdx.x;
+  if (rd >= nrounds) return;
+  pos_t pc, pn;
+  locate(rd, pc);
+  uint4 ring[2][2][NP];   // two taps: [slot][q][plane]
+  raw_t raw;
+  if constexpr (IN4) request_in4(pc, raw);
+  else request_tap(pc, ring[0], 0);
+  while (true) {
+    locate(rd + stride, pn);
+    f32x16 L, R;
+    seed(pc, L, R);
+    if constexpr (IN4) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = ((raw.live >> (2 * q + (e >> 2))) & 1u) ? raw.raw[2 * q + (e >> 2)][e & 3] : 0.f;
+        uint4 kb[NP];
+        split8p<NP>(x, kb);
+        L = mm<NP>(img + CF::o_gL + q * BS + lane, kb, L);
+        __builtin_amdgcn_sched_barrier(0);
+        R = mm<NP>(img + CF::o_gR + q * BS + lane, kb, R);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      request_in4(pn, raw);                                        // the next tile's gathers: in flight during this tile's tail
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        if (i + 1 < NT) request_tap(pc, ring[(i + 1) & 1], i + 1);
+        else if constexpr (DUAL) request_tap(pc, ring[0], nth_tap(P1MASK, 0));   // phase 1's first tap: in flight during tail 0
+        else request_tap(pn, ring[0], 0);                                         // the next tile's first tap
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          L = mm<NP>(img + CF::o_gL + (i * 2 + q) * BS + lane, ring[i & 1][q], L);
+          __builtin_amdgcn_sched_barrier(0);
+          R = mm<NP>(img + CF::o_gR + (i * 2 + q) * BS + lane, ring[i & 1][q], R);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    const float v0 = tail(pc, std::integral_constant<int, 0>{}, L, R);
+    float v1 = 0.f;
+    if constexpr (DUAL) {
+      seed(pc, L, R);
+#pragma unroll
+      for (int k = 0; k < NT1; ++k) {
+        if (k + 1 < NT1) request_tap(pc, ring[(k + 1) & 1], nth_tap(P1MASK, k + 1));
+        else request_tap(pn, ring[0], 0);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          L = mm<NP>(img + CF::o_gL1 + (k * 2 + q) * BS + lane, ring[k & 1][q], L);
+          __builtin_amdgcn_sched_barrier(0);
+          R = mm<NP>(img + CF::o_gR1 + (k * 2 + q) * BS + lane, ring[k & 1][q], R);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      v1 = tail(pc, std::integral_constant<int, 1>{}, L, R);
+    }
+    if constexpr (C2 == 1) {
+      if (pc.valid && h == 0) {
+        float* const po = d.out + ((int64_t)b * d.out_sb + (int64_t)pc.t * d.out_st + (int64_t)pc.j * d.out_sf + d.out_off);
+        if constexpr (DUAL) {
+          const bool two = pc.j < d.Fout1;
+          const int64_t bin = d.out_sf >> 1;
+          if (two && bin == 1) store_pair(po, v0, v1);
+          else {
+            po[0] = v0;
+            if (two) po[bin] = v1;
+          }
+        } else {
+          po[0] = v0;
+        }
+      }
+    }
+    rd += stride;
+    if (rd >= nrounds) break;
+    pc = pn;
   }
 }
 
@@ -790,12 +1235,12 @@ __global__ __launch_bounds__(256) void planes_kernel(const pdse_planes_desc d) {
   for (int pl = 0; pl < NP; ++pl) base[pl * d.hp_Fp] = p[pl];
 }
 
-template <int NT, int P1MASK, int C2, int NXN, bool IN4, int NP, bool PIPE>
+template <int NT, int P1MASK, int C2, int NXN, bool IN4, int NP, bool PIPE, bool SPR = false>
 int launch_(const pdse_bglu_desc* d, hipStream_t s) {
   using CF = bglu_cfg<NT, P1MASK, C2, NXN, IN4, NP, PIPE>;
   const int P = d->Tout * d->Fout;
   const int rounds = (((P + 31) >> 5) + CF::WV - 1) / CF::WV;
-  static const int wgs = getenv("PDSE_BGLU_WGS") ? atoi(getenv("PDSE_BGLU_WGS")) : 256;
+  static const int wgs = PDSE_DIAG_ENV("PDSE_BGLU_WGS") ? atoi(PDSE_DIAG_ENV("PDSE_BGLU_WGS")) : 256;
   int gx = (wgs + d->B - 1) / d->B;
   if (gx > rounds) gx = rounds;
   if (gx < 1) gx = 1;
@@ -803,7 +1248,7 @@ int launch_(const pdse_bglu_desc* d, hipStream_t s) {
     pdse_set_error("bglu: LDS image too large");
     return 1;
   }
-  const void* fn = (const void*)bglu_kernel<NT, P1MASK, C2, NXN, IN4, NP, PIPE>;
+  const void* fn = (const void*)bglu_kernel<NT, P1MASK, C2, NXN, IN4, NP, PIPE, SPR>;
   static unsigned long long attr_mask = 0;   // per instantiation and device
   if (pdse_lds_attr(fn, &attr_mask, "bglu lds attribute")) return 1;
 #ifdef BGLU_DIAG
@@ -813,7 +1258,7 @@ int launch_(const pdse_bglu_desc* d, hipStream_t s) {
   for (int k = 0; k < 97; ++k) zs[k] = 0;
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bglu_slots), zs, sizeof(zs));
 #endif
-  hipLaunchKernelGGL((bglu_kernel<NT, P1MASK, C2, NXN, IN4, NP, PIPE>), dim3(gx, d->B, 1), dim3(64 * CF::WV), CF::lds_bytes, s, *d);
+  hipLaunchKernelGGL((bglu_kernel<NT, P1MASK, C2, NXN, IN4, NP, PIPE, SPR>), dim3(gx, d->B, 1), dim3(64 * CF::WV), CF::lds_bytes, s, *d);
 #ifdef BGLU_DIAG
   (void)hipStreamSynchronize(s);
   (void)hipMemcpyFromSymbol(z, HIP_SYMBOL(g_bglu_diag), sizeof(z));
@@ -834,15 +1279,43 @@ int launch_(const pdse_bglu_desc* d, hipStream_t s) {
   return pdse_check_launch("bglu");
 }
 
+int g_bglu_form = -1;   // pdse_bglu_set_form: -1 = chosen per geometry (default), 0 = 8 waves, 1 = 4 waves pipelined, 2 = 16 waves, 3 = 12 waves
+
+#ifdef BGLU_FORMS
+template <int NT, int P1MASK, int C2, int NXN, bool IN4, int NP, int WV>
+int launch16_(const pdse_bglu_desc* d, hipStream_t s) {
+  using CF = bglu_cfg<NT, P1MASK, C2, NXN, IN4, NP, false>;
+  const int P = d->Tout * d->Fout;
+  const int rounds = (((P + 31) >> 5) + WV - 1) / WV;
+  int gx = (256 + d->B - 1) / d->B;
+  if (gx > rounds) gx = rounds;
+  if (gx < 1) gx = 1;
+  if (CF::lds_bytes > 160 * 1024) {
+    pdse_set_error("bglu: LDS image too large");
+    return 1;
+  }
+  const void* fn = (const void*)bglu16_kernel<NT, P1MASK, C2, NXN, IN4, NP, WV>;
+  static unsigned long long attr_mask = 0;   // per instantiation and device
+  if (pdse_lds_attr(fn, &attr_mask, "bglu16 lds attribute")) return 1;
+  hipLaunchKernelGGL((bglu16_kernel<NT, P1MASK, C2, NXN, IN4, NP, WV>), dim3(gx, d->B, 1), dim3(64 * WV), CF::lds_bytes, s, *d);
+  return pdse_check_launch("bglu16");
+}
+
+#endif
+
 template <int NT, int P1MASK, int C2, int NXN, bool IN4, int NP>
 int launch(const pdse_bglu_desc* d, hipStream_t s) {
-  // PDSE_BGLU_PIPE = 0 | 1 overrides the form (tuning); default: see bglu_kernel
-  static const int force = getenv("PDSE_BGLU_PIPE") ? atoi(getenv("PDSE_BGLU_PIPE")) : -1;
   // measured (profiles/r03_bglu_forms.txt, B=32, T=401): the 8-wave form is 10-25 % faster than the pipelined 4-wave form
   // on every geometry and for both plane counts: a wave issues at most one instruction per four cycles whatever its type,
   // so two waves per SIMD double the issue rate, which the interleaving inside one wave does not make up for
-  const bool pipe = force >= 0 ? force != 0 : false;
-  return pipe ? launch_<NT, P1MASK, C2, NXN, IN4, NP, true>(d, s) : launch_<NT, P1MASK, C2, NXN, IN4, NP, false>(d, s);
+#ifdef BGLU_FORMS   // the forms that were measured and not kept (profiles/r03_bglu_forms.txt, r04_bglu_forms.txt): diagnostic builds only
+  const int form = g_bglu_form;
+  if (form == 1) return launch_<NT, P1MASK, C2, NXN, IN4, NP, true>(d, s);
+  if (form == 2) return launch16_<NT, P1MASK, C2, NXN, IN4, NP, 16>(d, s);
+  if (form == 3) return launch16_<NT, P1MASK, C2, NXN, IN4, NP, 12>(d, s);
+  if (form == 4) return launch_<NT, P1MASK, C2, NXN, IN4, NP, false, !IN4>(d, s);
+#endif
+  return launch_<NT, P1MASK, C2, NXN, IN4, NP, false>(d, s);
 }
 
 template <int NP>
@@ -945,6 +1418,18 @@ int pdse_bglu_launch(const pdse_bglu_desc* d, hipStream_t s) {
     }
   }
   return d->np == 3 ? dispatch<3>(d, s) : dispatch<1>(d, s);
+}
+
+int pdse_bglu_set_form(int form) {
+#ifdef BGLU_FORMS
+  const int top = 4;
+#else
+  const int top = 0;   // the product library holds the 8-wave form only
+#endif
+  if (form < -1 || form > top) return -2;
+  const int prev = g_bglu_form;
+  g_bglu_form = form;
+  return prev;
 }
 
 int pdse_planes_launch(const pdse_planes_desc* d, hipStream_t s) {

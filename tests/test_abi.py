@@ -97,10 +97,12 @@ def test_generated_block_schedule_is_current(tmp_path, monkeypatch):
     spec = importlib.util.spec_from_file_location("gen_bglu_sched", os.path.join(ROOT, "tools", "gen_bglu_sched.py"))
     gen = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(gen)
-    committed = open(gen.OUT).read()
+    committed, committed_forms = open(gen.OUT).read(), open(gen.OUT_FORMS).read()
     monkeypatch.setattr(gen, "OUT", str(tmp_path / "sched.inc"))
+    monkeypatch.setattr(gen, "OUT_FORMS", str(tmp_path / "sched_forms.inc"))
     gen.main()
     assert open(str(tmp_path / "sched.inc")).read() == committed
+    assert open(str(tmp_path / "sched_forms.inc")).read() == committed_forms      # the -DBGLU_FORMS schedules (diagnostic builds)
     for name, var in gen.VARIANTS:
         M, V = gen.build(var)
         slots = gen.schedule(M, V)

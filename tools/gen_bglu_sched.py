@@ -19,7 +19,8 @@ an mm one slot later.
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OUT = os.path.join(ROOT, "prior-diffuse_amd", "csrc", "bglu_sched.inc")
+OUT = os.path.join(ROOT, "prior-diffuse_amd", "csrc", "bglu_sched.inc")              # the product kernel's schedules (8 waves)
+OUT_FORMS = os.path.join(ROOT, "prior-diffuse_amd", "csrc", "bglu_sched_forms.inc")  # the measured-and-not-kept forms (-DBGLU_FORMS builds)
 
 
 class Item:
@@ -36,6 +37,7 @@ def popc(m):
 def build(variant):
     NT, P1, C2, NXN, IN4 = variant["NT"], variant["P1"], variant["C2"], variant["NXN"], variant["IN4"]
     pipe = variant.get("pipe", True)      # False: K loop and tail of the SAME tile, one after the other (8-wave workgroups)
+    spread = variant.get("spread", False) # vector-memory instructions one or two at a time, spread over the slots, instead of bursts of 4-6
     dual = P1 != 0
     accn = "accn" if pipe else "acc"
     kprio = -1 if pipe else 1000
@@ -63,19 +65,30 @@ def build(variant):
                      after="REQ_IN4();" if q == 2 else None)
     else:
         for tap in range(NT):
+            mine = []
             for q in range(2):
                 last = None
-                m("K.L%d%d" % (tap, q), "MM(%s.L, in.pl[%d][%d]);" % (accn, tap, q), "GL(%d,%d)" % (tap, q), prio=kprio)
+                mine.append(m("K.L%d%d" % (tap, q), "MM(%s.L, in.pl[%d][%d]);" % (accn, tap, q), "GL(%d,%d)" % (tap, q), prio=kprio))
                 last = m("K.R%d%d" % (tap, q), "MM(%s.R, in.pl[%d][%d]);" % (accn, tap, q), "GR(%d,%d)" % (tap, q), prio=kprio)
+                mine.append(last)
                 if (P1 >> tap) & 1:
                     rk = popc(P1 & ((1 << tap) - 1))
-                    m("K.L1%d%d" % (tap, q), "MM(%s.L1, in.pl[%d][%d]);" % (accn, tap, q), "GL1(%d,%d)" % (rk, q), prio=kprio)
+                    mine.append(m("K.L1%d%d" % (tap, q), "MM(%s.L1, in.pl[%d][%d]);" % (accn, tap, q), "GL1(%d,%d)" % (rk, q), prio=kprio))
                     last = m("K.R1%d%d" % (tap, q), "MM(%s.R1, in.pl[%d][%d]);" % (accn, tap, q), "GR1(%d,%d)" % (rk, q), prio=kprio)
-                if q == 1:
+                    mine.append(last)
+                if q == 1 and not spread:
                     if pipe:
                         last.after = "REQ(%d);" % tap
                     else:   # two taps ahead: the rest of this tile, then the first two taps of the next one
                         last.after = "REQ_CUR(%d);" % (tap + 2) if tap + 2 < NT else "REQ(%d);" % (tap + 2 - NT)
+            if spread:
+                # the six loads of the tap two ahead go out one (or two) at a time behind this tap's mm items: no wave ever
+                # queues six 1 KB requests at once, and the memory pipeline sees a steady trickle instead of eight waves' bursts
+                tgt = ("REQ_CUR1(%d" % (tap + 2)) if tap + 2 < NT else ("REQ1(%d" % (tap + 2 - NT))
+                loads = ["%s,%d,%d);" % (tgt, q, pl) for q in range(2) for pl in range(3)]
+                for k, code in enumerate(loads):
+                    it = mine[k % len(mine)]
+                    it.after = (it.after + " " if it.after else "") + code
     klast = last
 
     # ---- tails (current tile), phase A (and B)
@@ -104,12 +117,21 @@ def build(variant):
             v("%s.keep" % S, "V_KEEP(%s);" % S, [sy[1][1]], prio=base + 10)    # the split chunks are dropped for NXN == 0 (see emit)
             continue
         zs = []
-        if dual:    # the fp32 addend of chained tile 0 (16 loads): requested when conv2 starts, four to five slots before its use
+        if dual and spread:   # the addend's four 16-byte loads behind the four conv2 mm items, one each
+            c2[0][0].after = "V_ZOFF(%s,%d); V_ZLD(%s,0);" % (S, ph, S)
+            c2[0][1].after = "V_ZLD(%s,1);" % S
+            c2[1][0].after = "V_ZLD(%s,2);" % S
+            c2[1][1].after = "V_ZLD(%s,3);" % S
+            zs = [c2[1][1]]
+        elif dual:    # the fp32 addend of chained tile 0 (16 loads): requested when conv2 starts, four to five slots before its use
             zs = [v("%s.zseed" % S, "V_ZSEED(%s,%d);" % (S, ph), [c2[0][0]], prio=base + 28)]
         for i in range(NXN):
             nx = [m("%s.nx%d%d%d" % (S, i, m2, s), "MM(%s.Z%d, %s.yp[%d][%d]);" % (S, i, S, m2, s), "NXW(%d,%d,%d)" % (i, m2, s),
                     [sy[m2][s]] + (zs if i == 0 else []), prio=base + 20 - i) for m2 in range(2) for s in range(2)]
-            if i == 0:
+            if i == 0 and spread:   # each half's three plane stores right behind its split, and ahead of the other phase's remaining splits
+                for s in range(2):
+                    v("%s.sZ%d" % (S, s), "V_SZ(%s,%d); V_ST0Q(%s,%d,%d);" % (S, s, S, ph, s), [nx[3]], prio=base + 60)
+            elif i == 0:
                 sz = [v("%s.sZ%d" % (S, s), "V_SZ(%s,%d);" % (S, s), [nx[3]], prio=base + 10) for s in range(2)]
                 v("%s.st0" % S, "V_ST0(%s,%d);" % (S, ph), sz, prio=base + 9)
             else:
@@ -209,15 +231,21 @@ VARIANTS0 = [
 ]
 
 
-VARIANTS = VARIANTS0 + [(name + " - K loop, then tail (8 waves)", dict(var, id=var["id"] + 10, pipe=False)) for name, var in VARIANTS0]
+VARIANTS = (VARIANTS0 + [(name + " - K loop, then tail (8 waves)", dict(var, id=var["id"] + 10, pipe=False)) for name, var in VARIANTS0] +
+            [(name + " - K loop, then tail (8 waves), vector-memory instructions spread over the slots",
+              dict(var, id=var["id"] + 20, pipe=False, spread=True)) for name, var in VARIANTS0 if not var["IN4"]])
 
 
 def main():
-    with open(OUT, "w") as f:
-        f.write("// GENERATED by tools/gen_bglu_sched.py - do not edit.  One iteration of bglu_kernel's loop as a sequence of slots\n"
-                "// (one mm beside one chunk of vector work); vocabulary: csrc/bglu.hip.\n\n")
+    head = ("// GENERATED by tools/gen_bglu_sched.py - do not edit.  One iteration of bglu_kernel's loop as a sequence of slots\n"
+            "// (one mm beside one chunk of vector work); vocabulary: csrc/bglu.hip.\n\n")
+    with open(OUT, "w") as f, open(OUT_FORMS, "w") as g:
+        f.write(head)
+        g.write(head.replace("do not edit.", "do not edit.  Forms that were measured and are not the product kernel (4 waves software-\n"
+                                             "// pipelined, round 3; vector-memory instructions spread over the slots, round 4): compiled with -DBGLU_FORMS only."))
         for name, var in VARIANTS:
-            slots = emit(name, var, f)
+            product = not var.get("pipe", True) and not var.get("spread", False)
+            slots = emit(name, var, f if product else g)
             print("%-70s %3d slots" % (name, len(slots)))
             for i, (pm, pv) in enumerate(slots):
                 print("   %3d  %-12s %-12s" % (i, pm.name if pm else "-", pv.name if pv else "-"))

@@ -15,7 +15,12 @@ L = importlib.import_module("prior-diffuse_amd._lib")
 DEV = "cuda:0"
 
 
+ZERO = bool(os.environ.get("BGLU_ZERO"))     # all-zero operands: same instructions, no toggling - how much of a launch is the clock the chip holds under load
+
+
 def rnd16(*shape):
+    if ZERO:
+        return torch.zeros(*shape, device=DEV, dtype=torch.int16)
     return (torch.randn(*shape, device=DEV) * 0.1).to(torch.bfloat16).view(torch.int16)
 
 
@@ -39,7 +44,7 @@ def bench(name, NT, p1mask, C2, nx_n, Fin, Fout, Fout1, sf_in, taps, NP=3, B=32,
         return w.data_ptr()
 
     def Fv(n):
-        v = torch.randn(n, device=DEV) * 0.1
+        v = torch.randn(n, device=DEV) * (0.0 if ZERO else 0.1)
         keep.append(v)
         return v.data_ptr()
 
@@ -68,7 +73,7 @@ def bench(name, NT, p1mask, C2, nx_n, Fin, Fout, Fout1, sf_in, taps, NP=3, B=32,
         keep.append(nhp)
         d.nx_hp, d.nx_hp_sb, d.nx_Tp, d.nx_Fp, d.nx_t0, d.nx_f0 = nhp.data_ptr(), nhp[0].numel(), T + 1, nFp, 1, 2
         if p1mask:
-            add = torch.randn(B, 32, T, Fo + 1, device=DEV)
+            add = torch.randn(B, 32, T, Fo + 1, device=DEV) * (0.0 if ZERO else 1.0)
             keep.append(add)
             d.nx_add, d.add_sb, d.add_sc, d.add_st, d.add_sf = add.data_ptr(), add[0].numel(), 4 * T * (Fo + 1), 4 * (Fo + 1), 4   # [B][8][T][F][4]
         if not os.environ.get("NOPAR"):   # skip halves with their bins split by parity (both the encoder's stores and the decoder's loads)
@@ -97,6 +102,10 @@ DEC = [(0, 0), (0, -1), (-1, 0), (-1, -1)]
 DEC1 = [(0, 0), (0, -1), (0, -2), (-1, 0), (-1, -1), (-1, -2)]
 ENC = [(-1, 0), (-1, 1), (-1, 2), (0, 0), (0, 1), (0, 2)]
 if __name__ == "__main__":
+    form = int(os.environ.get("BGLU_FORM", "-1"))       # pdse_bglu_set_form: 0 = 8 waves, 1 = 4 waves pipelined, 2 = 16 waves, 3 = 12 waves
+    if L.load().pdse_bglu_set_form(form) == -2:
+        sys.exit("this libpdse.so holds the product form only: build with -DBGLU_FORMS (HIPCC_FLAGS) to time the others")
+    print("kernel form %d" % form, flush=True)
     for NP in (3, 1):
         for Fin in (4, 9, 19, 39):
             bench("decoder (4 taps, dual, nx 1)", 4, 5, 64, 1, Fin, Fin + 1, Fin, 1, DEC, NP)
