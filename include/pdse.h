@@ -748,6 +748,23 @@ int pdse_plan_time_ops(pdse_plan* p, int begin, int end, pdse_stream_t s, float*
 int pdse_plan_time_tag(pdse_plan* p, int tag, pdse_stream_t s, float* ms_out, int* count_out);
 void pdse_plan_destroy(pdse_plan* p);
 
+/* ---- network-level entry points (ABI 6; SURVEY 8b: prior_forward, eps_forward, the whole path) --------------------------------
+ * A recorded plan can be written to a file together with everything it points at (packed weights, tables, buffer sizes; the
+ * Python builders write it: prior-diffuse_amd/planfile.py) and loaded by a host that has neither Python nor the builders:
+ * pdse_plan_load allocates the buffers on the current device, uploads the data and rebases every descriptor.  The loaded plan
+ * owns its buffers (pdse_plan_destroy frees them); inputs and outputs are found by name.  The three calls below copy their
+ * device-resident arguments into / out of those buffers on stream s (device to device, asynchronous) around one pdse_plan_run:
+ * they replace self.model(feat) (trainer/complex_ddpm_trainer.py:941), self.model_ddpm(audio, init, t) (:968) and the per-batch
+ * body of generate_wav (:921-1016) for the (B, T) the plan was recorded for.  A null argument skips that copy. */
+int pdse_plan_load(const char* path, pdse_plan** out);
+int pdse_plan_region(const pdse_plan* p, const char* name, void** dev_ptr, uint64_t* nbytes);
+/* feat, x_init: [B,2,T,161] fp32 */
+int pdse_prior_forward(pdse_plan* p, const float* feat, float* x_init, pdse_stream_t s);
+/* x, x_init, eps: [B,2,T,161] fp32; t: [B] fp32 diffusion steps (fractional steps interpolate the embedding table) */
+int pdse_eps_forward(pdse_plan* p, const float* x, const float* x_init, const float* t, float* eps, pdse_stream_t s);
+/* wav, wav_out: [B,L] fp32; x_T, spec_out: [B,2,T,161] fp32 (spec_out may be null) */
+int pdse_enhance(pdse_plan* p, const float* wav, const float* x_T, float* wav_out, float* spec_out, pdse_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

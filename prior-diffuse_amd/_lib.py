@@ -218,7 +218,7 @@ EXPORTS = [
     "pdse_plan_create", "pdse_plan_add", "pdse_plan_size", "pdse_plan_set_device", "pdse_plan_clear", "pdse_plan_run",
     "pdse_plan_run_range",
     "pdse_plan_build_graph", "pdse_plan_launch_graph", "pdse_plan_time_ops", "pdse_plan_time_tag",
-    "pdse_plan_destroy",
+    "pdse_plan_destroy", "pdse_plan_load", "pdse_plan_region", "pdse_prior_forward", "pdse_eps_forward", "pdse_enhance",
 ]
 
 _DIRECT = {OP_GCONV: "pdse_gconv_f32", OP_TIME: "pdse_time_embed_f32", OP_EW: "pdse_ew_f32",

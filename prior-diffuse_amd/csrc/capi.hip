@@ -2,6 +2,7 @@
 // per-thread error text, direct launches and recorded plans (replayable, graph-capturable).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <string.h>
 
 #include <new>
@@ -67,8 +68,16 @@ struct pdse_op {
   pdse_any_desc d;
 };
 
+// a device allocation owned by a plan that was loaded from a file (pdse_plan_load)
+struct pdse_region {
+  std::string name;      // empty: internal; else the name an input / output is found by (pdse_plan_region)
+  void* ptr = nullptr;
+  uint64_t bytes = 0;
+};
+
 struct pdse_plan {
   std::vector<pdse_op> ops;
+  std::vector<pdse_region> regions;
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
   int device = -1;   // -1: whatever device is current on the calling thread
@@ -369,7 +378,194 @@ void pdse_plan_destroy(pdse_plan* p) {
   if (!p) return;
   if (p->exec) (void)hipGraphExecDestroy(p->exec);
   if (p->graph) (void)hipGraphDestroy(p->graph);
+  for (auto& r : p->regions)
+    if (r.ptr) (void)hipFree(r.ptr);
   delete p;
+}
+
+// ---- plan files: a recorded plan with everything it points at, for hosts without the Python builders ---------------------------
+// Layout (little endian, every item padded to 8 bytes; written by prior-diffuse_amd/planfile.py):
+//   "PDSEPLN1" | u32 abi | u32 nregions | u32 nops | u32 0
+//   region: u64 old_base | u64 bytes | u32 kind (low byte: 0 scratch, 1 zeroed, 2 data follows; bits 8..: element type, for
+//           readers that want typed views - ignored here) | u32 name_len | name | [data]
+//   op:     i32 kind | i32 tag | u32 desc_size | u32 nptr | u32 offsets[nptr] | descriptor bytes
+// Loading allocates every region on the current device (or the plan's), uploads / zeroes it and rebases the pointer fields of
+// every descriptor (listed by offset) from the recorded addresses to the new ones.
+}   // extern "C"
+namespace {
+struct reader {
+  FILE* f;
+  bool ok = true;
+  void get(void* dst, size_t n) {
+    if (ok && fread(dst, 1, n, f) != n) ok = false;
+  }
+  void skip_pad(size_t n) {
+    const size_t pad = (8 - (n & 7)) & 7;
+    char z[8];
+    if (pad) get(z, pad);
+  }
+  template <typename T>
+  T val() {
+    T v{};
+    get(&v, sizeof(T));
+    return v;
+  }
+};
+}  // namespace
+extern "C" {
+
+int pdse_plan_load(const char* path, pdse_plan** out) {
+  if (!path || !out) {
+    pdse_set_error("plan_load: null argument");
+    return 1;
+  }
+  FILE* f = fopen(path, "rb");
+  if (!f) {
+    pdse_set_error("plan_load: cannot open the file");
+    return 1;
+  }
+  reader rd{f};
+  pdse_plan* p = new (std::nothrow) pdse_plan();
+  auto fail = [&](const char* msg) {
+    pdse_set_error(msg);
+    fclose(f);
+    pdse_plan_destroy(p);
+    return 1;
+  };
+  if (!p) return fail("plan_load: out of memory");
+  char magic[8];
+  rd.get(magic, 8);
+  const uint32_t abi = rd.val<uint32_t>(), nreg = rd.val<uint32_t>(), nops = rd.val<uint32_t>();
+  (void)rd.val<uint32_t>();
+  if (!rd.ok || memcmp(magic, "PDSEPLN1", 8) != 0) return fail("plan_load: not a plan file");
+  if (abi != PDSE_ABI_VERSION) return fail("plan_load: the file was written for another ABI version");
+  if (nreg > (1u << 20) || nops > (1u << 22)) return fail("plan_load: implausible header");
+  std::vector<uint64_t> old_base(nreg);
+  std::vector<char> buf;
+  for (uint32_t i = 0; i < nreg; ++i) {
+    pdse_region r;
+    old_base[i] = rd.val<uint64_t>();
+    r.bytes = rd.val<uint64_t>();
+    const uint32_t kind = rd.val<uint32_t>() & 0xffu, nlen = rd.val<uint32_t>();
+    if (!rd.ok || nlen > 256 || kind > 2 || r.bytes == 0 || r.bytes > (1ull << 40)) return fail("plan_load: bad region record");
+    r.name.resize(nlen);
+    rd.get(&r.name[0], nlen);
+    rd.skip_pad(nlen);
+    if (pdse_check_hip(hipMalloc(&r.ptr, r.bytes), "plan_load: hipMalloc")) return fail(pdse_last_error());
+    p->regions.push_back(r);   // owned from here on (freed by destroy)
+    if (kind == 2) {
+      buf.resize(r.bytes);
+      rd.get(buf.data(), r.bytes);
+      rd.skip_pad(r.bytes);
+      if (!rd.ok) return fail("plan_load: truncated region data");
+      if (pdse_check_hip(hipMemcpy(r.ptr, buf.data(), r.bytes, hipMemcpyHostToDevice), "plan_load: upload")) return fail(pdse_last_error());
+    } else {
+      if (pdse_check_hip(hipMemset(r.ptr, 0, r.bytes), "plan_load: memset")) return fail(pdse_last_error());
+    }
+  }
+  std::vector<uint32_t> offs;
+  for (uint32_t i = 0; i < nops; ++i) {
+    pdse_op op;
+    op.kind = rd.val<int32_t>();
+    op.tag = rd.val<int32_t>();
+    const uint32_t dsz = rd.val<uint32_t>(), nptr = rd.val<uint32_t>();
+    const int want = op_size(op.kind);
+    if (!rd.ok || want < 0 || (uint32_t)want != dsz || nptr > dsz / 8) return fail("plan_load: bad operator record (descriptor size or kind)");
+    offs.resize(nptr);
+    rd.get(offs.data(), nptr * sizeof(uint32_t));
+    rd.skip_pad(nptr * sizeof(uint32_t));
+    memset(&op.d, 0, sizeof(op.d));
+    rd.get(&op.d, dsz);
+    rd.skip_pad(dsz);
+    if (!rd.ok) return fail("plan_load: truncated operator record");
+    char* const base = reinterpret_cast<char*>(&op.d);
+    for (uint32_t k = 0; k < nptr; ++k) {
+      if (offs[k] + 8 > dsz || (offs[k] & 7)) return fail("plan_load: bad pointer offset");
+      uint64_t v;
+      memcpy(&v, base + offs[k], 8);
+      if (!v) continue;
+      bool found = false;
+      for (uint32_t r = 0; r < nreg && !found; ++r) {
+        if (v >= old_base[r] && v < old_base[r] + p->regions[r].bytes) {
+          v = reinterpret_cast<uint64_t>(p->regions[r].ptr) + (v - old_base[r]);
+          found = true;
+        }
+      }
+      if (!found) return fail("plan_load: a descriptor points outside every recorded region");
+      memcpy(base + offs[k], &v, 8);
+    }
+    p->ops.push_back(op);
+  }
+  fclose(f);
+  *out = p;
+  return 0;
+}
+
+int pdse_plan_region(const pdse_plan* p, const char* name, void** ptr, uint64_t* nbytes) {
+  if (!p || !name || !ptr) {
+    pdse_set_error("plan_region: null argument");
+    return 1;
+  }
+  for (const auto& r : p->regions) {
+    if (r.name == name) {
+      *ptr = r.ptr;
+      if (nbytes) *nbytes = r.bytes;
+      return 0;
+    }
+  }
+  pdse_set_error("plan_region: no region of that name in this plan (plans recorded in this process keep their buffers in the caller)");
+  return 1;
+}
+
+// copy inputs into the plan's named regions, run it, copy the named outputs out - all on stream s, device to device
+static int plan_call(pdse_plan* p, const int n_in, const char* const* in_names, const void* const* in_ptrs, const int n_out,
+                     const char* const* out_names, void* const* out_ptrs, pdse_stream_t s) {
+  if (!p) {
+    pdse_set_error("forward: null plan");
+    return 1;
+  }
+  device_guard dg(p);
+  if (!dg.ok) return 1;
+  for (int i = 0; i < n_in; ++i) {
+    if (!in_ptrs[i]) continue;   // optional input left as the plan holds it
+    void* dst;
+    uint64_t n;
+    if (pdse_plan_region(p, in_names[i], &dst, &n)) return 1;
+    if (pdse_check_hip(hipMemcpyAsync(dst, in_ptrs[i], n, hipMemcpyDeviceToDevice, (hipStream_t)s), "forward: input copy")) return 1;
+  }
+  if (pdse_plan_run(p, s)) return 1;
+  for (int i = 0; i < n_out; ++i) {
+    if (!out_ptrs[i]) continue;
+    void* src;
+    uint64_t n;
+    if (pdse_plan_region(p, out_names[i], &src, &n)) return 1;
+    if (pdse_check_hip(hipMemcpyAsync(out_ptrs[i], src, n, hipMemcpyDeviceToDevice, (hipStream_t)s), "forward: output copy")) return 1;
+  }
+  return 0;
+}
+
+int pdse_prior_forward(pdse_plan* p, const float* feat, float* x_init, pdse_stream_t s) {
+  const char* in[] = {"x"};
+  const void* ip[] = {feat};
+  const char* on[] = {"out"};
+  void* op[] = {x_init};
+  return plan_call(p, 1, in, ip, 1, on, op, s);
+}
+
+int pdse_eps_forward(pdse_plan* p, const float* x, const float* x_init, const float* t, float* eps, pdse_stream_t s) {
+  const char* in[] = {"x", "x_init", "t"};
+  const void* ip[] = {x, x_init, t};
+  const char* on[] = {"out"};
+  void* op[] = {eps};
+  return plan_call(p, 3, in, ip, 1, on, op, s);
+}
+
+int pdse_enhance(pdse_plan* p, const float* wav, const float* x_T, float* wav_out, float* spec_out, pdse_stream_t s) {
+  const char* in[] = {"wav", "x_T"};
+  const void* ip[] = {wav, x_T};
+  const char* on[] = {"wav_out", "spec"};
+  void* op[] = {wav_out, spec_out};
+  return plan_call(p, 2, in, ip, 2, on, op, s);
 }
 
 }  // extern "C"

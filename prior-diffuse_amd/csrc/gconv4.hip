@@ -253,7 +253,9 @@ __global__ __launch_bounds__(512, 2) void gconv4_kernel(const pdse_gconv_desc d)
           const int m = f % MT;
           if (f < MT) acc0[m] = g4_mfma6(af[f], b1, b2, b3, acc0[m]);
           else acc1[m] = g4_mfma6(af[f], b1, b2, b3, acc1[m]);
-          if (more) g4_lds_read3(wn + f * (192 * 16), af[f]);
+          // (i + 1 < G4_CH is a compile-time fact once the loop is unrolled: no read is emitted behind the last possible block,
+          // whose destination registers would be dead - free for the compiler to re-use - while the read is still in flight)
+          if (i + 1 < G4_CH && more) g4_lds_read3(wn + f * (192 * 16), af[f]);
         }
       }
     }

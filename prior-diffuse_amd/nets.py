@@ -62,10 +62,13 @@ class Ctx:
         self.keep = []                  # per-plan tensors (activations, workspaces, per-step tables)
         self.bank = bank if bank is not None else WeightBank()
         self._banking = 0
+        self.scratch = set()            # data_ptr of buffers whose initial contents do not matter (planfile.py saves no bytes for them)
 
     def alloc(self, *shape, zero=False):
         t = (torch.zeros if zero else torch.empty)(*shape, dtype=torch.float32, device=self.device)
         self.keep.append(t)
+        if not zero:
+            self.scratch.add(t.data_ptr())
         return t
 
     def up(self, arr, dtype=np.float32):

@@ -31,7 +31,8 @@ from .schedule import inference_schedule as _inference_schedule
 class ComplexDDPMTrainer(object):
     MAX_PLANS = 3   # recorded (B, T) geometries kept alive (least recently used first out); weights are shared by all
 
-    def __init__(self, args, config, device=None, prior_state_dict=None, ddpm_state_dict=None, params=None, exclusive=None):
+    def __init__(self, args, config, device=None, prior_state_dict=None, ddpm_state_dict=None, params=None, exclusive=None,
+                 dtype=None):
         """args: .retrain .joint .draw .sigma .checkpoint .generated_wav
         config: .model.name, .train.{fft_num, win_size, win_shift, feat_type}
         Weights come from ``<args.checkpoint>/best_checkpoint.pth`` under the reference's
@@ -39,7 +40,16 @@ class ComplexDDPMTrainer(object):
         exclusive: this trainer is the only work on its GPU (the reference's situation: one process, one batch at a
         time), so small batches may take the persistent LSTM launch (csrc/lstmp.hip).  None: True unless the process is
         one rank of a torch.distributed job - a sharded run keeps the kernels that make an utterance's result
-        bit-identical whatever the number of ranks (prior-diffuse_amd/shard.py)."""
+        bit-identical whatever the number of ranks (prior-diffuse_amd/shard.py).
+        dtype: "f32" (default: the reference's arithmetic - fp32, or the fp32-equivalent exact three-way bf16 split) or "bf16",
+        the OPT-IN reduced-precision mode BASELINE configs 2/4/5 name (``SamplerPipeline(dtype="bf16")``: plain bf16 operands
+        and bf16 block-boundary tensors in the eps-net, tolerance 3e-2 rel-L2; never the default).  None: ``args.bf16`` when the
+        CLI set it (``main.py --bf16``), else "f32"."""
+        if dtype is None:
+            dtype = "bf16" if getattr(args, "bf16", False) else "f32"
+        if dtype not in ("f32", "bf16"):
+            raise ValueError("dtype must be 'f32' or 'bf16'")
+        self.dtype = dtype
         if exclusive is None:
             import torch.distributed as dist
 
@@ -116,7 +126,7 @@ class ComplexDDPMTrainer(object):
             pipe = self._pipes[key] = SamplerPipeline(
                 self.device, self.prior_name, self.prior_sd, self.ddpm_sd, B, T=T, L_=L_,
                 fast_sampling=self.params.fast_sampling, use_sigma=key[3], params=self.params, deltamu=self.deltamu,
-                cond=self.cond, bank=self.bank, xT_plus_init=self.xT_plus_init, exclusive=self.exclusive)
+                cond=self.cond, bank=self.bank, xT_plus_init=self.xT_plus_init, exclusive=self.exclusive, dtype=self.dtype)
         else:
             self._pipes.move_to_end(key)
         return pipe

@@ -89,3 +89,89 @@ def test_persistent_lstm_rejects_what_it_cannot_run(L):
     d.B, d.Bp, d.T, d.H, d.G = 9, 32, 4, 512, 2
     with pytest.raises(L.PdseError, match="glstmp: bad sizes"):
         L.launch(d)
+
+
+# ------------------------------------------------------------------ network-level C entry points on a saved plan
+def _client(tmp_path, kind, plan, golden_path, tol):
+    import os
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    lib = os.path.join(ROOT, "prior-diffuse_amd", "libpdse.so")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "helpers", "plan_client.py"), lib, kind, plan, golden_path, repr(tol)],
+                       capture_output=True, text=True, timeout=300)
+    print(r.stdout, r.stderr[-2000:])
+    assert r.returncode == 0, r.stderr[-2000:]
+    return float(r.stdout.strip().split()[-1])
+
+
+def test_saved_plans_through_the_bare_c_abi(L, weights, tmp_path):
+    """pdse_plan_load + pdse_eps_forward / pdse_prior_forward / pdse_enhance from a process that imports nothing of this package:
+    the reference's goldens for DiffUNet1 and GCRN (tests/golden/diffunet1_small.npz, gcrn_small.npz) at their own tolerances,
+    and the whole path wav -> wav equal to the pipeline that wrote the plan."""
+    import os
+
+    from conftest import GOLDEN
+
+    pf = pkg("planfile")
+    g = golden("diffunet1_small")
+    eps_plan = pf.save_eps_net(str(tmp_path / "eps.plan"), weights("DiffUNet1"), int(g["B"]), int(g["T"]), DEV)
+    assert _client(tmp_path, "eps", eps_plan, os.path.join(GOLDEN, "diffunet1_small.npz"), 2e-5) < 2e-5
+    prior_plan = pf.save_prior(str(tmp_path / "gcrn.plan"), "GCRN", weights("GCRN"), 2, 20, DEV)
+    assert _client(tmp_path, "prior", prior_plan, os.path.join(GOLDEN, "gcrn_small.npz"), 2e-5) < 2e-5
+    B, L_ = 2, 2400
+    pipe = pkg("pipeline").SamplerPipeline(DEV, "GCRN", weights("GCRN"), weights("DiffUNet1"), B, L_=L_)
+    wav, x_T = pkg("synth").synthetic_waveforms(B, L_, seed=31)
+    plan = pf.save_pipeline(str(tmp_path / "path.plan"), pipe)          # before the first run: buffers as the builders left them
+    out, spec = pipe.enhance(wav.to(DEV), x_T.to(DEV))
+    torch.cuda.synchronize()
+    ref = str(tmp_path / "ref.npz")
+    np.savez(ref, wav=wav.numpy(), x_T=x_T.numpy(), wav_out=out.cpu().numpy(), spec=spec.cpu().numpy())
+    assert _client(tmp_path, "enhance", plan, ref, 1e-12) == 0.0        # the same kernels on the same operands: bit for bit
+
+
+# ------------------------------------------------------------------ the bf16 rows of BASELINE configs 4 and 5 (config 2: test_gpu_round2.py)
+@pytest.mark.parametrize("config", [4, 5])
+def test_bf16_mode_tolerance_configs_4_and_5(L, weights, config, tmp_path):
+    """The opt-in bf16 mode at the shapes BASELINE names it for, against the reference's own fp32 results: config 4 (B=32, T=401,
+    aia_complex_trans_ri prior, 6 steps; tests/golden/full_aia_complex_trans_ri_seed404_t401_6step.npz) and config 5 (B=16,
+    L=160,000, T=1001, GCRN, STFT..ISTFT; full_generate_wav_seed505_l160000.npz).  Stated tolerance: 3e-2 rel-L2 on the
+    enhanced spectrogram and waveform (the mode's own, DESIGN.md 4.1g: 8 significand bits per operand over 15 blocks x 6 steps);
+    the prior is not in the mode and stays at its fp32 tolerance.  The mode must also be selectable from the drop-in class."""
+    from conftest import assert_rows2_and_checksums
+
+    P = pkg("pipeline").SamplerPipeline
+    if config == 4:
+        B, T = 32, 401
+        feat, x_T = pkg("synth").synthetic_spectrogram(B, T, seed=404)
+        pipe = P(DEV, "aia_complex_trans_ri", weights("aia_complex_trans_ri"), weights("DiffUNet1"), B, T=T, dtype="bf16")
+        spec, init = pipe.sample(feat.to(DEV), x_T.to(DEV))
+        g = golden("full_aia_complex_trans_ri_seed404_t401_6step")
+        e_init, e_spec = rel_l2(init[0].cpu(), g["init"][0]), rel_l2(spec[0].cpu(), g["out"][0])
+        print("bf16 mode, config 4: prior %.2e | spectrogram %.2e" % (e_init, e_spec))
+        assert e_init < 1e-4 and 1e-4 < e_spec < 3e-2
+    else:
+        B, L_ = 16, 160000
+        wav, x_T = pkg("synth").synthetic_waveforms(B, L_, seed=505)
+        wav = wav * torch.linspace(0.05, 2.0, B)[:, None]
+        pipe = P(DEV, "GCRN", weights("GCRN"), weights("DiffUNet1"), B, L_=L_, dtype="bf16")
+        assert pipe.T == 1001 and all(d.np == 1 for d, _ in pipe.descs if isinstance(d, (L.BgluDesc, L.Tcm2Desc)))
+        out, spec = pipe.enhance(wav.to(DEV), x_T.to(DEV))
+        g = golden("full_generate_wav_seed505_l160000")
+        e_wav = rel_l2(out[0].cpu(), g["wav"])
+        e_spec = rel_l2(np.asarray(spec[:1].cpu(), np.float64)[:, :, ::2], g["spec_rows2"])
+        print("bf16 mode, config 5: spectrogram %.2e | waveform %.2e" % (e_spec, e_wav))
+        assert 1e-4 < e_spec < 3e-2 and e_wav < 3e-2
+        import argparse
+
+        ns = argparse.Namespace
+        tr = pkg("trainer").ComplexDDPMTrainer(
+            ns(retrain=False, joint=True, draw=False, sigma=False, checkpoint="x", generated_wav=str(tmp_path), bf16=True),
+            ns(model=ns(name="GCRN"), train=ns(fft_num=320, win_size=320, win_shift=160, feat_type="sqrt")),
+            device=DEV, prior_state_dict=weights("GCRN"), ddpm_state_dict=weights("DiffUNet1"))
+        assert tr.dtype == "bf16"
+        y = tr.enhance(wav[:1, :4000].to(DEV), x_T=x_T[:1, :, :26].to(DEV))
+        p = tr._pipes[next(reversed(tr._pipes))]
+        assert p.dtype == "bf16" and all(d.np == 1 for d, _ in p.descs if isinstance(d, L.BgluDesc)) and torch.isfinite(y).all()

@@ -1,0 +1,27 @@
+# round-4 evidence run on the GPU box (gpurun -- 'bash tools/scripts/r04_prof.sh'); summaries are copied to profiles/ by hand.
+# Every profiled command runs with --no-file-loop --no-fp32-compare --no-cpu-baseline: the trace then holds the B = 32 launches of
+# the graded pass only, so the per-kernel averages of the kernel_stats CSVs can be used for the roofline directly.
+set -o pipefail
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+O=gpurun_out/r4p; mkdir -p $O
+python bench.py > $O/bench_default.json 2> $O/bench_default.err; tail -c 300 $O/bench_default.json; echo
+P="--no-cpu-baseline --no-fp32-compare --no-file-loop"
+rocprofv3 --kernel-trace --stats -d $O/ks_default -o p --output-format csv -- python3 bench.py $P > $O/bench_default_prof.json 2> $O/ks_default.log
+rocprofv3 --kernel-trace --stats -d $O/ks_seq -o p --output-format csv -- python3 bench.py $P --inflight 1 --no-graph --steps 3 --warmup 1 > $O/bench_seq_prof.json 2> $O/ks_seq.log
+for c in FETCH_SIZE WRITE_SIZE; do rocprofv3 --pmc $c -d $O/pmc_$c -o p --output-format csv -- python3 bench.py $P --inflight 1 --no-graph --steps 1 --warmup 0 > /dev/null 2> $O/pmc_$c.log; done
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d $O/pmc_SQ -o p --output-format csv -- python3 bench.py $P --inflight 1 --no-graph --steps 1 --warmup 0 > /dev/null 2> $O/pmc_SQ.log
+for d in pmc_FETCH_SIZE pmc_WRITE_SIZE pmc_SQ; do f=$(find $O/$d -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp $f $O/$d/p_counter_collection.csv; done
+python tools/summarize_pmc.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_SQ $O/pmc_traffic.json > $O/pmc_traffic.log 2>&1; tail -3 $O/pmc_traffic.log
+python tools/pmc_summary.py $O/pmc_SQ > $O/pmc_sq.txt 2>&1
+for f in $(find $O/ks_default $O/ks_seq -name "*kernel_stats.csv"); do echo $f; head -6 $f | cut -c1-150; done
+python bench.py --no-cpu-baseline --fp32 > $O/bench_fp32.json 2> /dev/null
+python bench.py --no-cpu-baseline --bf16 > $O/bench_bf16.json 2> /dev/null
+python bench.py --no-cpu-baseline --prior aia_complex_trans_ri > $O/bench_aia_ri.json 2> /dev/null
+python bench.py --no-cpu-baseline --prior dual_aia_trans_merge_crm > $O/bench_aia_dual.json 2> /dev/null
+python bench.py --no-cpu-baseline --seconds 10 --batch 16 > $O/bench_10s_b16.json 2> /dev/null
+python bench.py --no-cpu-baseline --full-schedule > $O/bench_full50.json 2> /dev/null
+python tools/time_eps.py > $O/eps_per_launch.txt 2>&1
+python tools/time_gcrn.py > $O/gcrn_per_launch.txt 2>&1
+python tools/time_glstm.py > $O/glstm_timing.txt 2>&1
+python tools/time_glstm.py --persist >> $O/glstm_timing.txt 2>&1
+for f in default fp32 bf16 aia_ri aia_dual 10s_b16 full50; do python -c "import json; d=json.loads(open('$O/bench_$f.json').read().strip().splitlines()[-1]); print('$f', d['ms_per_step'], d.get('ms_per_step_sequential'), d['value'], d['dtype'], d.get('file_loop_b1'))"; done
