@@ -99,6 +99,8 @@ def main():
                     help="the opt-in bf16 mode (BASELINE configs 2/4/5): plain bf16 operands and bf16 conv1 tensors in the "
                          "eps-net's BiConv(Trans)GLU blocks (SamplerPipeline(dtype='bf16')); own tolerance (3e-2), dtype 'bf16' "
                          "in the line - never the graded default")
+    ap.add_argument("--tcm-launches", action="store_true",
+                    help="A/B: one launch per TCM residual block (round 3) instead of the persistent stack launch (csrc/tcm2.hip: tcm2s_kernel)")
     ap.add_argument("--no-file-loop", action="store_true",
                     help="skip the B = 1 generate_wav file loop reported as file_loop_b1 (profiling runs: keeps its B = 1 launches "
                          "out of the kernel trace, so that per-kernel averages of the trace are B = 32 launches only)")
@@ -158,6 +160,8 @@ def main():
     nets = importlib.import_module("prior-diffuse_amd.nets")
     shard = importlib.import_module("prior-diffuse_amd.shard")
 
+    if args.tcm_launches:
+        nets.EpsNetPlan.tcm_stack = False
     B, L_ = args.batch, int(args.seconds * 16000)
     T = 1 + L_ // 160
     gs, ds = synth.make_state_dict(args.prior), synth.make_state_dict("DiffUNet1")
@@ -204,6 +208,12 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
+    # persistent launches (TCM stack; the small-batch LSTM) wait for their own workgroups with bounded polls: a launch that gave
+    # up has left its code in a status word - a timed region with one of those set is not a measurement
+    for p_ in (runner.pipes if hasattr(runner, "pipes") else [runner]):
+        for st_ in (getattr(p_.eps, "tcm_status", None), getattr(p_.prior, "status", None), getattr(p_.prior, "tcm_status", None)):
+            if st_ is not None and int(st_[0].item()) != 0:
+                sys.exit("bench.py: a persistent launch gave up waiting (status %d): result invalid" % int(st_[0].item()))
     if dist is not None:
         tt = torch.tensor([elapsed], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -230,15 +240,25 @@ def main():
     pipe.stft.wav.copy_(wav)
     pipe.xT_in.copy_(x_T)
     torch.cuda.synchronize()
-    # the strictly sequential pass (one batch at a time, one stream, hipGraph replay) beside the in-flight number
+    # the strictly sequential pass (one batch at a time, one stream, hipGraph replay) beside the in-flight number.  A pipeline that
+    # runs alone owns the GPU (exclusive=True): the TCM stack is then one persistent launch (csrc/tcm2.hip: tcm2s_kernel, bit-
+    # identical results); the in-flight runners and the per-stage timing below keep one launch per block
     seq_steps = max(3, min(args.steps, 10))
     pipe.enhance(wav, x_T, graph=use_graph)
     torch.cuda.synchronize()
+    pseq = pipeline.SamplerPipeline(dev, args.prior, gs, ds, B, L_=L_, fast_sampling=fast, bank=pipe.bank, split_bf16=args.split_bf16,
+                                    dtype=dtype, exclusive=not args.tcm_launches)
+    pseq.enhance(wav, x_T, graph=use_graph)
+    torch.cuda.synchronize()
     ts = time.perf_counter()
     for _ in range(seq_steps):
-        pipe.run(graph=use_graph)
+        pseq.run(graph=use_graph)
     torch.cuda.synchronize()
     ms_sequential = (time.perf_counter() - ts) / seq_steps * 1e3
+    pseq.check()
+    tcm_stack_ms = pseq.plan.time_tag(nets.TAG_TCM, stream)[0]
+    del pseq
+    torch.cuda.empty_cache()
     fp32_exact = None
     if args.split_bf16 and not args.no_fp32_compare:   # the same pass with exact fp32 MFMA arithmetic everywhere, measured in the same run
         p32 = pipeline.SamplerPipeline(dev, args.prior, gs, ds, B, L_=L_, fast_sampling=fast, split_bf16=False)
@@ -450,6 +470,8 @@ def main():
         "ms_per_step": round(ms_per_step, 3), "ms_per_step_sequential": round(ms_sequential, 3),
         # box-independent: summed hipEvent durations of the eps-net launches (the roofline's denominator) and of everything
         "eps_net_kernel_ms": round(eps_ms, 4), "all_kernel_ms": round(sum(v["ms"] for v in per_tag.values()), 4),
+        "sequential_note": "one batch at a time owns the GPU: TCM stack as one persistent launch (%.3f ms per pass; %.3f as %d launches in "
+                           "the in-flight pass)" % (tcm_stack_ms, per_tag["tcm"]["ms"], per_tag["tcm"]["launches"]),
         "value_sequential": round(B * args.seconds / (ms_sequential * 1e-3), 2),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16" if args.bf16 else ("bf16x3" if args.split_bf16 else "f32"), "data": "synthetic",
@@ -490,6 +512,12 @@ def dry_run(args, dist, world, rank):
         time.sleep(0.001 * (1 + rank))          # uneven ranks: the reduction must return the slowest
     barrier()
     elapsed = time.perf_counter() - t0
+    # persistent launches (TCM stack; the small-batch LSTM) wait for their own workgroups with bounded polls: a launch that gave
+    # up has left its code in a status word - a timed region with one of those set is not a measurement
+    for p_ in (runner.pipes if hasattr(runner, "pipes") else [runner]):
+        for st_ in (getattr(p_.eps, "tcm_status", None), getattr(p_.prior, "status", None), getattr(p_.prior, "tcm_status", None)):
+            if st_ is not None and int(st_[0].item()) != 0:
+                sys.exit("bench.py: a persistent launch gave up waiting (status %d): result invalid" % int(st_[0].item()))
     mine = elapsed
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64)

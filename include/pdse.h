@@ -524,6 +524,22 @@ typedef struct pdse_tcm2_desc {
   int32_t pad_;
 } pdse_tcm2_desc;
 
+/* The residual blocks of the TCM stack as ONE launch (ABI 6, csrc/tcm2.hip: tcm2s_kernel): blk[0..n-1] are the mode-0
+ * descriptors in order, each reading the hs its predecessor wrote (two hs buffers alternate; blk[0].hs comes from the mode-1
+ * launch in front).  Every
+ * workgroup (utterance, 32-frame tile) walks the blocks itself and waits for the tiles within +-2 of its utterance through the
+ * progress counters in flags; results are bit-identical to n launches of pdse_tcm2_bf16x3.
+ *   flags  [B][ceil(T / 32)] int32, zeroed by every launch
+ *   status [1] int32: 0, or the block (+1) at which a workgroup gave up waiting (bounded waits; the caller zeroes it once) */
+#define PDSE_TCM2S_MAX 20
+typedef struct pdse_tcm2s_desc {
+  pdse_tcm2_desc blk[PDSE_TCM2S_MAX];
+  int32_t* flags;
+  int32_t* status;
+  int32_t n;
+  int32_t pad_;
+} pdse_tcm2s_desc;
+
 /* GroupNorm(1,C) statistics + the AIA layer update (dbaiat.py:142,147-148):
  *   out = base + k1 * gn(row) + k2 * gn(col);  stats scratch [B][4] (sum,sumsq of row | col). */
 typedef struct pdse_gncomb_desc {
@@ -683,7 +699,8 @@ enum pdse_op_kind {
   PDSE_OP_TCM2 = 22,
   PDSE_OP_BGLU = 23,
   PDSE_OP_PLANES = 24,
-  PDSE_OP_GLSTMP = 25
+  PDSE_OP_GLSTMP = 25,
+  PDSE_OP_TCM2S = 26
 };
 
 int pdse_abi_version(void);
@@ -716,6 +733,7 @@ int pdse_masked_mse_f32(const pdse_maskloss_desc* d, pdse_stream_t s);
 int pdse_glstm_f32(const pdse_glstm_desc* d, pdse_stream_t s);
 int pdse_glstm_persistent_f32(const pdse_glstmp_desc* d, pdse_stream_t s);
 int pdse_tcm2_bf16x3(const pdse_tcm2_desc* d, pdse_stream_t s);
+int pdse_tcm2_stack_bf16x3(const pdse_tcm2s_desc* d, pdse_stream_t s);
 int pdse_bglu_planes(const pdse_bglu_desc* d, pdse_stream_t s);
 int pdse_split_planes(const pdse_planes_desc* d, pdse_stream_t s);
 /* Kernel form of pdse_bglu_planes (ABI 6; process-wide, tuning only): -1 / 0 = 8 waves with the generated slot schedule

@@ -53,6 +53,7 @@ union pdse_any_desc {
   pdse_transpose_desc transpose;
   pdse_tcm_desc tcm;
   pdse_tcm2_desc tcm2;
+  pdse_tcm2s_desc tcm2s;
   pdse_crm_desc crm;
   pdse_gcrnlast_desc gcrnlast;
   pdse_maskloss_desc maskloss;
@@ -121,6 +122,7 @@ static int op_size(int kind) {
     case PDSE_OP_TRANSPOSE: return (int)sizeof(pdse_transpose_desc);
     case PDSE_OP_TCM: return (int)sizeof(pdse_tcm_desc);
     case PDSE_OP_TCM2: return (int)sizeof(pdse_tcm2_desc);
+    case PDSE_OP_TCM2S: return (int)sizeof(pdse_tcm2s_desc);
     case PDSE_OP_CRM: return (int)sizeof(pdse_crm_desc);
     case PDSE_OP_GCRNLAST: return (int)sizeof(pdse_gcrnlast_desc);
     case PDSE_OP_MASKLOSS: return (int)sizeof(pdse_maskloss_desc);
@@ -158,6 +160,7 @@ static int launch_op(const pdse_op& op, hipStream_t s) {
     case PDSE_OP_GLSTM: return pdse_glstm_launch(&op.d.glstm, s);
     case PDSE_OP_GLSTMP: return pdse_glstmp_launch(&op.d.glstmp, s);
     case PDSE_OP_TCM2: return pdse_tcm2_launch(&op.d.tcm2, s);
+    case PDSE_OP_TCM2S: return pdse_tcm2s_launch(&op.d.tcm2s, s);
     case PDSE_OP_BGLU: return pdse_bglu_launch(&op.d.bglu, s);
     case PDSE_OP_PLANES: return pdse_planes_launch(&op.d.planes, s);
     default: pdse_set_error("plan: unknown op kind"); return 1;
@@ -194,6 +197,7 @@ int pdse_masked_mse_f32(const pdse_maskloss_desc* d, pdse_stream_t s) { return p
 int pdse_glstm_f32(const pdse_glstm_desc* d, pdse_stream_t s) { return pdse_glstm_launch(d, (hipStream_t)s); }
 int pdse_glstm_persistent_f32(const pdse_glstmp_desc* d, pdse_stream_t s) { return pdse_glstmp_launch(d, (hipStream_t)s); }
 int pdse_tcm2_bf16x3(const pdse_tcm2_desc* d, pdse_stream_t s) { return pdse_tcm2_launch(d, (hipStream_t)s); }
+int pdse_tcm2_stack_bf16x3(const pdse_tcm2s_desc* d, pdse_stream_t s) { return pdse_tcm2s_launch(d, (hipStream_t)s); }
 int pdse_bglu_planes(const pdse_bglu_desc* d, pdse_stream_t s) { return pdse_bglu_launch(d, (hipStream_t)s); }
 int pdse_split_planes(const pdse_planes_desc* d, pdse_stream_t s) { return pdse_planes_launch(d, (hipStream_t)s); }
 

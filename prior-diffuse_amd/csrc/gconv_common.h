@@ -723,6 +723,13 @@ __device__ __forceinline__ uint4 bload16(const __amdgpu_buffer_rsrc_t r, const u
   const v4i_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, 0);
   return make_uint4((uint32_t)v.x, (uint32_t)v.y, (uint32_t)v.z, (uint32_t)v.w);
 }
+// AUX: cache policy bits of the load (16 = sc1: served by L2 / memory, never by this CU's L1 - data another workgroup of the same
+// launch has written)
+template <int AUX>
+__device__ __forceinline__ uint4 bload16a(const __amdgpu_buffer_rsrc_t r, const uint32_t voff, const int soff) {
+  const v4i_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, AUX);
+  return make_uint4((uint32_t)v.x, (uint32_t)v.y, (uint32_t)v.z, (uint32_t)v.w);
+}
 __device__ __forceinline__ float bload4(const __amdgpu_buffer_rsrc_t r, const uint32_t voff, const int soff) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, soff, 0));
 }

@@ -49,6 +49,7 @@ int pdse_maskloss_launch(const pdse_maskloss_desc* d, hipStream_t s);
 int pdse_glstm_launch(const pdse_glstm_desc* d, hipStream_t s);
 int pdse_glstmp_launch(const pdse_glstmp_desc* d, hipStream_t s);   /* csrc/lstmp.hip */
 int pdse_tcm2_launch(const pdse_tcm2_desc* d, hipStream_t s);
+int pdse_tcm2s_launch(const pdse_tcm2s_desc* d, hipStream_t s);   /* csrc/tcm2.hip: the whole stack as one launch */
 int pdse_bglu_launch(const pdse_bglu_desc* d, hipStream_t s);
 int pdse_planes_launch(const pdse_planes_desc* d, hipStream_t s);
 int pdse_gru3_launch(const pdse_gru_desc* d, hipStream_t s);   /* csrc/gru3.hip, reached through pdse_gru_launch */

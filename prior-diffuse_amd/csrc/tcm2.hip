@@ -123,14 +123,20 @@ __device__ long long* g_trace = nullptr;   // PDSE_TCM2_TRACE=1 (diagnostic): [w
 // NT = frame tiles of 32 per wave, TW = teams of 8 waves per workgroup (workgroup = 32 NT TW frames of one utterance).
 // The teams of a workgroup run the same instruction stream on neighbouring frames between the same barriers, so
 // their weight requests reach the CU's L1 together.
-template <int MODE, int NT, int TW, int NP = 3>
-__global__ __launch_bounds__(512 * TW, NT == 1 ? 4 : 2) void tcm2_kernel(const pdse_tcm2_desc d) {
-  // par: [64][4] main bias, mask bias, BN scale, BN shift of the gate | [256] conv2 bias | [64] next conv1 bias |
-  //      [64][4] next block's input transforms: main scale, shift, mask scale, shift
-  __shared__ __attribute__((aligned(16))) float par[832];
-  __shared__ float part_[TW * NT][4][64][33];                                    // A: [2 branch + kh]; C: partial sums of four waves
-  __shared__ __attribute__((aligned(16))) char gls_[TW * NT][NP * 32 * GL_ROW];   // conv2's B operand: [plane][frame][64 + 8 bf16]
-  const int tid = threadIdx.x & 511;                                             // within the team
+// One residual block for the frame tile(s) of this workgroup.  HSA: cache policy of the hs loads - 0 for one launch per block, 16
+// (sc1) inside the persistent stack kernel, where hs was written by other workgroups of the SAME launch (tcm2s_kernel below).
+struct tcm2_nowait {
+  __device__ __forceinline__ void operator()() const {}
+};
+
+// hs_ready(): called once, by every thread, after the block's first weight requests have gone out and before the first hs request
+// (the stack kernel waits for the neighbours' progress counters there, with the weight fetch already in flight).
+template <int MODE, int NT, int TW, int NP, int HSA, typename Wait = tcm2_nowait>
+__device__ __forceinline__ void tcm2_block(const pdse_tcm2_desc& d, float* const par, float (*const part_)[4][64][33],
+                                           char (*const gls_)[NP * 32 * GL_ROW], const Wait hs_ready = Wait()) {
+  int tid_ = threadIdx.x & 511;                                                  // within the team
+  if constexpr (HSA != 0) asm volatile("" : "+v"(tid_));   // stack kernel: per-lane indices are recomputed per block, not kept live (and spilled) across the block loop
+  const int tid = tid_;
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int team = wv >> 3, wave = wv & 7;
@@ -140,7 +146,7 @@ __global__ __launch_bounds__(512 * TW, NT == 1 ? 4 : 2) void tcm2_kernel(const p
   const int b = blockIdx.y, t0 = (blockIdx.x * TW + team) * (32 * NT), T = d.T, TP = T + 2 * HS_PAD;
   const bool chain = d.hs_out != nullptr;
 #ifdef PDSE_DIAG
-  long long* trace = g_trace;
+  long long* trace = (HSA == 0) ? g_trace : nullptr;
 #else
   long long* trace = nullptr;
 #endif
@@ -185,24 +191,44 @@ __global__ __launch_bounds__(512 * TW, NT == 1 ? 4 : 2) void tcm2_kernel(const p
     // for the same weight lines at the same moment (-6 % on phase A); a function of the frame tile only, so an
     // utterance's result does not depend on its place in the batch
     const int js = (int)(blockIdx.x % 5);
-    auto request = [&](int i) {
+    auto request_w = [&](int i) {
+      const int slot = i % D;
+      const int j = (i + js) % 5;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int p = 0; p < NP; ++p) qa[slot][mi][p] = bload16(r_wa, lane * 16, ((mi * 20 + j) * NP + p) * 1024);
+    };
+    auto request_h = [&](int i) {
       const int slot = i % D;
       const int j = (i + js) % 5;
       const int kbi = 5 * kq + j;                              // wave-uniform: tap = kbi >> 2, channel block = kbi & 3
       const int hq = (kbi & 3) * (2 * NP) * plane + (kbi >> 2) * d.dil * 16;
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int p = 0; p < NP; ++p) qa[slot][mi][p] = bload16(r_wa, lane * 16, ((mi * 20 + j) * NP + p) * 1024);
-#pragma unroll
       for (int n = 0; n < NT; ++n)
 #pragma unroll
-        for (int p = 0; p < NP; ++p) qb[slot][n][p] = bload16(r_hs, roff[n], hq + p * plane);
+        for (int p = 0; p < NP; ++p) qb[slot][n][p] = bload16a<HSA>(r_hs, roff[n], hq + p * plane);
     };
+    auto request = [&](int i) {
+      request_w(i);
+      request_h(i);
+    };
+    if constexpr (HSA != 0) {   // stack kernel: the weights of the first K blocks fly while the neighbours' counters are awaited
+#pragma unroll
+      for (int j = 0; j < D; ++j) request_w(j);
+      __builtin_amdgcn_sched_barrier(0);
+      hs_ready();
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        request_h(j);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
 #pragma unroll
     for (int j = 0; j < D; ++j) {
       request(j);
       __builtin_amdgcn_sched_barrier(0);   // slot 0's operands are requested first (hipcc interleaved the two slots)
+    }
     }
     f32x16 acc[2][NT];
 #pragma unroll
@@ -410,6 +436,81 @@ __global__ __launch_bounds__(512 * TW, NT == 1 ? 4 : 2) void tcm2_kernel(const p
   STAMP(7);
 }
 
+template <int MODE, int NT, int TW, int NP = 3>
+__global__ __launch_bounds__(512 * TW, NT == 1 ? 4 : 2) void tcm2_kernel(const pdse_tcm2_desc d) {
+  // par: [64][4] main bias, mask bias, BN scale, BN shift of the gate | [256] conv2 bias | [64] next conv1 bias |
+  //      [64][4] next block's input transforms: main scale, shift, mask scale, shift
+  __shared__ __attribute__((aligned(16))) float par[832];
+  __shared__ float part_[TW * NT][4][64][33];                                    // A: [2 branch + kh]; C: partial sums of four waves
+  __shared__ __attribute__((aligned(16))) char gls_[TW * NT][NP * 32 * GL_ROW];   // conv2's B operand: [plane][frame][64 + 8 bf16]
+  tcm2_block<MODE, NT, TW, NP, 0>(d, par, part_, gls_);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// [r4] The 18 residual blocks of the TCM stack (model/diff3.py:215-277) as ONE launch (the first block's conv1 stays the small
+// mode-1 launch in front of it: with both block forms in one kernel hipcc spilled 14 registers at the 128 that two workgroups
+// per CU allow).
+// One launch per block leaves ~9 us of every 25 us outside the waves (launch boundary, ramp, the end-of-kernel write-back), 19
+// times per forward.  What a block needs from other workgroups is only the bottleneck tensor hs of the frame tiles within
+// +-2 (dilation <= 32, 32-frame tiles) of the SAME utterance; the residual stream x is private to a tile.  So every workgroup
+// (utterance b, tile f) walks the blocks itself: before block i it waits until tiles f-2..f+2 of its utterance have published
+// block i-1 (progress counters, one per (b, f): the same wait also keeps a neighbour from still READING the hs buffer this block
+// is about to overwrite - the ping-pong), and after its stores have drained it publishes block i.
+//   * hs is written through (sc0 sc1 stores, as before) and, in this kernel, read with sc1 loads (never from the CU's L1); the
+//     counter is an sc1 store behind every wave's s_waitcnt vmcnt(0) and the workgroup barrier, polled with sc1 loads by the
+//     five lanes that own a neighbour each (MI355X_MICROARCH.md, valid forms: payload and flag sc1 on both sides, no fence);
+//   * the counters are zeroed by a memset node in front of the launch; every wait is bounded (a workgroup that gives up records
+//     the block in d.status and leaves, its neighbours follow), so a launch cannot hang;
+//   * liveness needs the 13 workgroups of an utterance to become resident, not the whole grid: their dependencies never leave
+//     the utterance, so a partially resident launch (other kernels still draining, other batches in flight) keeps completing
+//     utterances and freeing slots.
+// Same arithmetic, same order as one launch per block: results are bit-identical (tests/test_gpu_round4.py).
+// ---------------------------------------------------------------------------------------------------------------
+#define TCM2S_SPINS 60000   // polls of one neighbour counter before a workgroup gives up (~50-100 ms)
+
+template <int NP>
+__global__ __launch_bounds__(512, 4) void tcm2s_kernel(const pdse_tcm2s_desc s) {
+  __shared__ __attribute__((aligned(16))) float par[832];
+  __shared__ float part_[1][4][64][33];
+  __shared__ __attribute__((aligned(16))) char gls_[1][NP * 32 * GL_ROW];
+  __shared__ int dead;
+  typedef __attribute__((address_space(1))) int gint;
+  const int tid = threadIdx.x;
+  const int tile = blockIdx.x, ntiles = gridDim.x, b = blockIdx.y;
+  gint* const flags = (gint*)(s.flags + (size_t)b * ntiles);
+  if (tid == 0) dead = 0;
+  for (int i = 0; i < s.n; ++i) {
+    bool gave_up = false;
+    auto wait = [&]() {
+      if (i > 0 && tid < 5) {
+        const int f = tile - 2 + tid;
+        if (f >= 0 && f < ntiles && f != tile) {
+          int spins = 0;
+          while (__hip_atomic_load(flags + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < i) {
+            if (++spins > TCM2S_SPINS) {
+              dead = 1;
+              break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+          }
+        }
+      }
+      __syncthreads();   // the neighbours' block i - 1 is visible to every wave
+      gave_up = dead != 0;
+    };
+    tcm2_block<0, 1, 1, NP, 16>(s.blk[i], par, part_, gls_, wait);
+    // a workgroup that gave up still ran the block (on whatever hs held): every barrier of the block was reached by all waves;
+    // it records the failure and leaves before publishing, so its neighbours give up at their next wait
+    if (gave_up) {
+      if (tid == 0) atomicCAS(s.status, 0, i + 1);
+      return;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave: its x' and hs stores have left
+    __syncthreads();                                    // ... and the block's LDS use is over before the next block's begins
+    if (tid == 0) __hip_atomic_store(flags + tile, i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 template <int NT, int TW, int NP>
 int launch_tcm2(const pdse_tcm2_desc* d, hipStream_t s) {
   const dim3 grid((d->T + 32 * NT * TW - 1) / (32 * NT * TW), d->B);
@@ -449,6 +550,32 @@ int launch_tcm2(const pdse_tcm2_desc* d, hipStream_t s) {
 }
 
 }  // namespace
+
+int pdse_tcm2s_launch(const pdse_tcm2s_desc* d, hipStream_t s) {
+  REQ(d && d->flags && d->status, "tcm2s: null pointer");
+  REQ(d->n >= 1 && d->n <= PDSE_TCM2S_MAX, "tcm2s: 1 .. PDSE_TCM2S_MAX blocks");
+  const int B = d->blk[0].B, T = d->blk[0].T, np = d->blk[0].np ? d->blk[0].np : 3;
+  REQ(B > 0 && B <= 65535 && T > 0 && (np == 3 || np == 1), "tcm2s: bad sizes");
+  for (int i = 0; i < d->n; ++i) {
+    const pdse_tcm2_desc& k = d->blk[i];
+    REQ(k.x && k.par && k.B == B && k.T == T && (k.np ? k.np : 3) == np, "tcm2s: blocks of one stack share B, T and the plane count");
+    REQ(k.mode == 0, "tcm2s: residual blocks only (mode 0; the first block's conv1 is its own pdse_tcm2_bf16x3 launch)");
+    REQ(k.dil > 0 && 2 * k.dil <= HS_PAD, "tcm2s: dilation <= 32");
+    REQ(!k.hs_out || k.wn1, "tcm2s: the chained conv1 needs its weights");
+    REQ(k.hs && k.x_out && k.wbr && k.wc2 && k.hs_out != k.hs, "tcm2s: bad residual block");
+    REQ(i == 0 || k.hs == d->blk[i - 1].hs_out, "tcm2s: block i reads the hs that block i - 1 wrote (the wait protocol assumes it)");
+    // the wait in front of block i covers the neighbours' block i - 1 only: block i may overwrite nothing but the buffer block
+    // i - 1 READ, i.e. the one block i - 2 wrote (two buffers, strictly alternating)
+    REQ(!k.hs_out || k.hs_out == (i >= 2 ? d->blk[i - 2].hs_out : (i == 1 ? d->blk[0].hs : k.hs_out)), "tcm2s: the hs buffers must alternate strictly");
+    REQ(k.x != k.x_out, "tcm2s: x and x_out of a block differ (other tiles never read them, but a tile's waves do)");
+  }
+  const int ntiles = (T + 31) / 32;
+  if (pdse_check_hip(hipMemsetAsync(d->flags, 0, (size_t)B * ntiles * sizeof(int), s), "tcm2s: memset")) return 1;
+  const dim3 grid(ntiles, B);
+  if (np == 1) hipLaunchKernelGGL((tcm2s_kernel<1>), grid, dim3(512), 0, s, *d);
+  else hipLaunchKernelGGL((tcm2s_kernel<3>), grid, dim3(512), 0, s, *d);
+  return pdse_check_launch("tcm2s");
+}
 
 int pdse_tcm2_launch(const pdse_tcm2_desc* d, hipStream_t s) {
   REQ(d && d->x && d->par, "tcm2: null pointer");

@@ -361,13 +361,21 @@ class EpsNetPlan(PlanBase):
     # True: every stage (10-20 % faster than csrc/gconv3.hip per launch, profiles/r03_bglu_forms.txt; the only form of the
     # bf16 mode); False: csrc/gconv3.hip throughout (fp32 conv1 tensors, split in every tap).
     plane_h = True
+    # the 18 residual blocks of the TCM stack as ONE persistent launch (pdse_tcm2s_desc, csrc/tcm2.hip: tcm2s_kernel) instead of
+    # 18: same kernels' arithmetic, bit-identical results, no launch boundary between dependent 16 us blocks.  Used by plans
+    # built with exclusive=True (see __init__).
+    tcm_stack = True
     parity_planes = True    # the encoders' plane tensors with their bins split by parity (contiguous stride-2 taps; pdse_bglu_desc.hp_par)
     planes = 3              # 3: exact three-way bf16 split (fp32-equivalent); 1: plain bf16 operands (the opt-in bf16 mode)
     NSLOT = 20  # 15 stages + en1 real-row bias + 4 composed encoder-stage-1 biases (l/r x frame >= 1 / frame 0)
 
     def __init__(self, ctx, sd, B, T, time_cond=True, nsteps=1, plan=None, table=None, with_pre=None, split_bf16=None,
-                 planes=None, plane_h=None):
+                 planes=None, plane_h=None, exclusive=False):
         """with_pre False + time_cond True: ``Nocon`` (model/piror_grad.py), DiffUNet1 without Preprocess.
+        exclusive: the plan owns the GPU while it runs (one batch in flight): the TCM stack then runs as one persistent launch
+        (``tcm_stack``; bit-identical results).  With several batches in flight the persistent workgroups keep CUs from the other
+        batches' block kernels while they wait for their neighbours - measured 17.8 instead of 17.4 ms per pass - so the
+        in-flight runners keep one launch per block.
         split_bf16: run the BIGLU blocks on the bf16 matrix cores with exact 3-way operand splits (None: class default).
         planes 1: the opt-in bf16 mode (plain bf16 operands and bf16 block-boundary tensors; implies plane_h True)."""
         with_pre = time_cond if with_pre is None else with_pre
@@ -379,6 +387,7 @@ class EpsNetPlan(PlanBase):
             self.plane_h = bool(plane_h)
         if self.planes == 1:
             self.plane_h = True
+        self.use_tcm_stack = bool(self.tcm_stack and exclusive)
         self.sd = sd
         ok = (self.split_bf16 and self.chain_conv1 and self.compose_stage1 and time_cond and with_pre and not self.force_generic
               and all(float(P._np(sd[k])[0]) <= 1.0 for k in sd if k.endswith(".weight") and P._np(sd[k]).shape == (1,)))
@@ -405,6 +414,10 @@ class EpsNetPlan(PlanBase):
         self.tcm_h, self.tcm_g = a(B, 64, T), a(B, 64, T)
         # the same bottleneck tensor as the split-bf16 blocks exchange it (pdse_tcm2_desc.hs; its margins stay zero)
         self.tcm_hs = [ctx.alloc_u16(*P.tcm2_hs_shape(B, T, self.planes)) for _ in range(2)]
+        self._tcm_stack = None
+        self.tcm_flags = torch.zeros(B * ((T + 31) // 32), dtype=torch.int32, device=ctx.device)   # progress counters of the stack launch
+        self.tcm_status = torch.zeros(4, dtype=torch.int32, device=ctx.device)                     # [0]: 0, or block + 1 a workgroup gave up at
+        ctx.keep += [self.tcm_flags, self.tcm_status]
         self.dec = [a(B, 64, T, 79), a(B, 64, T, 79)]  # ping-pong decoder activations (largest F=79)
         if self.plane_h:
             # plane tensors of the conv1 outputs (include/pdse.h: hp), one per stage so that their margins stay zero:
@@ -770,7 +783,10 @@ class EpsNetPlan(PlanBase):
         if p_next is not None:
             d.hs_out = hout.data_ptr()
         d.dil, d.B, d.T, d.mode, d.np = dil, self.B, self.T, mode, self.planes
-        self.add(d, TAG_TCM)
+        if mode == 0 and self._tcm_stack is not None:
+            self._tcm_stack.append(d)          # collected: one pdse_tcm2s_desc for the whole stack (build_step)
+        else:
+            self.add(d, TAG_TCM)
 
 
     # ---- the plane path (csrc/bglu.hip) ------------------------------------------------------------------------
@@ -1053,11 +1069,20 @@ class EpsNetPlan(PlanBase):
         elif self.split_bf16 and self.split_tcm:
             hcur, hnxt = self.tcm_hs
             self._residual_split(None, 1, cur, None, None, hcur, names[0][0], mode=1)
+            self._tcm_stack = [] if self.use_tcm_stack else None
             for n, (p, dil) in enumerate(names):
                 p_next = names[n + 1][0] if n + 1 < len(names) else None
                 self._residual_split(p, dil, cur, nxt, hcur, hnxt, p_next)
                 cur, nxt = nxt, (self.tcm_b if nxt is self.tcm_a else self.tcm_a)
                 hcur, hnxt = hnxt, hcur
+            if self._tcm_stack:
+                sd_ = L.Tcm2sDesc()
+                for n, blk in enumerate(self._tcm_stack):
+                    sd_.blk[n] = blk
+                sd_.n = len(self._tcm_stack)
+                sd_.flags, sd_.status = self.tcm_flags.data_ptr(), self.tcm_status.data_ptr()
+                self.add(sd_, TAG_TCM)
+            self._tcm_stack = None
         else:
             # one launch per block; each also produces the next block's conv1 output (h ping-pongs: halo reads)
             hcur, hnxt = self.tcm_h, self.tcm_g

@@ -86,7 +86,7 @@ class DiffUNet1Op(_PlannedOp):
         tf = self._steps(t)
 
         def build(ctx):
-            net = nets.EpsNetPlan(ctx, self.sd, B, T, time_cond=True, nsteps=1)
+            net = nets.EpsNetPlan(ctx, self.sd, B, T, time_cond=True, nsteps=1, exclusive=self.exclusive)
             net.build_time()
             net.build_step(0)
             return net
@@ -110,7 +110,7 @@ class NoconOp(_PlannedOp):
         tf = self._steps(t)
 
         def build(ctx):
-            net = nets.EpsNetPlan(ctx, self.sd, B, T, time_cond=True, nsteps=1, with_pre=False)
+            net = nets.EpsNetPlan(ctx, self.sd, B, T, time_cond=True, nsteps=1, with_pre=False, exclusive=self.exclusive)
             net.build_time()
             net.build_step(0)
             return net
@@ -130,7 +130,7 @@ class DiffUNetOp(_PlannedOp):
         B, _, T, _ = x.shape
 
         def build(ctx):
-            net = nets.EpsNetPlan(ctx, self.sd, B, T, time_cond=False)
+            net = nets.EpsNetPlan(ctx, self.sd, B, T, time_cond=False, exclusive=self.exclusive)
             net.build_step(0)
             return net
 

@@ -48,8 +48,9 @@ class SamplerPipeline:
         bank: a ``nets.WeightBank`` shared with other pipelines built from the same state_dicts (packed weights are
         uploaded once, every further (B, T) only records descriptors).
         exclusive: this pipeline is the only work on the GPU while it runs (one batch in flight - ``ComplexDDPMTrainer``
-        passes True): small batches may then use persistent launches whose workgroups wait for each other (the GCRN
-        prior's LSTM at B <= 4, csrc/lstmp.hip; 1e-5 from, not bit-identical to, the kernels large batches take).
+        passes True): launches whose workgroups wait for each other may then be used - the TCM stack as one launch
+        (csrc/tcm2.hip: tcm2s_kernel, bit-identical) and, for B <= 4, the GCRN prior's LSTM (csrc/lstmp.hip; 1e-5 from, not
+        bit-identical to, the kernels large batches take).
         ``ConcurrentSampler`` / ``PipelinedSampler`` and the sharded path keep False.
         split_bf16: the eps-net's BIGLU blocks and the priors' GEMM-shaped convolutions on the bf16 matrix cores with exact three-way
         operand splits - fp32-level accuracy at 16/6 of the fp32 MFMA rate (csrc/gconv3.hip); None: on for fast sampling,
@@ -92,7 +93,7 @@ class SamplerPipeline:
         if prior_name == "GCRN":
             self.prior = adopt(nets.GcrnPlan(ctx, prior_sd, B, T, plan=self.plan, split_bf16=split_bf16, exclusive=exclusive))
         elif prior_name == "DiffUNet":
-            self.prior = adopt(nets.EpsNetPlan(ctx, prior_sd, B, T, time_cond=False, plan=self.plan, split_bf16=split_bf16))
+            self.prior = adopt(nets.EpsNetPlan(ctx, prior_sd, B, T, time_cond=False, plan=self.plan, split_bf16=split_bf16, exclusive=exclusive))
         elif prior_name == "aia_complex_trans_ri":
             self.prior = adopt(nets.AiaPlan(ctx, prior_sd, B, T, plan=self.plan, split_bf16=split_bf16))
         elif prior_name == "dual_aia_trans_merge_crm":
@@ -102,7 +103,8 @@ class SamplerPipeline:
         if dtype == "bf16":
             split_bf16 = True
         self.eps = adopt(nets.EpsNetPlan(ctx, ddpm_sd, B, T, time_cond=True, nsteps=S, plan=self.plan,
-                                         with_pre=not deltamu, split_bf16=split_bf16, planes=1 if dtype == "bf16" else None))
+                                         with_pre=not deltamu, split_bf16=split_bf16, planes=1 if dtype == "bf16" else None,
+                                         exclusive=exclusive))
         self.split_bf16 = self.eps.split_bf16
         self.deltamu = deltamu
         self.xT_plus_init = xT_plus_init = bool(deltamu if xT_plus_init is None else xT_plus_init)
@@ -202,13 +204,15 @@ class SamplerPipeline:
     def check(self):
         """Synchronises and raises if a persistent launch of the last run gave up (its workgroups wait for each other
         with bounded polls: another workload on the GPU can keep them from all being resident)."""
-        st = getattr(self.prior, "status", None)
-        if st is not None:
-            code = int(st[0].item())
-            if code:
-                st.zero_()
-                raise L.PdseError("persistent LSTM gave up at step %d: its 256 workgroups were not all resident (is another "
-                                  "workload sharing the GPU?); build the pipeline with exclusive=False" % (code - 1))
+        for net, field, what in ((self.prior, "status", "persistent LSTM gave up at step %d"), (self.eps, "tcm_status", "TCM stack launch gave up at block %d"),
+                                 (self.prior, "tcm_status", "TCM stack launch of the prior gave up at block %d")):
+            st = getattr(net, field, None)
+            if st is not None:
+                code = int(st[0].item())
+                if code:
+                    st.zero_()
+                    raise L.PdseError((what % (code - 1)) + ": its workgroups wait for each other and were not all resident in time (is "
+                                      "another workload sharing the GPU?); build the pipeline with exclusive=False")
 
     def sample(self, feat, x_T, graph=False):
         """feat, x_T [B,2,T,161] -> (enhanced compressed spectrogram, X_init); the

@@ -86,7 +86,7 @@ class ComplexDDPMTrainer(object):
             raise ValueError("no weights: pass state_dicts or use --retrain with a best_checkpoint.pth")
         self.bank = nets.WeightBank()     # packed weights in HBM: uploaded once, shared by every plan of this trainer
         self.model = ops.PRIOR_OPS[self.prior_name](self.prior_sd, self.device, bank=self.bank, exclusive=self.exclusive)       # :69
-        self.model_ddpm = (ops.NoconOp if self.deltamu else ops.DiffUNet1Op)(self.ddpm_sd, self.device, bank=self.bank)   # :70-73
+        self.model_ddpm = (ops.NoconOp if self.deltamu else ops.DiffUNet1Op)(self.ddpm_sd, self.device, bank=self.bank, exclusive=self.exclusive)   # :70-73
         self._pipes = OrderedDict()
         self._hits = {}                   # uses of a recorded geometry after the first
 
@@ -105,7 +105,7 @@ class ComplexDDPMTrainer(object):
             self._hits.clear()
             self.bank = nets.WeightBank()
             self.model = ops.PRIOR_OPS[self.prior_name](self.prior_sd, self.device, bank=self.bank, exclusive=self.exclusive)
-            self.model_ddpm = (ops.NoconOp if self.deltamu else ops.DiffUNet1Op)(self.ddpm_sd, self.device, bank=self.bank)
+            self.model_ddpm = (ops.NoconOp if self.deltamu else ops.DiffUNet1Op)(self.ddpm_sd, self.device, bank=self.bank, exclusive=self.exclusive)
         logging.info("loaded %s", path)
 
     # ---- A1 ---------------------------------------------------------------

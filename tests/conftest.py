@@ -113,3 +113,16 @@ _FIRST = ("golden", "full_size", "config3", "config4", "config5", "full_50", "bi
 def pytest_collection_modifyitems(config, items):
     """Parity against the reference's fixtures runs first, so a time limit cannot leave a parity row unreached."""
     items.sort(key=lambda it: 0 if any(k in it.name for k in _FIRST) else 1)
+
+
+def tcm2_blocks(descs):
+    """Every pdse_tcm2_desc of a recorded plan in launch order, whether it is an operator of its own or one of the residual blocks
+    inside the stack launch (pdse_tcm2s_desc, round 4)."""
+    L = pkg("_lib")
+    out = []
+    for d, _ in descs:
+        if isinstance(d, L.Tcm2Desc):
+            out.append(d)
+        elif isinstance(d, L.Tcm2sDesc):
+            out += [d.blk[i] for i in range(d.n)]
+    return out

@@ -727,7 +727,13 @@ def run_bglu(d, mem):
                 flat[np.broadcast_to(idx, Z.shape)] = Z.astype(np.float32)
 
 
-RUNNERS = {L.BgluDesc: run_bglu, L.PlanesDesc: run_planes, L.GcrnLastDesc: run_gcrnlast, L.TcmDesc: run_tcm, L.Tcm2Desc: run_tcm2, L.GconvDesc: run_gconv, L.TimeDesc: run_time, L.EwDesc: run_ew, L.CompandDesc: run_compand,
+def run_tcm2s(d, mem):
+    """pdse_tcm2s_desc: the residual blocks of the stack, one after the other (what the persistent launch computes)."""
+    for i in range(d.n):
+        run_tcm2(d.blk[i], mem)
+
+
+RUNNERS = {L.Tcm2sDesc: run_tcm2s, L.BgluDesc: run_bglu, L.PlanesDesc: run_planes, L.GcrnLastDesc: run_gcrnlast, L.TcmDesc: run_tcm, L.Tcm2Desc: run_tcm2, L.GconvDesc: run_gconv, L.TimeDesc: run_time, L.EwDesc: run_ew, L.CompandDesc: run_compand,
            L.WavprepDesc: run_wavprep, L.OlaDesc: run_ola, L.SigmaDesc: run_sigma, L.LnDesc: run_ln,
            L.LstmDesc: run_lstm, L.GlstmDesc: run_glstm, L.GlstmpDesc: run_glstmp}
 

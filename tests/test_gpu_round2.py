@@ -15,7 +15,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import ROOT, assert_rows2_and_checksums, full_pair, golden, pkg, rel_l2, seeded
+from conftest import ROOT, assert_rows2_and_checksums, full_pair, golden, pkg, rel_l2, seeded, tcm2_blocks
 
 pytestmark = pytest.mark.gpu
 
@@ -465,9 +465,8 @@ def test_split_tcm_blocks_match_fp32_kernel_and_validate_descriptors(L, weights)
         net.plan.run()
         torch.cuda.synchronize()
         outs[split] = net.out.clone()
-        n_tcm2 = sum(1 for d, _ in net.descs if isinstance(d, L.Tcm2Desc))
-        assert n_tcm2 == (19 if split else 0)
-        last = [d for d, _ in net.descs if isinstance(d, (L.Tcm2Desc, L.TcmDesc))][-1]
+        assert len(tcm2_blocks(net.descs)) == (19 if split else 0)
+        last = (tcm2_blocks(net.descs) or [d for d, _ in net.descs if isinstance(d, L.TcmDesc)])[-1]
         tcm[split] = (net.tcm_a if last.x_out == net.tcm_a.data_ptr() else net.tcm_b).clone()
         if split:
             for hs in net.tcm_hs:                     # margins untouched (join asserts it), planes finite
@@ -477,7 +476,7 @@ def test_split_tcm_blocks_match_fp32_kernel_and_validate_descriptors(L, weights)
     assert rel_l2(tcm[True].cpu(), tcm[False].cpu()) < 5e-6
     assert rel_l2(outs[True].cpu(), outs[False].cpu()) < 2e-5
     # descriptor validation
-    d = [d for d, _ in split_net.descs if isinstance(d, L.Tcm2Desc) and d.mode == 0][0]
+    d = [d for d in tcm2_blocks(split_net.descs) if d.mode == 0][0]
     bad = type(d).from_buffer_copy(d)
     bad.dil = 33
     with pytest.raises(L.PdseError, match="dilation"):
@@ -550,7 +549,7 @@ def test_bf16_mode_tolerance(L, weights):
     net.tsteps.copy_(torch.from_numpy(g["t"]).view(1, B))
     net.plan.run()
     torch.cuda.synchronize()
-    assert all(d.np == 1 for d, _ in net.descs if isinstance(d, (L.BgluDesc, L.Tcm2Desc))) and sum(1 for d, _ in net.descs if isinstance(d, L.BgluDesc)) == 15
+    assert all(d.np == 1 for d, _ in net.descs if isinstance(d, L.BgluDesc)) and all(d.np == 1 for d in tcm2_blocks(net.descs)) and sum(1 for d, _ in net.descs if isinstance(d, L.BgluDesc)) == 15
     e_net = rel_l2(net.out.cpu(), g["out"])
     B, T = 32, 401
     feat, x_T = pkg("synth").synthetic_spectrogram(B, T, seed=1234)

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden, pkg, rel_l2, seeded
+from conftest import golden, pkg, rel_l2, seeded, tcm2_blocks
 
 pytestmark = pytest.mark.gpu
 
@@ -157,7 +157,7 @@ def test_bf16_mode_tolerance_configs_4_and_5(L, weights, config, tmp_path):
         wav, x_T = pkg("synth").synthetic_waveforms(B, L_, seed=505)
         wav = wav * torch.linspace(0.05, 2.0, B)[:, None]
         pipe = P(DEV, "GCRN", weights("GCRN"), weights("DiffUNet1"), B, L_=L_, dtype="bf16")
-        assert pipe.T == 1001 and all(d.np == 1 for d, _ in pipe.descs if isinstance(d, (L.BgluDesc, L.Tcm2Desc)))
+        assert pipe.T == 1001 and all(d.np == 1 for d, _ in pipe.descs if isinstance(d, L.BgluDesc)) and all(d.np == 1 for d in tcm2_blocks(pipe.descs))
         out, spec = pipe.enhance(wav.to(DEV), x_T.to(DEV))
         g = golden("full_generate_wav_seed505_l160000")
         e_wav = rel_l2(out[0].cpu(), g["wav"])
@@ -175,3 +175,51 @@ def test_bf16_mode_tolerance_configs_4_and_5(L, weights, config, tmp_path):
         y = tr.enhance(wav[:1, :4000].to(DEV), x_T=x_T[:1, :, :26].to(DEV))
         p = tr._pipes[next(reversed(tr._pipes))]
         assert p.dtype == "bf16" and all(d.np == 1 for d, _ in p.descs if isinstance(d, L.BgluDesc)) and torch.isfinite(y).all()
+
+
+# ------------------------------------------------------------------ the TCM stack as one persistent launch (csrc/tcm2.hip: tcm2s_kernel)
+@pytest.mark.parametrize("B,T,planes", [(2, 20, 3), (32, 401, 3), (3, 1001, 3), (32, 401, 1)])
+def test_tcm_stack_launch_is_bit_identical_to_one_launch_per_block(L, weights, B, T, planes, monkeypatch):
+    """The 18 residual blocks as ONE launch whose workgroups wait for their neighbours' progress counters (pdse_tcm2s_desc)
+    against 18 launches of the same block kernel: the residual stream after the stack and the network output bit for bit, at a
+    small shape, at the bench shape (416 co-resident workgroups), at T = 1001 (32 tiles per utterance) and in the one-plane bf16
+    mode; run three times (the counters are re-initialised by every launch) and with two plans interleaved on two streams (two
+    stack launches competing for the CUs)."""
+    nets = pkg("nets")
+    x, xi = seeded((B, 2, T, 161), 71).to(DEV), (seeded((B, 2, T, 161), 72) * 0.3).to(DEV)
+    res = {}
+    for stack in (False, True):
+        monkeypatch.setattr(nets.EpsNetPlan, "tcm_stack", stack)
+        net = nets.EpsNetPlan(nets.Ctx(DEV), weights("DiffUNet1"), B, T, time_cond=True, nsteps=1, planes=planes if planes == 1 else None, exclusive=True)
+        net.build_time()
+        net.build_step(0)
+        net.finish()
+        assert sum(1 for d, _ in net.descs if isinstance(d, L.Tcm2sDesc)) == (1 if stack else 0)
+        net.x.copy_(x)
+        net.x_init.copy_(xi)
+        net.tsteps.fill_(7.25)
+        for _ in range(3 if stack else 1):
+            net.plan.run()
+        torch.cuda.synchronize()
+        last = tcm2_blocks(net.descs)[-1]
+        res[stack] = (net.out.clone(), (net.tcm_a if last.x_out == net.tcm_a.data_ptr() else net.tcm_b).clone(), net)
+    assert int(res[True][2].tcm_status[0].item()) == 0
+    assert torch.equal(res[True][1], res[False][1]) and torch.equal(res[True][0], res[False][0])
+    # two stack launches in flight at once
+    a = res[True][2]
+    monkeypatch.setattr(nets.EpsNetPlan, "tcm_stack", True)
+    b = nets.EpsNetPlan(nets.Ctx(DEV), weights("DiffUNet1"), B, T, time_cond=True, nsteps=1, planes=planes if planes == 1 else None, exclusive=True)
+    b.build_time()
+    b.build_step(0)
+    b.finish()
+    b.x.copy_(x)
+    b.x_init.copy_(xi)
+    b.tsteps.fill_(7.25)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for _ in range(3):
+        a.plan.run(s1.cuda_stream)
+        b.plan.run(s2.cuda_stream)
+    torch.cuda.synchronize()
+    assert int(a.tcm_status[0].item()) == 0 and int(b.tcm_status[0].item()) == 0
+    assert torch.equal(a.out, res[False][0]) and torch.equal(b.out, res[False][0])

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 import emu
-from conftest import pkg, rel_l2, seeded
+from conftest import pkg, rel_l2, seeded, tcm2_blocks
 from oracle import restate as R
 
 TOL = 5e-6
@@ -43,7 +43,7 @@ def test_eps_net_plan_vs_oracle(weights, chained, split, plane_h, parity, monkey
     B, T = 2, 12
     sd = weights("DiffUNet1")
     ctx = nets.Ctx("cpu")
-    net = nets.EpsNetPlan(ctx, sd, B, T, time_cond=True, nsteps=1)
+    net = nets.EpsNetPlan(ctx, sd, B, T, time_cond=True, nsteps=1, exclusive=True)      # exclusive: the TCM stack as one persistent launch
     net.build_time()
     net.build_step(0)
     n_conv1 = sum(1 for _, tag in net.descs if tag == nets.TAG_EPS_CONV1)
@@ -56,8 +56,9 @@ def test_eps_net_plan_vs_oracle(weights, chained, split, plane_h, parity, monkey
         bg = [d for d, _ in net.descs if isinstance(d, lib.BgluDesc)]
         assert sum(d.hp_par for d in bg) == (4 if parity else 0) and sum(d.nx_par for d in bg) == (4 if parity else 0)
         assert sum(1 for d in bg if d.skip_Fh) == (12 if parity else 0)
-    n_tcm2 = sum(1 for d, _ in net.descs if isinstance(d, pkg("_lib").Tcm2Desc))
-    assert n_tcm2 == (19 if split else 0)             # the first block's conv1 + 18 residual blocks (csrc/tcm2.hip)
+    assert len(tcm2_blocks(net.descs)) == (19 if split else 0)      # the first block's conv1 + 18 residual blocks (csrc/tcm2.hip)
+    stacks = [d for d, _ in net.descs if isinstance(d, pkg("_lib").Tcm2sDesc)]
+    assert len(stacks) == (1 if split else 0) and all(d.n == 18 for d in stacks)   # ... the 18 as ONE persistent launch (round 4)
     x, xi = seeded((B, 2, T, 161), 3), seeded((B, 2, T, 161), 4) * 0.3
     t = torch.tensor([4.086654, 22.992493])
     net.x.copy_(x)
@@ -159,7 +160,7 @@ def test_step_descriptors_are_cloned_not_repacked(weights):
     L = pkg("_lib")
     for a, b in zip(first, second):
         assert type(a) is type(b)
-        if isinstance(a, (L.TcmDesc, L.Tcm2Desc)):         # fused TCM blocks carry no time bias: identical clones
+        if isinstance(a, (L.TcmDesc, L.Tcm2Desc, L.Tcm2sDesc)):         # fused TCM blocks carry no time bias: identical clones
             assert bytes(a) == bytes(b)
             continue
         if isinstance(a, L.PlanesDesc):                      # fp32 -> planes of the first decoder stage's conv1: no bias
@@ -205,8 +206,8 @@ def test_eps_net_plan_bf16_mode_vs_oracle(weights):
     net = nets.EpsNetPlan(ctx, sd, B, T, time_cond=True, nsteps=1, planes=1)
     net.build_time()
     net.build_step(0)
-    assert all(d.np == 1 for d, _ in net.descs if isinstance(d, (Lb.BgluDesc, Lb.Tcm2Desc, Lb.PlanesDesc)))
-    assert sum(1 for d, _ in net.descs if isinstance(d, Lb.BgluDesc)) == 15 and sum(1 for d, _ in net.descs if isinstance(d, Lb.Tcm2Desc)) == 19
+    assert all(d.np == 1 for d, _ in net.descs if isinstance(d, (Lb.BgluDesc, Lb.PlanesDesc))) and all(d.np == 1 for d in tcm2_blocks(net.descs))
+    assert sum(1 for d, _ in net.descs if isinstance(d, Lb.BgluDesc)) == 15 and len(tcm2_blocks(net.descs)) == 19
     x, xi = seeded((B, 2, T, 161), 3), seeded((B, 2, T, 161), 4) * 0.3
     t = torch.tensor([4.086654, 22.992493])
     net.x.copy_(x)

@@ -17,7 +17,7 @@ L = importlib.import_module("prior-diffuse_amd._lib")
 
 def run(split, B=32, T=401, plane_h=None, planes=None):
     net = nets.EpsNetPlan(nets.Ctx("cuda:0"), synth.make_state_dict("DiffUNet1"), B, T, time_cond=True, nsteps=1, split_bf16=split,
-                          plane_h=plane_h, planes=planes)
+                          plane_h=plane_h, planes=planes, exclusive=True)
     net.build_time()
     net.build_step(0)
     net.finish()
@@ -41,6 +41,8 @@ def run(split, B=32, T=401, plane_h=None, planes=None):
                 d.np, d.ntaps, 1 if d.p1mask else 0, d.nx_n, d.C2, d.Tout, d.Fout, m * 1e3))
         if isinstance(d, L.Tcm2Desc):
             print("  TCM split mode %d dil %2d: %6.1f us" % (d.mode, d.dil, m * 1e3))
+        if isinstance(d, L.Tcm2sDesc):
+            print("  TCM stack, %d residual blocks in one launch: %6.1f us (%.1f us per block)" % (d.n, m * 1e3, m * 1e3 / d.n))
     tcm = sum(m for (d, tag), m in zip(net.descs, best) if tag == nets.TAG_TCM)
     print("  TCM %.1f us; whole forward %.3f ms" % (tcm * 1e3, tot))
 
@@ -53,5 +55,7 @@ if __name__ == "__main__":
     run(False)
     run(True, plane_h=False)
     run(True)
+    nets.EpsNetPlan.tcm_stack = False      # one launch per residual block (round 3) beside the stack launch (round 4)
     run(True, plane_h=True)
+    nets.EpsNetPlan.tcm_stack = True
     run(True, planes=1)
