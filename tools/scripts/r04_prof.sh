@@ -15,7 +15,10 @@ python tools/summarize_pmc.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_SQ $O/p
 python tools/pmc_summary.py $O/pmc_SQ > $O/pmc_sq.txt 2>&1
 for f in $(find $O/ks_default $O/ks_seq -name "*kernel_stats.csv"); do echo $f; head -6 $f | cut -c1-150; done
 python bench.py --no-cpu-baseline --fp32 > $O/bench_fp32.json 2> /dev/null
-python bench.py --no-cpu-baseline --bf16 > $O/bench_bf16.json 2> /dev/null
+python bench.py --no-cpu-baseline --bf16 > $O/bench_bf16_cfg2.json 2> /dev/null
+python bench.py --no-cpu-baseline --bf16 --prior aia_complex_trans_ri > $O/bench_bf16_cfg4.json 2> /dev/null
+python bench.py --no-cpu-baseline --bf16 --seconds 10 --batch 16 > $O/bench_bf16_cfg5.json 2> /dev/null
+python bench.py --no-cpu-baseline --no-fp32-compare --no-file-loop --tcm-launches > $O/bench_tcm_launches.json 2> /dev/null
 python bench.py --no-cpu-baseline --prior aia_complex_trans_ri > $O/bench_aia_ri.json 2> /dev/null
 python bench.py --no-cpu-baseline --prior dual_aia_trans_merge_crm > $O/bench_aia_dual.json 2> /dev/null
 python bench.py --no-cpu-baseline --seconds 10 --batch 16 > $O/bench_10s_b16.json 2> /dev/null
@@ -24,4 +27,5 @@ python tools/time_eps.py > $O/eps_per_launch.txt 2>&1
 python tools/time_gcrn.py > $O/gcrn_per_launch.txt 2>&1
 python tools/time_glstm.py > $O/glstm_timing.txt 2>&1
 python tools/time_glstm.py --persist >> $O/glstm_timing.txt 2>&1
-for f in default fp32 bf16 aia_ri aia_dual 10s_b16 full50; do python -c "import json; d=json.loads(open('$O/bench_$f.json').read().strip().splitlines()[-1]); print('$f', d['ms_per_step'], d.get('ms_per_step_sequential'), d['value'], d['dtype'], d.get('file_loop_b1'))"; done
+python tools/time_aia.py > $O/aia_per_launch.txt 2>&1
+for f in default fp32 bf16_cfg2 bf16_cfg4 bf16_cfg5 tcm_launches aia_ri aia_dual 10s_b16 full50; do python -c "import json; d=json.loads(open('$O/bench_$f.json').read().strip().splitlines()[-1]); print('$f', d['ms_per_step'], d.get('ms_per_step_sequential'), d['value'], d['dtype'], d.get('file_loop_b1'))"; done
