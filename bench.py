@@ -425,8 +425,8 @@ def main():
                      "value": round(nfiles * args.seconds / tfl, 1), "unit": "audio_s/s",
                      "ms_per_file": round(tfl / nfiles * 1e3, 2),
                      "note": "ComplexDDPMTrainer.generate_wav (trainer/complex_ddpm_trainer.py:903-1018), B = 1, wav read + "
-                             "enhance + wav write per file, plan and weights resident, hipGraph replay once a length comes back (GPU-bound either way: "
-                             "the 403 dependent LSTM launches of the prior)"}
+                             "enhance + wav write per file, plan and weights resident, hipGraph replay once a length comes back; the trainer owns "
+                             "the GPU (exclusive): the prior's LSTM is one persistent launch (csrc/lstmp.hip), the TCM stack one launch per forward"}
     cpu = None
     if not args.no_cpu_baseline:
         from oracle import restate as R
