@@ -453,19 +453,21 @@ typedef struct pdse_crm_desc {
  *   u = cat(in0, ELU(in1))  [32 ch, 80 bins]          (in0 = previous stage, already BN + ELU; in1 = encoder-1 skip)
  *   g[f] = (convT1(u)[f] + b1) * sigmoid(convT2(u)[f] + b2),  ConvTranspose2d(32 -> 1, (1,3), stride (1,2)): 161 bins
  *   y = ELU(bn_scale * g + bn_shift);   out[b, t, :] = fcT^T y + fcb        (Linear(161, 161))
- * A persistent workgroup keeps fcT [161 in][161 out] in LDS and walks (b, t) rows: the single output channel wastes
- * 31/32 of an MFMA tile and the Linear is a 161-tap gather on the generic kernel otherwise (3 launches, 0.34 ms). */
+ * A workgroup owns 32 (b, t) rows: the gated transposed convolution on the vector units (the single output channel wastes 31/32
+ * of an MFMA tile), the Linear on the fp32 matrix cores with the rows as M (ABI 6; csrc/misc.hip). */
 typedef struct pdse_gcrnlast_desc {
   const float* in0;   /* [B][16][T][80] */
   const float* in1;   /* [B][16][T][80] */
   const float* w1;    /* [32][3] main branch, ConvTranspose weight[c][0][0][k] */
   const float* w2;    /* [32][3] gate branch */
-  const float* fcT;   /* [161][161] = fc.weight^T */
+  const float* fcT;   /* [161][161] = fc.weight^T (kept for readers of the descriptor; the kernel reads fcp) */
   const float* fcb;   /* [161] */
   float* out;         /* element (b, t, o) at out + b*out_sb + t*161 + o */
   int64_t out_sb;
   float b1, b2, bn_scale, bn_shift;
   int32_t B, T;
+  const float* fcp;   /* ABI 6: fc.weight^T as the MFMA B operand, [6 bin tiles][21 k groups][64 lanes][4]: entry i of lane (col, h)
+                         of group g = fcT[2 (4 g + i) + h][32 tile + col], zero beyond 161 (packing.pack_a4) */
 } pdse_gcrnlast_desc;
 
 /* One dilated residual block of the eps-net's TCMs (model/diff3.py:215-257) over [B][256][T], fused with the

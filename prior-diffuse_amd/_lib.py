@@ -207,7 +207,8 @@ class CrmDesc(C.Structure):
 
 class GcrnLastDesc(C.Structure):
     _fields_ = [("in0", _fp), ("in1", _fp), ("w1", _fp), ("w2", _fp), ("fcT", _fp), ("fcb", _fp), ("out", _fp),
-                ("out_sb", _i64), ("b1", _f32), ("b2", _f32), ("bn_scale", _f32), ("bn_shift", _f32), ("B", _i32), ("T", _i32)]
+                ("out_sb", _i64), ("b1", _f32), ("b2", _f32), ("bn_scale", _f32), ("bn_shift", _f32), ("B", _i32), ("T", _i32),
+                ("fcp", _fp)]
 
 
 DESC_TYPES = {OP_TCM2S: Tcm2sDesc, OP_GLSTMP: GlstmpDesc, OP_BGLU: BgluDesc, OP_PLANES: PlanesDesc, OP_TCM2: Tcm2Desc, OP_GLSTM: GlstmDesc, OP_MASKLOSS: MasklossDesc, OP_GCRNLAST: GcrnLastDesc, OP_CRM: CrmDesc, OP_TCM: TcmDesc, OP_TRANSPOSE: TransposeDesc, OP_QSAMPLE: QsampleDesc, OP_ROWLN: RowlnDesc, OP_CHLN: ChlnDesc, OP_ATTN: AttnDesc, OP_GRU: GruDesc, OP_GNCOMB: GncombDesc,

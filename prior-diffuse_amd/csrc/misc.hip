@@ -397,121 +397,133 @@ int pdse_qsample_launch(const pdse_qsample_desc* d, hipStream_t s) {
 
 // ---------------------------------------------------------------------------------------
 // GCRN: last decoder stage (gated ConvTranspose 32 -> 1, BN, ELU) + Linear(161,161) over the bins
-// (model/gcrn.py:158-163).  Persistent workgroups: the Linear's weight matrix is read once per workgroup (one
-// column per thread, in registers) and re-used for ~B*T/512 rows; per row 10 KB of activations come in, 644 bytes go out.
+// (model/gcrn.py:158-163).
+//
+// [r4] Until round 3 a persistent 512-thread workgroup handled ONE (b, t) row per iteration: five barriers per row, the Linear on
+// the vector units (84 FMAs per thread and row from a register-resident column): 152-175 us per launch for 1.5 GFLOP and 131 MB.
+// Now a workgroup owns a tile of 32 rows:
+//   * the transposed convolution + gate + BatchNorm + ELU two rows per iteration (thread = (output bin, which of the two rows),
+//     all 32 channels of its bin from an LDS copy of the row, ELU applied to the skip half on the way in; the next two rows' 20
+//     loads per thread are in flight meanwhile; one barrier per iteration thanks to a double-buffered copy), its 161 values per
+//     row written straight into the A-operand layout of the Linear;
+//   * the Linear on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, exact fp32): rows = M, output bins = N, six waves take one
+//     32-bin tile each, K = 161 padded to 168 as 21 groups of four k-steps (one ds_read_b128 of y and one 16-byte load of the
+//     packed matrix per group, packing.pack_a4); the accumulator layout puts 32 consecutive output bins of one row on the lanes
+//     of each store.
 // ---------------------------------------------------------------------------------------
 #define GL_F 161
 #define GL_FI 80
+#define GL_KQ 21   // K groups of four k-steps (8 inputs each): 168 >= 161
+#define GL_YB 132  // floats per (kq, h) block of ys: 32 rows x 4 + 4 of skew
 __device__ __forceinline__ float gl_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 
-__global__ __launch_bounds__(512, 2) void gcrnlast_kernel(const pdse_gcrnlast_desc d) {
-  __shared__ float xs[32 * GL_FI];          // inputs of the current row (ELU already applied to the skip)
-  __shared__ __attribute__((aligned(16))) float ys[164];   // gated, normalised, activated bins (padded to a multiple of 4)
-  __shared__ float pm[2][GL_F], pg[2][GL_F], pf[GL_F];   // partial sums of the second thread half
+__global__ __launch_bounds__(512, 4) void gcrnlast_kernel(const pdse_gcrnlast_desc d) {
+  typedef float f32x16 __attribute__((ext_vector_type(16)));
+  __shared__ __attribute__((aligned(16))) float xs[2][2][32 * GL_FI];                               // [buffer][row of the pair][channel][bin], ELU applied to the skip half
+  // y of the 32 rows: input k = 2 (4 kq + i) + h at block (2 kq + h), [row][i]; blocks 4 floats apart from a multiple of 32 banks, so that
+  // the 161 threads of a row (i, h and kq vary, the row does not) do not all write into four banks
+  __shared__ __attribute__((aligned(16))) float ys[GL_KQ * 2 * GL_YB];
   __shared__ __attribute__((aligned(16))) float4 wl4[2][32];
-  const int tid = threadIdx.x;
-  const int o = tid & 255, half = tid >> 8;  // output bin, K half (conv: channels 16*half.., Linear: inputs 84*half..)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int o = tid & 255, rr = tid >> 8;                               // conv: output bin, row of the pair
   const bool act = o < GL_F;
-  // thread (o, half) keeps its half of column o of the Linear (84 / 77 weights) in registers for all its rows: the
-  // matrix is read once per workgroup and the per-row product needs only broadcast reads of y.  (A 104 KB LDS image
-  // of the matrix allowed one workgroup per CU and cost 161 more LDS reads per output: 320 us per launch; whole
-  // columns in registers: 205 us at one wave per SIMD.)
-  constexpr int KH = 84;                    // multiple of 4: half 0 covers inputs 0..83, half 1 covers 84..160 (+ zero padding)
-  float col[KH];
-#pragma unroll
-  for (int i = 0; i < KH; ++i) {
-    const int k = KH * half + i;
-    col[i] = (act && k < GL_F) ? d.fcT[k * GL_F + o] : 0.f;
-  }
-  if (tid < 3) ys[GL_F + tid] = 0.f;
-  if (tid < 4) ys[160 + tid] = 0.f;
-  const float fcb = (act && half == 0) ? d.fcb[o] : 0.f;
-  // wl4[parity][c] = (main weight of x[j], of x[j-1], gate weight of x[j], of x[j-1]) of channel c for even / odd output bins
-  // (even bin 2j <- tap 0 at j, tap 2 at j-1; odd bin 2j+1 <- tap 1 at j): one 16-byte LDS read per channel instead of two to four
   const bool odd = (o & 1) != 0;
+  // wl4[parity][c] = (main weight of x[j], of x[j-1], gate weight of x[j], of x[j-1]) of channel c for even / odd output bins
+  // (even bin 2j <- tap 0 at j, tap 2 at j-1; odd bin 2j+1 <- tap 1 at j): one 16-byte LDS read per channel
   if (tid < 64) {
     const int c = tid & 31, par = tid >> 5;
     wl4[par][c] = par ? make_float4(d.w1[3 * c + 1], 0.f, d.w2[3 * c + 1], 0.f) : make_float4(d.w1[3 * c], d.w1[3 * c + 2], d.w2[3 * c], d.w2[3 * c + 2]);
   }
+  // inputs 161 .. 167 of the Linear do not exist: their slots stay zero (so does the packed matrix there)
+  for (int e = tid; e < GL_KQ * 2 * GL_YB; e += 512) ys[e] = 0.f;
   const int64_t plane = (int64_t)d.T * GL_FI;
-  const int rows = d.B * d.T;
-  // this thread's five (channel, bin) items of a row: element e = tid + 512*i, channel e / 80
-  auto fetch = [&](const int row, float (&v)[5]) {
-    const int b = row / d.T, t = row - b * d.T;
+  const int rows = d.B * d.T, ntiles = (rows + 31) >> 5;
+  // this thread's ten (channel, bin) items of its row: element e = o + 256 i, channel e / 80 (a row beyond the last reads row 0).
+  // (Measured and not kept: two pairs of rows in flight - no change, the iteration is not waiting for its loads; 16-byte loads with
+  // per-thread offsets computed once - 84 instead of 75 us per launch.)
+  auto fetch = [&](const int row, float (&v)[10]) {
+    const int rw = row < rows ? row : 0;
+    const int b = rw / d.T, t = rw - b * d.T;
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      const int e = tid + 512 * i;
+    for (int i = 0; i < 10; ++i) {
+      const int e = o + 256 * i;
       const int c = e / GL_FI, f = e - c * GL_FI;
       v[i] = c < 16 ? d.in0[((int64_t)b * 16 + c) * plane + (int64_t)t * GL_FI + f]
                     : d.in1[((int64_t)b * 16 + (c - 16)) * plane + (int64_t)t * GL_FI + f];
     }
   };
-  float nxt[5];
-  if ((int)blockIdx.x < rows) fetch(blockIdx.x, nxt);
-  for (int row = blockIdx.x; row < rows; row += gridDim.x) {   // uniform trip count per workgroup
-    const int b = row / d.T, t = row - b * d.T;
-    __syncthreads();                        // previous row's buffers are free (and the staging above is complete)
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {   // uniform trip count per workgroup
+    const int row0 = tile * 32;
+    float nxt[10];
+    fetch(row0 + rr, nxt);
+    __syncthreads();                                                 // the previous tile's ys / xs are free (and the staging above is done)
+    for (int it = 0; it < 16; ++it) {
+      float* const xb = xs[it & 1][rr];
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      const int e = tid + 512 * i;
-      const float v = nxt[i];
-      xs[e] = e < 16 * GL_FI ? v : (v > 0.f ? v : gl_exp(v) - 1.0f);   // ELU on the skip half
+      for (int i = 0; i < 10; ++i) {
+        const int e = o + 256 * i;
+        const float v = nxt[i];
+        xb[e] = e < 16 * GL_FI ? v : (v > 0.f ? v : gl_exp(v) - 1.0f);   // ELU on the skip half
+      }
+      if (it + 1 < 16) fetch(row0 + 2 * (it + 1) + rr, nxt);         // the next pair of rows: in flight during this pair's arithmetic
+      __syncthreads();                                               // (the other buffer was last read two iterations ago)
+      if (act) {
+        // ConvTranspose (1,3) stride 2: even bin 2j <- tap 0 at j, tap 2 at j-1; odd bin 2j+1 <- tap 1 at j
+        const int j = o >> 1;
+        const bool has0 = odd || j < GL_FI, has2 = !odd && j >= 1;     // bin 160 = 2 * 80 has no tap 0, bin 0 no tap 2
+        const int j0 = has0 ? j : GL_FI - 1, j2 = has2 ? j - 1 : 0;
+        float m = 0.f, g = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) {
+          const float4 w = wl4[odd ? 1 : 0][k];
+          const float x0 = has0 ? xb[k * GL_FI + j0] : 0.f, x2 = has2 ? xb[k * GL_FI + j2] : 0.f;
+          m += x0 * w.x + x2 * w.y;
+          g += x0 * w.z + x2 * w.w;
+        }
+        float y = (m + d.b1) * __builtin_amdgcn_rcpf(1.0f + gl_exp(-(g + d.b2)));
+        y = y * d.bn_scale + d.bn_shift;
+        y = y > 0.f ? y : gl_exp(y) - 1.0f;
+        ys[(2 * (o >> 3) + (o & 1)) * GL_YB + (2 * it + rr) * 4 + ((o >> 1) & 3)] = y;   // k = o = 2 (4 kq + i) + h
+      }
     }
-    if (row + (int)gridDim.x < rows) fetch(row + gridDim.x, nxt);   // next row: in flight during this row's arithmetic
     __syncthreads();
-    float m = 0.f, g = 0.f;
-    if (act) {
-      // ConvTranspose (1,3) stride 2: even bin 2j <- tap 0 at j, tap 2 at j-1; odd bin 2j+1 <- tap 1 at j.  The thread's
-      // weights come as one float4 per channel (wl4)
-      const int j = o >> 1, c0 = 16 * half;
-      const bool has0 = odd || j < GL_FI, has2 = !odd && j >= 1;     // bin 160 = 2 * 80 has no tap 0, bin 0 no tap 2
-      const int j0 = has0 ? j : GL_FI - 1, j2 = has2 ? j - 1 : 0;
+    // ---- Linear(161,161): wave w < 6 owns output bins 32 w .. 32 w + 31 of all 32 rows
+    if (wave < 6) {
+      f32x16 acc;
 #pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        const float4 w = wl4[odd ? 1 : 0][c0 + k];
-        const float x0 = has0 ? xs[(c0 + k) * GL_FI + j0] : 0.f, x2 = has2 ? xs[(c0 + k) * GL_FI + j2] : 0.f;
-        m += x0 * w.x + x2 * w.y;
-        g += x0 * w.z + x2 * w.w;
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const float4* const B4 = reinterpret_cast<const float4*>(d.fcp) + (size_t)wave * GL_KQ * 64 + lane;   // [6 tiles][21][64 lanes][4]
+      const float* const A1 = ys + (lane >> 5) * GL_YB + (lane & 31) * 4;                                   // + kq * 2 * GL_YB
+#pragma unroll 7
+      for (int kq = 0; kq < GL_KQ; ++kq) {
+        const float4 bv = B4[(size_t)kq * 64];
+        const float4 av = *reinterpret_cast<const float4*>(A1 + kq * 2 * GL_YB);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
       }
-      if (half) {
-        pm[1][o] = m;
-        pg[1][o] = g;
-      }
-    }
-    __syncthreads();
-    if (act && half == 0) {
-      m += pm[1][o];
-      g += pg[1][o];
-      float y = (m + d.b1) * __builtin_amdgcn_rcpf(1.0f + gl_exp(-(g + d.b2)));
-      y = y * d.bn_scale + d.bn_shift;
-      ys[o] = y > 0.f ? y : gl_exp(y) - 1.0f;
-    }
-    __syncthreads();
-    float a0 = fcb, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    if (act) {
-      const float* yh = ys + KH * half;     // half 1 reads 84..167: ys[161..163] are zero, col[] is zero there too
+      const int ob = 32 * wave + (lane & 31);
+      if (ob < GL_F) {
+        const float bias = d.fcb[ob];
 #pragma unroll
-      for (int i = 0; i < KH; i += 4) {
-        float4 y;
-        if (KH * half + i + 4 <= 164) y = *reinterpret_cast<const float4*>(yh + i);
-        else y = make_float4(0.f, 0.f, 0.f, 0.f);
-        a0 += col[i] * y.x;
-        a1 += col[i + 1] * y.y;
-        a2 += col[i + 2] * y.z;
-        a3 += col[i + 3] * y.w;
+        for (int r = 0; r < 16; ++r) {
+          const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);   // accumulator row of register r
+          if (row < rows) {
+            const int b = row / d.T, t = row - b * d.T;
+            d.out[(int64_t)b * d.out_sb + (int64_t)t * GL_F + ob] = acc[r] + bias;
+          }
+        }
       }
-      if (half) pf[o] = (a0 + a1) + (a2 + a3);
     }
-    __syncthreads();
-    if (act && half == 0) d.out[(int64_t)b * d.out_sb + (int64_t)t * GL_F + o] = ((a0 + a1) + (a2 + a3)) + pf[o];
   }
 }
 
 int pdse_gcrnlast_launch(const pdse_gcrnlast_desc* d, hipStream_t s) {
-  REQ(d && d->in0 && d->in1 && d->w1 && d->w2 && d->fcT && d->fcb && d->out, "gcrn_last: null pointer");
+  REQ(d && d->in0 && d->in1 && d->w1 && d->w2 && d->fcT && d->fcp && d->fcb && d->out, "gcrn_last: null pointer");
   REQ(d->B > 0 && d->T > 0 && (int64_t)d->B * d->T < (1ll << 31), "gcrn_last: bad sizes");
-  const int rows = d->B * d->T;
-  hipLaunchKernelGGL(gcrnlast_kernel, dim3(rows < 512 ? rows : 512), dim3(512), 0, s, *d);   // two workgroups per CU
+  const int ntiles = (d->B * d->T + 31) / 32;
+  hipLaunchKernelGGL(gcrnlast_kernel, dim3(ntiles < 512 ? ntiles : 512), dim3(512), 0, s, *d);   // two workgroups per CU
   return pdse_check_launch("gcrn_last");
 }
 

@@ -1382,6 +1382,7 @@ class GcrnPlan(PlanBase):
                         return dict(w1=up(self.w(p + ".conv1.weight")[:, 0, 0, :]),          # [32, 3]
                                     w2=up(self.w(p + ".conv2.weight")[:, 0, 0, :]),
                                     fcT=up(self.w("fc%d.weight" % br).T), fcb=up(self.w("fc%d.bias" % br)),
+                                    fcp=up(P.pack_a4(self.w("fc%d.weight" % br).T, np.where(np.arange(168) < 161, np.arange(168), -1))),
                                     b1=float(self.w(p + ".conv1.bias")[0]), b2=float(self.w(p + ".conv2.bias")[0]),
                                     bn_scale=float(sc[0]), bn_shift=float(sh[0]))
 
