@@ -662,7 +662,11 @@ typedef struct pdse_bglu_desc {
   /* skip_Fh > 0 (ABI 5): the bins of the skip halves (nx_out written by the encoder at bin j; nx_add read by the dual-phase
      decoders at bins 2j and 2j+1) are stored split by parity, bin i at (i & 1) * skip_Fh + (i >> 1) (skip_Fh = ceil(F / 2) of the
      tensor): each decoder phase then reads whole lines instead of every other 16 bytes of them.  0: bin i at i. */
-  int32_t skip_Fh, pad1_;
+  int32_t skip_Fh;
+  /* ABI 6: items (of nx_hp_sb / nx_sb[i] elements each) the caller ALLOCATED for nx_hp and for every nx_out tensor.  Lanes beyond
+     the last position store unconditionally into a dump item at index B, so B + 1 are required; the launcher refuses fewer (a
+     B-item tensor handed to this public entry point would otherwise be written past its end, silently). */
+  int32_t nx_items;
 } pdse_bglu_desc;
 
 /* fp32 [B, 32, T, F] -> hp planes (the standalone conv1 of the first decoder stage) */

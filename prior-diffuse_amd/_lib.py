@@ -191,7 +191,7 @@ class BgluDesc(C.Structure):
                 ("nx_row0", _i32), ("nx_par", _i32),
                 ("nx_add", _fp), ("add_sb", _i64), ("add_sc", _i64), ("add_st", _i64), ("add_sf", _i64),
                 ("nx_out", _fp * 2), ("nx_sb", _i64 * 2), ("nx_sc", _i64 * 2), ("nx_st", _i64 * 2), ("nx_sf", _i64 * 2),
-                ("nx_bias", _fp * 3), ("nx_bias_sb", _i64 * 3), ("skip_Fh", _i32), ("pad1_", _i32)]
+                ("nx_bias", _fp * 3), ("nx_bias_sb", _i64 * 3), ("skip_Fh", _i32), ("nx_items", _i32)]
 
 
 class PlanesDesc(C.Structure):

@@ -253,9 +253,13 @@ int pdse_attn_launch(const pdse_attn_desc* d, hipStream_t s) {
   REQ(d->axis == 0 || d->axis == 1, "attention: axis 0 (bins) or 1 (frames)");
   const int S = d->axis == 0 ? d->F : d->T, lines = d->axis == 0 ? d->T : d->F;
   const int HD = d->E / 4;
-  // one LDS image of the head's K and V when the sequence fits (S <= 2048), else key chunks of 2048 positions (a multiple of four keys)
-  const int CH = S <= 2048 ? S : 2048;
+  // one LDS image of the head's K and V when the sequence fits, else key chunks (a multiple of four keys).  The chunk follows from
+  // the LDS budget: 2 CH HD floats <= 64 KB (two workgroups per CU at the least) - 2048 keys at head dimension 8 (d_model 32),
+  // 1024 at 16 (d_model 64: 2048 keys would ask for 256 KB, more than a CU has)
+  const int cap = (int)((64 * 1024) / (2 * HD * sizeof(float))) & ~3;
+  const int CH = S <= cap ? S : cap;
   const size_t lds = (size_t)2 * CH * HD * sizeof(float);
+  REQ(lds <= 160 * 1024, "attention: LDS image of K and V exceeds the CU");
   const void* fn = d->E == 32 ? (const void*)attn_kernel<8> : (const void*)attn_kernel<16>;
   if (lds > 64 * 1024)
     if (pdse_check_hip(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "attention lds attribute"))

@@ -1386,6 +1386,10 @@ int pdse_bglu_launch(const pdse_bglu_desc* d, hipStream_t s) {
     return 1;
   }
   if (d->nx_n > 0) {
+    if (d->nx_items < d->B + 1) {
+      pdse_set_error("bglu: nx_hp / nx_out need B + 1 allocated items (nx_items): item B is the dump target of lanes beyond the last position");
+      return 1;
+    }
     const long long frame = 4ll * d->np * d->nx_Fp;
     int maxbin = d->Fout - 1;
     if (d->p1mask) maxbin = 2 * (d->Fout - 1) > 2 * (d->Fout1 - 1) + 1 ? 2 * (d->Fout - 1) : 2 * (d->Fout1 - 1) + 1;

@@ -852,6 +852,8 @@ class EpsNetPlan(PlanBase):
             d.out_off = out_off
         d.skip_Fh = (skip_F + 1) // 2 if (skip_F and self.parity_planes) else 0   # bins of the skip halves split by parity
         d.nx_n = (1 if nx_hp is not None else 0) + len(nx_out)
+        d.nx_items = B + 1          # what hp_shape(B + 1, ...) and the Pskip tensors hold: item B is the kernel's dump target
+        assert all(t_.shape[0] == B + 1 for t_, *_ in nx_out) and (nx_hp is None or nx_hp.shape[0] == B + 1)
         if nx_hp is not None:
             shp = P.hp_shape(B + 1, T, nx_F, npl)
             d.nx_hp, d.nx_hp_sb, d.nx_Tp, d.nx_Fp, d.nx_t0, d.nx_f0 = (nx_hp.data_ptr(), int(np.prod(shp[1:])), shp[1], shp[4],

@@ -47,6 +47,11 @@ def test_argument_errors_do_not_need_a_device(lib):
         lib.launch(lib.BgluDesc())
     with pytest.raises(lib.PdseError, match="planes"):
         lib.launch(lib.PlanesDesc())
+    with pytest.raises(lib.PdseError, match="glstmp"):
+        lib.launch(lib.GlstmpDesc())
+    with pytest.raises(lib.PdseError, match="tcm2s"):
+        lib.launch(lib.Tcm2sDesc())
+    assert lib.load().pdse_bglu_set_form(7) == -2 and lib.load().pdse_bglu_set_form(0) in (-1, 0)      # the product library holds form 0 only
     # round 3 (ABI 5): channel-blocked sources are a feature of the korder-3 kernel; the split GRU is the fused H = 64 form
     import ctypes as C
 

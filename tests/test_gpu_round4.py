@@ -130,6 +130,30 @@ def test_saved_plans_through_the_bare_c_abi(L, weights, tmp_path):
     ref = str(tmp_path / "ref.npz")
     np.savez(ref, wav=wav.numpy(), x_T=x_T.numpy(), wav_out=out.cpu().numpy(), spec=spec.cpu().numpy())
     assert _client(tmp_path, "enhance", plan, ref, 1e-12) == 0.0        # the same kernels on the same operands: bit for bit
+    # ... and a plan that owns the GPU: the persistent LSTM (granule ring, status word) and the TCM stack descriptor (18 block
+    # descriptors by value, every pointer in them re-based) survive the file as well
+    pipe = pkg("pipeline").SamplerPipeline(DEV, "GCRN", weights("GCRN"), weights("DiffUNet1"), B, L_=L_, exclusive=True)
+    assert any(isinstance(d, L.GlstmpDesc) for d, _ in pipe.descs) and any(isinstance(d, L.Tcm2sDesc) for d, _ in pipe.descs)
+    plan = pf.save_pipeline(str(tmp_path / "path_x.plan"), pipe)
+    out, spec = pipe.enhance(wav.to(DEV), x_T.to(DEV))
+    pipe.check()
+    np.savez(ref, wav=wav.numpy(), x_T=x_T.numpy(), wav_out=out.cpu().numpy(), spec=spec.cpu().numpy())
+    assert _client(tmp_path, "enhance", plan, ref, 1e-12) == 0.0
+
+
+def test_block_kernel_refuses_a_tensor_without_its_dump_item(L, weights):
+    """pdse_bglu_planes stores unconditionally into item B of nx_hp / nx_out (lanes beyond the last position): the descriptor says
+    how many items were allocated and the launcher refuses fewer than B + 1 (advisor, round 3)."""
+    nets = pkg("nets")
+    net = nets.EpsNetPlan(nets.Ctx(DEV), weights("DiffUNet1"), 1, 8, time_cond=True, nsteps=1)
+    net.build_time()
+    net.build_step(0)
+    d = [d for d, _ in net.descs if isinstance(d, L.BgluDesc) and d.nx_n > 0][0]
+    assert d.nx_items == d.B + 1
+    bad = type(d).from_buffer_copy(d)
+    bad.nx_items = bad.B
+    with pytest.raises(L.PdseError, match="dump target"):
+        L.launch(bad)
 
 
 # ------------------------------------------------------------------ the bf16 rows of BASELINE configs 4 and 5 (config 2: test_gpu_round2.py)

@@ -60,7 +60,7 @@ def bench(name, NT, p1mask, C2, nx_n, Fin, Fout, Fout1, sf_in, taps, NP=3, B=32,
         d.nx_w = W(4 * nx_n)
     d.bias0, d.bias1, d.bias_sb = Fv(32 * B), Fv(32 * B), 32
     d.blc, d.brc, d.bc2 = Fv(32), Fv(32), Fv(64)
-    d.slope, d.C2, d.nx_n = 0.25, C2, nx_n
+    d.slope, d.C2, d.nx_n, d.nx_items = 0.25, C2, nx_n, B + 1
     Fo = 2 * Fout if p1mask else Fout
     if C2 == 1 or nx_n == 0:
         out = torch.empty(B, 64 if C2 == 64 else 1, T, Fo + 2, device=DEV)
