@@ -123,7 +123,9 @@ typedef struct pdse_gconv_desc {
                (packing.rho_bf16).  Activations, biases, BatchNorm and every output stay fp32.
      3: split-bf16 GEMM-shaped convolutions (csrc/gconv4.hip; LINEAR / GLU, channel counts in multiples of 16, no load
      transform): w0 (w1) [K blocks][ceil(Cout/32) tiles][3 planes][64 lanes][8 bf16], K blocks of 16 channels in the
-     order (source, tap, channel block); lane (row, h), element j = W[tap*Cin + cbase + 16cb + 8h + j][32 tile + row]. */
+     order (source, tap, channel block); lane (row, h), element j = W[tap*Cin + cbase + 16cb + 8h + j][32 tile + row].
+     4 (ABI 6): the same kernel on ONE plane - plain bf16 operands (weights and gathered activations rounded to nearest even),
+     one product, fp32 accumulation: w0 (w1) [K blocks][tiles][1][64][8].  The opt-in bf16 mode; its own tolerance. */
   int32_t korder;
   /* Dual-phase stride-(1,2) ConvTranspose2d (BIGLU only, korder 1): one launch computes the even
      output bins f_o = 2j (weights w0/w1 over all ntaps taps) AND the odd bins 2j+1 (weights w2/w3

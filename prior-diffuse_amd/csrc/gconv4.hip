@@ -89,30 +89,49 @@ __device__ __forceinline__ void g4_landed(g4_raw<true>& raw) {
 // block's ring reads - each chunk then waited for the NEXT chunk's DMA and gathers before its first MFMA.  The chunk
 // barrier orders the DMA of a buffer before its reads; the wait below orders the reads before their use.
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // a register quad the inline asm can name (uint4 is a struct)
+// the NP planes of one fragment (NP = 3: exact three-way split; NP = 1: plain bf16, the opt-in bf16 mode - korder 4)
 __device__ __forceinline__ void g4_lds_read3(const unsigned addr, u32x4 (&a)[3]) {
   asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:1024\n\tds_read_b128 %2, %3 offset:2048"
                : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2])
                : "v"(addr)
                : "memory");
 }
-template <int N>
-__device__ __forceinline__ void g4_lds_wait(u32x4 (&a)[N][3]) {
+__device__ __forceinline__ void g4_lds_read3(const unsigned addr, u32x4 (&a)[1]) {
+  asm volatile("ds_read_b128 %0, %1" : "=&v"(a[0]) : "v"(addr) : "memory");
+}
+template <int N, int NP>
+__device__ __forceinline__ void g4_lds_wait(u32x4 (&a)[N][NP]) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
   for (int i = 0; i < N; ++i)
 #pragma unroll
-    for (int p = 0; p < 3; ++p) asm volatile("" : "+v"(a[i][p]));
+    for (int p = 0; p < NP; ++p) asm volatile("" : "+v"(a[i][p]));
 }
-__device__ __forceinline__ f32x16 g4_mfma6(const u32x4 (&a)[3], const uint4& b1, const uint4& b2, const uint4& b3, f32x16 acc) {
+__device__ __forceinline__ f32x16 g4_mfma6(const u32x4 (&a)[3], const uint4 (&b)[3], f32x16 acc) {
   const uint4 a1 = make_uint4(a[0][0], a[0][1], a[0][2], a[0][3]), a2 = make_uint4(a[1][0], a[1][1], a[1][2], a[1][3]),
               a3 = make_uint4(a[2][0], a[2][1], a[2][2], a[2][3]);
-  acc = mfma_bf16(a1, b3, acc);
-  acc = mfma_bf16(a3, b1, acc);
-  acc = mfma_bf16(a2, b2, acc);
-  acc = mfma_bf16(a1, b2, acc);
-  acc = mfma_bf16(a2, b1, acc);
-  acc = mfma_bf16(a1, b1, acc);
+  acc = mfma_bf16(a1, b[2], acc);
+  acc = mfma_bf16(a3, b[0], acc);
+  acc = mfma_bf16(a2, b[1], acc);
+  acc = mfma_bf16(a1, b[1], acc);
+  acc = mfma_bf16(a2, b[0], acc);
+  acc = mfma_bf16(a1, b[0], acc);
   return acc;
+}
+__device__ __forceinline__ f32x16 g4_mfma6(const u32x4 (&a)[1], const uint4 (&b)[1], f32x16 acc) {
+  return mfma_bf16(make_uint4(a[0][0], a[0][1], a[0][2], a[0][3]), b[0], acc);
+}
+__device__ __forceinline__ uint32_t g4_pack_bf16(const float a, const float b) {   // round to nearest even (v_cvt_pk_bf16_f32)
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  const f32x2 v = {a, b};
+  union { bf16x2 h; uint32_t u; } c;
+  c.h = __builtin_convertvector(v, bf16x2);
+  return c.u;
+}
+__device__ __forceinline__ void g4_split(const float (&x)[8], uint4 (&b)[3]) { split8(x, b[0], b[1], b[2]); }
+__device__ __forceinline__ void g4_split(const float (&x)[8], uint4 (&b)[1]) {
+  b[0] = make_uint4(g4_pack_bf16(x[0], x[1]), g4_pack_bf16(x[2], x[3]), g4_pack_bf16(x[4], x[5]), g4_pack_bf16(x[6], x[7]));
 }
 
 struct g4_chunk {
@@ -122,8 +141,9 @@ struct g4_chunk {
 __device__ long long* g_trace4 = nullptr;   // PDSE_G4_TRACE=1 (diagnostic): [workgroup][wave][8] clock sums
 
 // BLK: every source is channel-blocked (pdse_src.blk = 8) / none is
-template <int EPI, int MT, bool BLK>
+template <int EPI, int MT, bool BLK, int NP = 3>
 __global__ __launch_bounds__(512, 2) void gconv4_kernel(const pdse_gconv_desc d) {
+  constexpr int FB = 64 * NP;   // uint4 entries per fragment (NP planes of 64 lanes)
 #ifdef PDSE_DIAG
   long long* const trace = g_trace4;
 #else
@@ -133,7 +153,7 @@ __global__ __launch_bounds__(512, 2) void gconv4_kernel(const pdse_gconv_desc d)
   long long c_req = 0, c_cmp = 0, c_bar = 0;
   constexpr bool DUAL = (EPI != PDSE_EPI_LINEAR);
   constexpr int NBR = DUAL ? 2 : 1, FR = NBR * MT;   // fragments (3 planes each) per K block and workgroup
-  extern __shared__ uint4 ring[];                     // [2 buffers][G4_CH blocks][FR][192]
+  extern __shared__ uint4 ring[];                     // [2 buffers][G4_CH blocks][FR][FB]
   const unsigned ring_base = (unsigned)(uintptr_t)ring;   // LDS byte address (the low half of the flat address)
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -166,14 +186,14 @@ __global__ __launch_bounds__(512, 2) void gconv4_kernel(const pdse_gconv_desc d)
   };
   // A fragments of a chunk -> ring buffer `buf`: one 1 KB piece (= one plane of one fragment) per wave instruction
   auto dma = [&](const g4_chunk& c, const int buf) {
-    const int npieces = c.n * FR * 3;
+    const int npieces = c.n * FR * NP;
     for (int pc = __builtin_amdgcn_readfirstlane(wave); pc < npieces; pc += 8) {
-      const int i = pc / (FR * 3), rem = pc - i * (FR * 3), f = rem / 3, part = rem - f * 3;
+      const int i = pc / (FR * NP), rem = pc - i * (FR * NP), f = rem / NP, part = rem - f * NP;
       const int br = f / MT, m = f - br * MT;
       if (mt0 + m < mtiles) {   // tiles past Cout keep stale fragments: their accumulators are never stored
-        const uint4* src = reinterpret_cast<const uint4*>(br ? d.w1 : d.w0) + ((size_t)(c.kb0 + i) * mtiles + mt0 + m) * 192 +
+        const uint4* src = reinterpret_cast<const uint4*>(br ? d.w1 : d.w0) + ((size_t)(c.kb0 + i) * mtiles + mt0 + m) * FB +
                            part * 64 + lane;
-        glds16_g4(src, ring + ((buf * G4_CH + i) * FR + f) * 192 + part * 64);
+        glds16_g4(src, ring + ((buf * G4_CH + i) * FR + f) * FB + part * 64);
       }
     }
   };
@@ -229,10 +249,10 @@ __global__ __launch_bounds__(512, 2) void gconv4_kernel(const pdse_gconv_desc d)
   // end every block waited for its twelve ring reads with an idle matrix pipe: 5.3k cycles per chunk for 3.1k of MFMAs.
   auto compute = [&](const g4_chunk& c, const g4_raw<BLK>& raw, const bool inb, const int buf) {
     const bool elu = uni((c.s ? d.in1.act : d.in0.act) == PDSE_ACT_ELU) != 0;   // GCRN re-applies ELU to the skip half (gcrn.py:152-155)
-    u32x4 af[FR][3];
-    const unsigned wa0 = ring_base + (unsigned)((((buf * G4_CH) * FR) * 192 + lane) * 16);
+    u32x4 af[FR][NP];
+    const unsigned wa0 = ring_base + (unsigned)((((buf * G4_CH) * FR) * FB + lane) * 16);
 #pragma unroll
-    for (int f = 0; f < FR; ++f) g4_lds_read3(wa0 + f * (192 * 16), af[f]);
+    for (int f = 0; f < FR; ++f) g4_lds_read3(wa0 + f * (FB * 16), af[f]);
 #pragma unroll
     for (int i = 0; i < G4_CH; ++i) {
       if (i < c.n) {
@@ -243,19 +263,19 @@ __global__ __launch_bounds__(512, 2) void gconv4_kernel(const pdse_gconv_desc d)
 #pragma unroll
           for (int e = 0; e < 8; ++e) x[e] = x[e] < 0.f ? fast_exp(x[e]) - 1.0f : x[e];
         }
-        uint4 b1, b2, b3;
-        split8(x, b1, b2, b3);   // runs under the LDS latency of the block's fragments
+        uint4 bp[NP];
+        g4_split(x, bp);         // runs under the LDS latency of the block's fragments
         g4_lds_wait(af);
         const bool more = i + 1 < c.n;   // wave-uniform
-        const unsigned wn = ring_base + (unsigned)((((buf * G4_CH + i + 1) * FR) * 192 + lane) * 16);
+        const unsigned wn = ring_base + (unsigned)((((buf * G4_CH + i + 1) * FR) * FB + lane) * 16);
 #pragma unroll
         for (int f = 0; f < FR; ++f) {
           const int m = f % MT;
-          if (f < MT) acc0[m] = g4_mfma6(af[f], b1, b2, b3, acc0[m]);
-          else acc1[m] = g4_mfma6(af[f], b1, b2, b3, acc1[m]);
+          if (f < MT) acc0[m] = g4_mfma6(af[f], bp, acc0[m]);
+          else acc1[m] = g4_mfma6(af[f], bp, acc1[m]);
           // (i + 1 < G4_CH is a compile-time fact once the loop is unrolled: no read is emitted behind the last possible block,
           // whose destination registers would be dead - free for the compiler to re-use - while the read is still in flight)
-          if (i + 1 < G4_CH && more) g4_lds_read3(wn + f * (192 * 16), af[f]);
+          if (i + 1 < G4_CH && more) g4_lds_read3(wn + f * (FB * 16), af[f]);
         }
       }
     }
@@ -313,14 +333,14 @@ __global__ __launch_bounds__(512, 2) void gconv4_kernel(const pdse_gconv_desc d)
   }
 }
 
-template <int EPI, int MT, bool BLK>
+template <int EPI, int MT, bool BLK, int NP>
 static int launch4b(const pdse_gconv_desc* d, hipStream_t s, const int mtiles) {
   const int P = d->Tout * d->Fout;
   const dim3 grid(((P + 31) / 32 + 7) / 8, d->B, (mtiles + MT - 1) / MT), block(512);
   constexpr int FR = (EPI == PDSE_EPI_LINEAR ? 1 : 2) * MT;
-  const size_t lds = (size_t)2 * G4_CH * FR * 192 * sizeof(uint4);
+  const size_t lds = (size_t)2 * G4_CH * FR * 64 * NP * sizeof(uint4);
   static unsigned long long attr_mask = 0;   // per instantiation and device
-  if (lds > 64 * 1024 && pdse_lds_attr((const void*)gconv4_kernel<EPI, MT, BLK>, &attr_mask, "gconv4 lds attribute")) return 1;
+  if (lds > 64 * 1024 && pdse_lds_attr((const void*)gconv4_kernel<EPI, MT, BLK, NP>, &attr_mask, "gconv4 lds attribute")) return 1;
   static const bool tracing = PDSE_DIAG_ENV("PDSE_G4_TRACE") != nullptr;
   static long long* tbuf = nullptr;
   const size_t nw = (size_t)grid.x * grid.y * grid.z * 8;
@@ -331,7 +351,7 @@ static int launch4b(const pdse_gconv_desc* d, hipStream_t s, const int mtiles) {
     }
     (void)hipMemsetAsync(tbuf, 0, nw * 64, s);
   }
-  hipLaunchKernelGGL((gconv4_kernel<EPI, MT, BLK>), grid, block, lds, s, *d);
+  hipLaunchKernelGGL((gconv4_kernel<EPI, MT, BLK, NP>), grid, block, lds, s, *d);
   if (tracing && nw * 64 <= ((size_t)1 << 24)) {   // diagnostic: per-wave averages in shader clocks
     (void)hipStreamSynchronize(s);
     long long* h = (long long*)malloc(nw * 64);
@@ -349,7 +369,9 @@ static int launch4b(const pdse_gconv_desc* d, hipStream_t s, const int mtiles) {
 
 template <int EPI, int MT>
 static int launch4(const pdse_gconv_desc* d, hipStream_t s, const int mtiles) {
-  return d->in0.blk ? launch4b<EPI, MT, true>(d, s, mtiles) : launch4b<EPI, MT, false>(d, s, mtiles);
+  if (d->korder == 4)   // one plane: plain bf16 operands, one product (the opt-in bf16 mode)
+    return d->in0.blk ? launch4b<EPI, MT, true, 1>(d, s, mtiles) : launch4b<EPI, MT, false, 1>(d, s, mtiles);
+  return d->in0.blk ? launch4b<EPI, MT, true, 3>(d, s, mtiles) : launch4b<EPI, MT, false, 3>(d, s, mtiles);
 }
 
 // korder 3: LINEAR / GLU, one or two sources of a multiple of 16 channels, no load transform; validated by pdse_gconv_launch

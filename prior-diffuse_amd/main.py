@@ -33,7 +33,7 @@ def parse_args_and_config(argv=None):
     p.add_argument("--data", type=str, default="data/noisy_testset_wav", help="directory of noisy wavs")
     p.add_argument("--bf16", action="store_true",
                    help="(not a flag of the reference) the opt-in reduced-precision mode: plain bf16 operands and bf16 block-boundary "
-                        "tensors in the eps-net's blocks, tolerance 3e-2 rel-L2 against the fp32 path; default: fp32-equivalent arithmetic")
+                        "tensors in the eps-net's blocks and the priors' GEMM-shaped convolutions, tolerance 3e-2 rel-L2 against the fp32 path; default: fp32-equivalent arithmetic")
     args = p.parse_args(argv)
     args.log = os.path.join(args.assets, "log", args.doc)
     args.checkpoint = os.path.join(args.assets, "checkpoint", args.doc)

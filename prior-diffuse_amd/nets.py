@@ -93,6 +93,8 @@ class Ctx:
 
 class PlanBase:
     force_generic = False   # tests: route every convolution through the un-pipelined kernel
+    gemm_planes = 3         # operand planes of the GEMM-shaped convolutions (csrc/gconv4.hip): 3 = exact three-way bf16 split
+                            # (korder 3), 1 = plain bf16, one product (korder 4: the opt-in bf16 mode, its own tolerance)
 
     def __init__(self, ctx, plan=None, ns=()):
         self.ctx = ctx
@@ -174,9 +176,10 @@ class PlanBase:
         ctx = self.ctx
         up = lambda a: ctx.up(a).data_ptr()   # noqa: E731
         up16 = lambda a: ctx.up(np.ascontiguousarray(a).view(np.int16), np.int16).data_ptr()   # noqa: E731
-        f = {"korder": 3, "ksteps": ntaps * (c0 + c1) // 2, "w0": up16(P.pack_s3_gemm(w["wk0"], ntaps, c0, c1))}
+        npl = self.gemm_planes
+        f = {"korder": 3 if npl == 3 else 4, "ksteps": ntaps * (c0 + c1) // 2, "w0": up16(P.pack_s3_gemm(w["wk0"], ntaps, c0, c1, npl))}
         if w.get("wk1") is not None:
-            f["w1"] = up16(P.pack_s3_gemm(w["wk1"], ntaps, c0, c1))
+            f["w1"] = up16(P.pack_s3_gemm(w["wk1"], ntaps, c0, c1, npl))
         for k in ("bias0", "bias1"):
             if w.get(k) is not None:
                 f[k] = up(w[k])
@@ -1147,15 +1150,22 @@ class GcrnPlan(PlanBase):
     ENC_C = [2, 16, 32, 64, 128, 256]
     ENC_F = [161, 80, 39, 19, 9, 4]
 
-    def __init__(self, ctx, sd, B, T, plan=None, split_bf16=None, exclusive=False):
-        """exclusive: nothing else runs on the GPU beside this plan (one batch in flight) - the condition under which the
+    def __init__(self, ctx, sd, B, T, plan=None, split_bf16=None, exclusive=False, planes=None):
+        """planes 1: the opt-in bf16 mode - the gated (transposed) convolutions and the LSTM input projection multiply plain
+        bf16 operands (csrc/gconv4.hip, korder 4); tensors, LSTM and the last stage stay fp32.
+        exclusive: nothing else runs on the GPU beside this plan (one batch in flight) - the condition under which the
         persistent LSTM may be used (its 256 workgroups wait for each other and must all be resident).  Off by default: a
         plan built with it takes another LSTM kernel at B <= PERSIST_MAX_B than at larger B, so an utterance's result is
         within 1e-5 of, not bit-identical to, the same utterance in a larger batch or shard."""
         if split_bf16 is not None:
             self.split_bf16 = bool(split_bf16)
+        if planes is not None:
+            if planes not in (1, 3) or (planes == 1 and not self.split_bf16):
+                raise ValueError("planes is 3 or 1; the one-plane bf16 mode runs on the GEMM kernels (split_bf16)")
+            self.gemm_planes = int(planes)
         self.persist = bool(self.persist_lstm and self.fused_glstm and exclusive and B <= self.PERSIST_MAX_B and not self.force_generic)
-        super().__init__(ctx, plan, ns=(ctx.bank.token(sd), self.fused_last, self.fused_glstm, self.split_bf16, self.block8, self.persist))
+        super().__init__(ctx, plan, ns=(ctx.bank.token(sd), self.fused_last, self.fused_glstm, self.split_bf16, self.block8, self.persist,
+                                        self.gemm_planes))
         self.sd, self.B, self.T = sd, B, T
         a = ctx.alloc
         self.Bp = Bp = (B + 31) // 32 * 32
@@ -1512,11 +1522,15 @@ class AiaPlan(PlanBase):
     split_gru = True         # (with split_bf16 and the fused form) that recurrence on split-bf16 operands (csrc/gru3.hip)
     split_bf16 = True        # dilated dense blocks and the strided / sub-pixel convolutions as split-bf16 GEMMs (csrc/gconv4.hip)
 
-    def __init__(self, ctx, sd, B, T, plan=None, d=32, split_bf16=None):
+    def __init__(self, ctx, sd, B, T, plan=None, d=32, split_bf16=None, planes=None):
         """d: d_model of the transformer layers (32: AIA_Transformer(64, 64); 64: AIA_Transformer_merge(128, 64))."""
         if split_bf16 is not None:
             self.split_bf16 = bool(split_bf16)
-        super().__init__(ctx, plan, ns=(ctx.bank.token(sd), d, self.fused_gru_input, self.split_bf16, self.split_gru))
+        if planes is not None:       # 1: the opt-in bf16 mode - dense blocks / strided convolutions on plain bf16 operands (korder 4)
+            if planes not in (1, 3) or (planes == 1 and not self.split_bf16):
+                raise ValueError("planes is 3 or 1; the one-plane bf16 mode runs on the GEMM kernels (split_bf16)")
+            self.gemm_planes = int(planes)
+        super().__init__(ctx, plan, ns=(ctx.bank.token(sd), d, self.fused_gru_input, self.split_bf16, self.split_gru, self.gemm_planes))
         self.sd, self.B, self.T, self.d = sd, B, T, d
         a = ctx.alloc
         FH = self.FH
@@ -1795,8 +1809,8 @@ class DualAiaPlan(AiaPlan):
     append), and IEEE addition commutes.  The golden vectors of the reference module confirm that the two output
     lists are bit-identical (tests/test_oracle_golden.py), so each layer is evaluated once."""
 
-    def __init__(self, ctx, sd, B, T, plan=None, split_bf16=None):
-        super().__init__(ctx, sd, B, T, plan, d=64, split_bf16=split_bf16)
+    def __init__(self, ctx, sd, B, T, plan=None, split_bf16=None, planes=None):
+        super().__init__(ctx, sd, B, T, plan, d=64, split_bf16=split_bf16, planes=planes)
         a = ctx.alloc
         self.mag = a(B, 1, T, F0)
         self.x_mag_en = a(B, 64, T, self.FH)

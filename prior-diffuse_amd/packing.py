@@ -424,8 +424,9 @@ def s3_gemm_krows(ntaps, c0, c1):
     return np.asarray(rows, np.int64)
 
 
-def pack_s3_gemm(wk, ntaps, c0, c1):
-    """wk [ntaps*(c0+c1), Cout] (k-major) -> uint16 [K blocks][ceil(Cout/32)][3 planes][64 lanes][8]."""
+def pack_s3_gemm(wk, ntaps, c0, c1, npl=3):
+    """wk [ntaps*(c0+c1), Cout] (k-major) -> uint16 [K blocks][ceil(Cout/32)][npl planes][64 lanes][8]
+    (npl 3: exact three-way bf16 split, korder 3; 1: the RNE bf16 value, korder 4 - the opt-in bf16 mode)."""
     wk = np.asarray(wk, np.float64).astype(np.float32)
     K, M = wk.shape
     assert K == ntaps * (c0 + c1) and c0 % 16 == 0 and c1 % 16 == 0
@@ -436,15 +437,17 @@ def pack_s3_gemm(wk, ntaps, c0, c1):
     nkb = K // 16
     frag = ordered.reshape(nkb, 2, 8, mt, 32).transpose(0, 3, 1, 4, 2)    # [kb, mt, h, row, j]
     frag = frag.reshape(nkb, mt, 64, 8)
+    if npl == 1:
+        return np.ascontiguousarray(bf16_rne(frag)[:, :, None])           # [kb, mt, 1, 64, 8]
     p = split_bf16x3(frag)
     return np.ascontiguousarray(np.stack(p, 2))                           # [kb, mt, 3, 64, 8]
 
 
-def unpack_s3_gemm(packed, ntaps, c0, c1, M):
+def unpack_s3_gemm(packed, ntaps, c0, c1, M, npl=3):
     K = ntaps * (c0 + c1)
     mt = (M + 31) // 32
-    packed = np.asarray(packed, np.uint16).reshape(K // 16, mt, 3, 2, 32, 8)      # [kb, mt, plane, h, row, j]
-    f = join_bf16x3([packed[:, :, i] for i in range(3)])                          # [kb, mt, h, row, j]
+    packed = np.asarray(packed, np.uint16).reshape(K // 16, mt, npl, 2, 32, 8)    # [kb, mt, plane, h, row, j]
+    f = join_bf16x3([packed[:, :, i] for i in range(3)]) if npl == 3 else bf16_to_f32(packed[:, :, 0])   # [kb, mt, h, row, j]
     ordered = f.transpose(0, 2, 4, 1, 3).reshape(K, mt * 32)                       # k within block = 8h + j
     out = np.zeros((K, mt * 32), np.float32)
     out[s3_gemm_krows(ntaps, c0, c1)] = ordered

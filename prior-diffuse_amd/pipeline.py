@@ -43,7 +43,9 @@ class SamplerPipeline:
         dtype: "f32" (default: fp32 or fp32-equivalent split-bf16 arithmetic, see split_bf16) or "bf16" - the OPT-IN reduced
         precision mode of BASELINE configs 2/4/5: the eps-net's BiConv(Trans)GLU and TCM blocks multiply plain bf16 operands
         (one MFMA product, fp32 accumulate) and exchange their conv1 / bottleneck tensors as bf16 (csrc/bglu.hip, csrc/tcm2.hip,
-        one plane); the diffusion state, the skip halves, the residual stream of the TCM stack and the prior stay as in "f32".  Its tolerance is its own (stated in
+        one plane); round 4: the priors' GEMM-shaped convolutions (GCRN's gated convolutions and LSTM projection, DB-AIAT's
+        dense blocks) multiply plain bf16 operands as well (csrc/gconv4.hip, korder 4); the diffusion state, the skip halves,
+        the residual stream of the TCM stack, the recurrences and every tensor of the priors stay fp32.  Its tolerance is its own (stated in
         tests/test_gpu_round2.py::test_bf16_mode_tolerance), it is never the default and never the graded bench line.
         bank: a ``nets.WeightBank`` shared with other pipelines built from the same state_dicts (packed weights are
         uploaded once, every further (B, T) only records descriptors).
@@ -90,14 +92,16 @@ class SamplerPipeline:
             return pb
 
         self.stft = adopt(nets.StftPlan(ctx, B, L_, plan=self.plan, split_bf16=split_bf16)) if with_signal else None
+        pplanes = 1 if dtype == "bf16" else None     # bf16 mode: the priors' GEMM-shaped convolutions on plain bf16 operands too (korder 4)
         if prior_name == "GCRN":
-            self.prior = adopt(nets.GcrnPlan(ctx, prior_sd, B, T, plan=self.plan, split_bf16=split_bf16, exclusive=exclusive))
+            self.prior = adopt(nets.GcrnPlan(ctx, prior_sd, B, T, plan=self.plan, split_bf16=split_bf16 or dtype == "bf16", exclusive=exclusive,
+                                             planes=pplanes))
         elif prior_name == "DiffUNet":
             self.prior = adopt(nets.EpsNetPlan(ctx, prior_sd, B, T, time_cond=False, plan=self.plan, split_bf16=split_bf16, exclusive=exclusive))
         elif prior_name == "aia_complex_trans_ri":
-            self.prior = adopt(nets.AiaPlan(ctx, prior_sd, B, T, plan=self.plan, split_bf16=split_bf16))
+            self.prior = adopt(nets.AiaPlan(ctx, prior_sd, B, T, plan=self.plan, split_bf16=split_bf16 or dtype == "bf16", planes=pplanes))
         elif prior_name == "dual_aia_trans_merge_crm":
-            self.prior = adopt(nets.DualAiaPlan(ctx, prior_sd, B, T, plan=self.plan, split_bf16=split_bf16))
+            self.prior = adopt(nets.DualAiaPlan(ctx, prior_sd, B, T, plan=self.plan, split_bf16=split_bf16 or dtype == "bf16", planes=pplanes))
         else:
             raise ValueError("prior %r not built (GCRN, DiffUNet, aia_complex_trans_ri, dual_aia_trans_merge_crm)" % prior_name)
         if dtype == "bf16":

@@ -89,12 +89,13 @@ def run_gconv(d, mem):
             out[rows[rows >= 0]] = wk[rows >= 0]
             assert np.all(wk[rows < 0] == 0)
             return out
-    elif d.korder == 3:   # split-bf16 GEMM-shaped convolution (csrc/gconv4.hip): weights streamed through LDS
+    elif d.korder in (3, 4):   # split-bf16 (3) / plain bf16 (4) GEMM-shaped convolution (csrc/gconv4.hip): weights streamed through LDS
         assert d.epi in (L.EPI_LINEAR, L.EPI_GLU) and not d.cin1 and d.xf_mode == 0
 
         def unpack(ptr):
-            n = d.ntaps * Cin // 16 * mtiles * 3 * 64 * 8
-            wk = P.unpack_s3_gemm(mem.arr(ptr, n, np.int16).view(np.uint16), d.ntaps, d.in0.C, d.in1.C, mtiles * 32)
+            npl = 3 if d.korder == 3 else 1
+            n = d.ntaps * Cin // 16 * mtiles * npl * 64 * 8
+            wk = P.unpack_s3_gemm(mem.arr(ptr, n, np.int16).view(np.uint16), d.ntaps, d.in0.C, d.in1.C, mtiles * 32, npl)
             return wk
     elif d.korder == 2:   # split-bf16 BIGLU block (csrc/gconv3.hip): exact 3-way bf16 splits in bf16 MFMA fragment order
         assert d.epi == L.EPI_BIGLU and Cin in (32, 4) and d.Cout == 32
@@ -144,7 +145,7 @@ def run_gconv(d, mem):
             flat, off = mem.view(S.ptr)
             cI = np.arange(S.C)[None, :, None, None]
             if S.blk:   # channel-blocked source (pdse_src.blk = 8, korder 3 only)
-                assert S.blk == 8 and d.korder == 3, "blocked sources are read by the korder 3 kernel only"
+                assert S.blk == 8 and d.korder in (3, 4), "blocked sources are read by the korder 3 / 4 kernel only"
                 idx = off + bI * S.sb + (cI >> 3) * S.sc + (cI & 7) + tin * S.st + fin * S.sf
             else:
                 idx = off + bI * S.sb + cI * S.sc + tin * S.st + fin * S.sf
@@ -152,6 +153,8 @@ def run_gconv(d, mem):
             v = flat[np.broadcast_to(idx, (B, S.C, To, Fo))]
             v = _act(v, S.act)
             v = np.where(inb, v, 0.0).astype(np.float32)
+            if d.korder == 4:            # one plane: the gathered activation is rounded to bf16 (after the load-side ELU)
+                v = _bf16_round(v).astype(np.float32)
             if d.padrow:
                 pv = pad_flat[pad_off + bI * d.padrow_sb + cbase + cI]
                 v = np.where(np.broadcast_to(isp, v.shape), np.broadcast_to(pv, v.shape), v)

@@ -557,8 +557,8 @@ def test_bf16_mode_tolerance(L, weights):
     spec, init = pipe.sample(feat.to(DEV), x_T.to(DEV))
     ref, exact, ref_init = full_pair("full_gcrn_seed1234_t401_6step")
     e_init, e_spec = rel_l2(init[0].cpu(), ref_init[0]), rel_l2(spec[0].cpu(), ref[0])
-    print("bf16 mode: eps-net forward vs golden %.2e | 6-step spectrogram vs the reference %.2e (prior, unchanged: %.2e)" % (e_net, e_spec, e_init))
-    assert e_init < 2e-5                   # the prior is not part of the bf16 mode
+    print("bf16 mode: eps-net forward vs golden %.2e | 6-step spectrogram vs the reference %.2e | prior (one-plane GEMM convolutions) %.2e" % (e_net, e_spec, e_init))
+    assert 2e-5 < e_init < 1e-2            # round 4: the prior's GEMM-shaped convolutions are in the mode as well (korder 4): its own bound
     assert e_net < 3e-2 and e_spec < 3e-2
     assert e_spec > 1e-4                   # and it is NOT fp32-equivalent: the mode must stay opt-in
     with pytest.raises(ValueError):

@@ -220,3 +220,24 @@ def test_eps_net_plan_bf16_mode_vs_oracle(weights):
     assert 1e-4 < e < 3e-2, e
     with pytest.raises(ValueError):
         nets.EpsNetPlan(nets.Ctx("cpu"), weights("Nocon"), B, T, time_cond=True, nsteps=1, with_pre=False, planes=1)
+
+
+def test_priors_one_plane_gemm_mode_vs_oracle(weights):
+    """The bf16 mode of the priors (round 4): the GEMM-shaped convolutions packed as ONE bf16 plane (korder 4, packing.pack_s3_gemm
+    with npl = 1), replayed on the interpreter with both operands rounded to bf16: within the mode's prior tolerance of the fp32
+    oracle, and not fp32-equivalent."""
+    nets = pkg("nets")
+    B, T = 2, 10
+    x = seeded((B, 2, T, 161), 5)
+    ctx = nets.Ctx("cpu")
+    net = nets.GcrnPlan(ctx, weights("GCRN"), B, T, planes=1)
+    net.build()
+    assert sum(1 for d, _ in net.descs if isinstance(d, pkg("_lib").GconvDesc) and d.korder == 4) == 22      # every korder-3 launch of the exact form
+    net.x.copy_(x)
+    emu.run(net.descs, ctx.all_tensors())
+    with torch.no_grad():
+        ref = R.gcrn_forward(weights("GCRN"), x)
+    e = rel_l2(net.out, ref)
+    assert 1e-4 < e < 1e-2, e
+    with pytest.raises(ValueError):
+        nets.GcrnPlan(nets.Ctx("cpu"), weights("GCRN"), B, T, planes=2)
