@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define PDSE_ABI_VERSION 6
+#define PDSE_ABI_VERSION 7
 
 typedef void* pdse_stream_t; /* hipStream_t */
 
@@ -386,6 +386,45 @@ typedef struct pdse_rowln_desc {
   int32_t pad_;
 } pdse_rowln_desc;
 
+/* One layer of the dilated dense block (dbaiat.py:605-631) on the channel-blocked concatenation buffer (ABI 7, csrc/dense.hip):
+ *   D[:, g_out .. g_out+8) = prelu(ln_F(conv_{(2,3), dilation (dil,1)}(pad(D[:, g_in .. g_in + cin/8))) + bias))
+ * D: [B][G][T + tpad][F + 2][8] fp32 - entry (b, g, t, f) holds channels 8g .. 8g+7 of bin f of frame t at
+ * (((b G + g)(T + tpad) + tpad + t)(F + 2) + f + 1) 8; the tpad leading rows and the two outer bins of every row are zero and stay
+ * zero (the convolution's causal / same padding).  w: bf16 fragments of the 64 x 6 cin weights, K steps in the order (16-channel
+ * block, time tap, bin tap): [cin/16][2][3][2 channel tiles][np planes][64 lanes][8] (packing.pack_dense); np = 3: exact
+ * three-way split of both operands (six products, fp32-equivalent), np = 1: plain bf16 (the opt-in bf16 mode).
+ * Replaces pdse_gconv_f32 + pdse_rowln_prelu_f32 of one layer; input and output groups must not overlap. */
+typedef struct pdse_dense_desc {
+  float* D;
+  const void* w;
+  const float* bias;  /* [64] */
+  const float* gamma; /* [F] */
+  const float* beta;  /* [F] */
+  const float* slope; /* [64] */
+  int32_t B, T, F, G, tpad;
+  int32_t g_in, cin; /* first input group, input channels (a multiple of 16) */
+  int32_t g_out;
+  int32_t dil, np;
+  float eps;
+  int32_t pad_;
+} pdse_dense_desc;
+
+/* Row LayerNorm + PReLU like pdse_rowln_desc - or, with gamma == NULL, a plain re-layout - from a channel-major tensor (rows of F
+ * contiguous floats at in + b in_sb + c in_sc + t in_st) into channel-blocked entries of 8 channels:
+ * out + b out_sb + (c / 8) out_sg + t out_st + 8 f + c % 8 (the layout of pdse_dense_desc.D; `out` points at frame 0, bin 0). */
+typedef struct pdse_rowlnb_desc {
+  const float* in;
+  const float* gamma; /* [F] or NULL */
+  const float* beta;
+  const float* slope; /* [C] */
+  float* out;
+  int64_t in_sb, in_sc, in_st;
+  int64_t out_sb, out_sg, out_st;
+  int32_t B, C, T, F;
+  float eps;
+  int32_t pad_;
+} pdse_rowlnb_desc;
+
 /* LayerNorm over the C channels at every (b,t,f) (nn.LayerNorm(d_model) on [S,N,32], dbaiat.py:76,81,87) */
 typedef struct pdse_chln_desc {
   const float* in;
@@ -708,7 +747,9 @@ enum pdse_op_kind {
   PDSE_OP_BGLU = 23,
   PDSE_OP_PLANES = 24,
   PDSE_OP_GLSTMP = 25,
-  PDSE_OP_TCM2S = 26
+  PDSE_OP_TCM2S = 26,
+  PDSE_OP_DENSE = 27,
+  PDSE_OP_ROWLNB = 28
 };
 
 int pdse_abi_version(void);
@@ -744,6 +785,8 @@ int pdse_tcm2_bf16x3(const pdse_tcm2_desc* d, pdse_stream_t s);
 int pdse_tcm2_stack_bf16x3(const pdse_tcm2s_desc* d, pdse_stream_t s);
 int pdse_bglu_planes(const pdse_bglu_desc* d, pdse_stream_t s);
 int pdse_split_planes(const pdse_planes_desc* d, pdse_stream_t s);
+int pdse_dense_layer_bf16x3(const pdse_dense_desc* d, pdse_stream_t s);
+int pdse_rowln_blocked_f32(const pdse_rowlnb_desc* d, pdse_stream_t s);
 /* Kernel form of pdse_bglu_planes (ABI 6; process-wide, tuning only): -1 / 0 = 8 waves with the generated slot schedule
  * (the product kernel).  A library built with -DBGLU_FORMS also holds the forms that were measured and not kept
  * (profiles/r03_bglu_forms.txt, r04_bglu_forms.txt): 1 = 4 waves software-pipelined, 2 / 3 = 16 / 12 waves with strictly

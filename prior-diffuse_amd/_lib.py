@@ -9,14 +9,14 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PDSE_LIB") or os.path.join(_HERE, "libpdse.so")   # PDSE_LIB: diagnostic builds only
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 ACT_NONE, ACT_PRELU, ACT_ELU, ACT_SIGMOID = 0, 1, 2, 3
 EPI_LINEAR, EPI_GLU, EPI_BIGLU = 0, 1, 2
 EW_DIV, EW_UPDATE, EW_UPDATE_FINAL, EW_COPY, EW_ADD_MUL = 0, 1, 2, 3, 4
 (OP_GCONV, OP_TIME, OP_EW, OP_COMPAND, OP_WAVPREP, OP_OLA, OP_SIGMA, OP_LN, OP_LSTM,
  OP_ROWLN, OP_CHLN, OP_ATTN, OP_GRU, OP_GNCOMB, OP_AHAM, OP_QSAMPLE, OP_TRANSPOSE, OP_TCM, OP_CRM, OP_GCRNLAST,
- OP_MASKLOSS, OP_GLSTM, OP_TCM2, OP_BGLU, OP_PLANES, OP_GLSTMP, OP_TCM2S) = range(27)
+ OP_MASKLOSS, OP_GLSTM, OP_TCM2, OP_BGLU, OP_PLANES, OP_GLSTMP, OP_TCM2S, OP_DENSE, OP_ROWLNB) = range(29)
 MASKLOSS_BLOCKS = 32
 
 _fp = C.c_void_p  # device pointers travel as integers
@@ -112,6 +112,18 @@ class GlstmpDesc(C.Structure):
 
 class RowlnDesc(C.Structure):
     _fields_ = [("in_", _fp), ("gamma", _fp), ("beta", _fp), ("slope", _fp), ("out", _fp), ("out_sb", _i64),
+                ("B", _i32), ("C", _i32), ("T", _i32), ("F", _i32), ("eps", _f32), ("pad_", _i32)]
+
+
+class DenseDesc(C.Structure):
+    _fields_ = [("D", _fp), ("w", _fp), ("bias", _fp), ("gamma", _fp), ("beta", _fp), ("slope", _fp),
+                ("B", _i32), ("T", _i32), ("F", _i32), ("G", _i32), ("tpad", _i32), ("g_in", _i32), ("cin", _i32), ("g_out", _i32),
+                ("dil", _i32), ("np", _i32), ("eps", _f32), ("pad_", _i32)]
+
+
+class RowlnbDesc(C.Structure):
+    _fields_ = [("in_", _fp), ("gamma", _fp), ("beta", _fp), ("slope", _fp), ("out", _fp),
+                ("in_sb", _i64), ("in_sc", _i64), ("in_st", _i64), ("out_sb", _i64), ("out_sg", _i64), ("out_st", _i64),
                 ("B", _i32), ("C", _i32), ("T", _i32), ("F", _i32), ("eps", _f32), ("pad_", _i32)]
 
 
@@ -211,7 +223,7 @@ class GcrnLastDesc(C.Structure):
                 ("fcp", _fp)]
 
 
-DESC_TYPES = {OP_TCM2S: Tcm2sDesc, OP_GLSTMP: GlstmpDesc, OP_BGLU: BgluDesc, OP_PLANES: PlanesDesc, OP_TCM2: Tcm2Desc, OP_GLSTM: GlstmDesc, OP_MASKLOSS: MasklossDesc, OP_GCRNLAST: GcrnLastDesc, OP_CRM: CrmDesc, OP_TCM: TcmDesc, OP_TRANSPOSE: TransposeDesc, OP_QSAMPLE: QsampleDesc, OP_ROWLN: RowlnDesc, OP_CHLN: ChlnDesc, OP_ATTN: AttnDesc, OP_GRU: GruDesc, OP_GNCOMB: GncombDesc,
+DESC_TYPES = {OP_DENSE: DenseDesc, OP_ROWLNB: RowlnbDesc, OP_TCM2S: Tcm2sDesc, OP_GLSTMP: GlstmpDesc, OP_BGLU: BgluDesc, OP_PLANES: PlanesDesc, OP_TCM2: Tcm2Desc, OP_GLSTM: GlstmDesc, OP_MASKLOSS: MasklossDesc, OP_GCRNLAST: GcrnLastDesc, OP_CRM: CrmDesc, OP_TCM: TcmDesc, OP_TRANSPOSE: TransposeDesc, OP_QSAMPLE: QsampleDesc, OP_ROWLN: RowlnDesc, OP_CHLN: ChlnDesc, OP_ATTN: AttnDesc, OP_GRU: GruDesc, OP_GNCOMB: GncombDesc,
               OP_AHAM: AhamDesc, OP_GCONV: GconvDesc, OP_TIME: TimeDesc, OP_EW: EwDesc, OP_COMPAND: CompandDesc,
               OP_WAVPREP: WavprepDesc, OP_OLA: OlaDesc, OP_SIGMA: SigmaDesc, OP_LN: LnDesc,
               OP_LSTM: LstmDesc}
@@ -223,7 +235,7 @@ EXPORTS = [
     "pdse_ola_f32", "pdse_sigma_mask_f32", "pdse_layernorm_f32", "pdse_lstm_f32",
     "pdse_rowln_prelu_f32", "pdse_chln_f32", "pdse_attention_f32", "pdse_bigru_f32", "pdse_gn_combine_f32",
     "pdse_aham_f32", "pdse_qsample_f32", "pdse_transpose_f32", "pdse_tcm_f32", "pdse_crm_f32", "pdse_gcrnlast_f32",
-    "pdse_masked_mse_f32", "pdse_glstm_f32", "pdse_glstm_persistent_f32", "pdse_tcm2_bf16x3", "pdse_tcm2_stack_bf16x3", "pdse_bglu_planes", "pdse_split_planes", "pdse_bglu_set_form",
+    "pdse_masked_mse_f32", "pdse_glstm_f32", "pdse_glstm_persistent_f32", "pdse_tcm2_bf16x3", "pdse_tcm2_stack_bf16x3", "pdse_bglu_planes", "pdse_split_planes", "pdse_dense_layer_bf16x3", "pdse_rowln_blocked_f32", "pdse_bglu_set_form",
     "pdse_plan_create", "pdse_plan_add", "pdse_plan_size", "pdse_plan_set_device", "pdse_plan_clear", "pdse_plan_run",
     "pdse_plan_run_range",
     "pdse_plan_build_graph", "pdse_plan_launch_graph", "pdse_plan_time_ops", "pdse_plan_time_tag",
@@ -237,7 +249,8 @@ _DIRECT = {OP_GCONV: "pdse_gconv_f32", OP_TIME: "pdse_time_embed_f32", OP_EW: "p
            OP_GRU: "pdse_bigru_f32", OP_GNCOMB: "pdse_gn_combine_f32", OP_AHAM: "pdse_aham_f32",
            OP_QSAMPLE: "pdse_qsample_f32", OP_TRANSPOSE: "pdse_transpose_f32", OP_TCM: "pdse_tcm_f32", OP_CRM: "pdse_crm_f32", OP_GCRNLAST: "pdse_gcrnlast_f32",
            OP_MASKLOSS: "pdse_masked_mse_f32", OP_GLSTM: "pdse_glstm_f32", OP_GLSTMP: "pdse_glstm_persistent_f32",
-           OP_TCM2: "pdse_tcm2_bf16x3", OP_TCM2S: "pdse_tcm2_stack_bf16x3", OP_BGLU: "pdse_bglu_planes", OP_PLANES: "pdse_split_planes"}
+           OP_TCM2: "pdse_tcm2_bf16x3", OP_TCM2S: "pdse_tcm2_stack_bf16x3", OP_BGLU: "pdse_bglu_planes", OP_PLANES: "pdse_split_planes",
+           OP_DENSE: "pdse_dense_layer_bf16x3", OP_ROWLNB: "pdse_rowln_blocked_f32"}
 
 
 class PdseError(RuntimeError):

@@ -54,6 +54,8 @@ union pdse_any_desc {
   pdse_tcm_desc tcm;
   pdse_tcm2_desc tcm2;
   pdse_tcm2s_desc tcm2s;
+  pdse_dense_desc dense;
+  pdse_rowlnb_desc rowlnb;
   pdse_crm_desc crm;
   pdse_gcrnlast_desc gcrnlast;
   pdse_maskloss_desc maskloss;
@@ -123,6 +125,8 @@ static int op_size(int kind) {
     case PDSE_OP_TCM: return (int)sizeof(pdse_tcm_desc);
     case PDSE_OP_TCM2: return (int)sizeof(pdse_tcm2_desc);
     case PDSE_OP_TCM2S: return (int)sizeof(pdse_tcm2s_desc);
+    case PDSE_OP_DENSE: return (int)sizeof(pdse_dense_desc);
+    case PDSE_OP_ROWLNB: return (int)sizeof(pdse_rowlnb_desc);
     case PDSE_OP_CRM: return (int)sizeof(pdse_crm_desc);
     case PDSE_OP_GCRNLAST: return (int)sizeof(pdse_gcrnlast_desc);
     case PDSE_OP_MASKLOSS: return (int)sizeof(pdse_maskloss_desc);
@@ -161,6 +165,8 @@ static int launch_op(const pdse_op& op, hipStream_t s) {
     case PDSE_OP_GLSTMP: return pdse_glstmp_launch(&op.d.glstmp, s);
     case PDSE_OP_TCM2: return pdse_tcm2_launch(&op.d.tcm2, s);
     case PDSE_OP_TCM2S: return pdse_tcm2s_launch(&op.d.tcm2s, s);
+    case PDSE_OP_DENSE: return pdse_dense_launch(&op.d.dense, s);
+    case PDSE_OP_ROWLNB: return pdse_rowlnb_launch(&op.d.rowlnb, s);
     case PDSE_OP_BGLU: return pdse_bglu_launch(&op.d.bglu, s);
     case PDSE_OP_PLANES: return pdse_planes_launch(&op.d.planes, s);
     default: pdse_set_error("plan: unknown op kind"); return 1;
@@ -198,6 +204,8 @@ int pdse_glstm_f32(const pdse_glstm_desc* d, pdse_stream_t s) { return pdse_glst
 int pdse_glstm_persistent_f32(const pdse_glstmp_desc* d, pdse_stream_t s) { return pdse_glstmp_launch(d, (hipStream_t)s); }
 int pdse_tcm2_bf16x3(const pdse_tcm2_desc* d, pdse_stream_t s) { return pdse_tcm2_launch(d, (hipStream_t)s); }
 int pdse_tcm2_stack_bf16x3(const pdse_tcm2s_desc* d, pdse_stream_t s) { return pdse_tcm2s_launch(d, (hipStream_t)s); }
+int pdse_dense_layer_bf16x3(const pdse_dense_desc* d, pdse_stream_t s) { return pdse_dense_launch(d, (hipStream_t)s); }
+int pdse_rowln_blocked_f32(const pdse_rowlnb_desc* d, pdse_stream_t s) { return pdse_rowlnb_launch(d, (hipStream_t)s); }
 int pdse_bglu_planes(const pdse_bglu_desc* d, pdse_stream_t s) { return pdse_bglu_launch(d, (hipStream_t)s); }
 int pdse_split_planes(const pdse_planes_desc* d, pdse_stream_t s) { return pdse_planes_launch(d, (hipStream_t)s); }
 

@@ -52,5 +52,7 @@ int pdse_tcm2_launch(const pdse_tcm2_desc* d, hipStream_t s);
 int pdse_tcm2s_launch(const pdse_tcm2s_desc* d, hipStream_t s);   /* csrc/tcm2.hip: the whole stack as one launch */
 int pdse_bglu_launch(const pdse_bglu_desc* d, hipStream_t s);
 int pdse_planes_launch(const pdse_planes_desc* d, hipStream_t s);
+int pdse_dense_launch(const pdse_dense_desc* d, hipStream_t s);     /* csrc/dense.hip */
+int pdse_rowlnb_launch(const pdse_rowlnb_desc* d, hipStream_t s);
 int pdse_gru3_launch(const pdse_gru_desc* d, hipStream_t s);   /* csrc/gru3.hip, reached through pdse_gru_launch */
 #endif

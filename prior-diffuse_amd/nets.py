@@ -1521,6 +1521,8 @@ class AiaPlan(PlanBase):
     fused_gru_input = True   # d_model 32: W_ih x inside the GRU kernel (csrc/aia.hip, gru_kernel<64, true>)
     split_gru = True         # (with split_bf16 and the fused form) that recurrence on split-bf16 operands (csrc/gru3.hip)
     split_bf16 = True        # dilated dense blocks and the strided / sub-pixel convolutions as split-bf16 GEMMs (csrc/gconv4.hip)
+    dense_fused = True       # (with split_bf16) a dense-block layer = ONE launch on a channel-blocked buffer (csrc/dense.hip)
+    TPAD, G = 8, 40          # leading zero frames (the largest dilation) and 8-channel groups of the dense buffers
 
     def __init__(self, ctx, sd, B, T, plan=None, d=32, split_bf16=None, planes=None):
         """d: d_model of the transformer layers (32: AIA_Transformer(64, 64); 64: AIA_Transformer_merge(128, 64))."""
@@ -1530,7 +1532,9 @@ class AiaPlan(PlanBase):
             if planes not in (1, 3) or (planes == 1 and not self.split_bf16):
                 raise ValueError("planes is 3 or 1; the one-plane bf16 mode runs on the GEMM kernels (split_bf16)")
             self.gemm_planes = int(planes)
-        super().__init__(ctx, plan, ns=(ctx.bank.token(sd), d, self.fused_gru_input, self.split_bf16, self.split_gru, self.gemm_planes))
+        self.fused = bool(self.dense_fused and self.split_bf16)
+        super().__init__(ctx, plan, ns=(ctx.bank.token(sd), d, self.fused_gru_input, self.split_bf16, self.split_gru, self.gemm_planes,
+                                        self.fused))
         self.sd, self.B, self.T, self.d = sd, B, T, d
         a = ctx.alloc
         FH = self.FH
@@ -1538,8 +1542,15 @@ class AiaPlan(PlanBase):
         self.out = a(B, 2, T, F0)
         self.tmp161 = a(B, 64, T, F0)
         self.tmp80 = a(B, 64, T, FH)
-        self.D161 = a(B, 320, T, F0)            # dense buffer [out4,out3,out2,out1,x]
-        self.D80 = a(B, 320, T, FH)
+        if self.fused:
+            # dense buffers [out4,out3,out2,out1,x] in blocks of 8 channels, [B][40][T + 8][F + 2][8]: the leading frames and the
+            # outer bins are the convolutions' zero padding (never written)
+            self.D161 = a(B, self.G, T + self.TPAD, F0 + 2, 8, zero=True)
+            self.D80 = a(B, self.G, T + self.TPAD, FH + 2, 8, zero=True)
+            self._d80_holds = None
+        else:
+            self.D161 = a(B, 320, T, F0)            # dense buffer [out4,out3,out2,out1,x]
+            self.D80 = a(B, 320, T, FH)
         self.x_ri = a(B, 64, T, FH)
         self.cur = a(B, d, T, FH)                # AIA state ("output" in dbaiat.py:138)
         self.nxt = a(B, d, T, FH)
@@ -1613,8 +1624,50 @@ class AiaPlan(PlanBase):
                    W=W, Cout=Cout, act=act, act_slope=act_slope, resid=resid, out=out_t,
                    out_strides=(Cout * plane, plane, 0, o_st, o_sf), B=B, Tout=F_, Fout=T, tag=TAG_PRIOR, label=label)
 
+    # ---- the channel-blocked dense buffers (csrc/dense.hip) ---------------------------------------
+    def _d_off(self, F_, g0):
+        """Float offset of entry (b 0, group g0, frame 0, bin 0) of a dense buffer with F_ bins."""
+        return ((g0 * (self.T + self.TPAD) + self.TPAD) * (F_ + 2) + 1) * 8
+
+    def _d_src(self, D, F_, g0, C_):
+        """C_ channels of a dense buffer from group g0 on as a channel-blocked convolution source (pdse_src.blk = 8)."""
+        Tp, Fp = self.T + self.TPAD, F_ + 2
+        return self.src(D, C_, self.G * Tp * Fp * 8, Tp * Fp * 8, Fp * 8, 8, off=self._d_off(F_, g0), blk=8)
+
+    def _to_dense(self, src, D, F_, g0, norm=None, prelu=None):
+        """[B,64,T,F_] channel-major -> groups g0..g0+7 of D, through LayerNorm(F_) + PReLU when ``norm`` is given."""
+        Tp, Fp = self.T + self.TPAD, F_ + 2
+        d = L.RowlnbDesc()
+        d.in_, d.out = src.data_ptr(), Ctx.ptr(D, self._d_off(F_, g0))
+        if norm is not None:
+            d.gamma, d.beta, d.slope = self._wp(norm + ".weight"), self._wp(norm + ".bias"), self._wp(prelu + ".weight")
+        d.in_sb, d.in_sc, d.in_st = 64 * self.T * F_, self.T * F_, F_
+        d.out_sb, d.out_sg, d.out_st = self.G * Tp * Fp * 8, Tp * Fp * 8, Fp * 8
+        d.B, d.C, d.T, d.F, d.eps = self.B, 64, self.T, F_, 1e-5
+        self.add(d, TAG_PRIOR)
+
+    def _dense_block_fused(self, p, D, F_):
+        """dbaiat.py:605-631, one launch per layer: convolution, LayerNorm over the bins and PReLU; x is in groups 32..39."""
+        kk = [(kt, kf) for kt in range(2) for kf in range(3)]
+        npl = self.gemm_planes
+        for i in range(1, 5):
+            cin = 64 * i
+            d = L.DenseDesc()
+            d.D = D.data_ptr()
+            d.w = self.upw("%s.conv%d.dense%d" % (p, i, npl), lambda i=i, cin=cin: P.pack_dense(
+                P.conv_kmat(self.sd["%s.conv%d.weight" % (p, i)], kk), cin, npl).view(np.int16), np.int16).data_ptr()
+            d.bias = self._wp("%s.conv%d.bias" % (p, i))
+            d.gamma, d.beta = self._wp("%s.norm%d.weight" % (p, i)), self._wp("%s.norm%d.bias" % (p, i))
+            d.slope = self._wp("%s.prelu%d.weight" % (p, i))
+            d.B, d.T, d.F, d.G, d.tpad = self.B, self.T, F_, self.G, self.TPAD
+            d.g_in, d.cin, d.g_out = (5 - i) * 8, cin, (4 - i) * 8
+            d.dil, d.np, d.eps = 2 ** (i - 1), npl, 1e-5
+            self.add(d, TAG_PRIOR)
+
     def _dense_block(self, p, D, F_, tmp):
         """dbaiat.py:605-631.  D [B,320,T,F_] holds [out4,out3,out2,out1,x]; x is already in block 4."""
+        if self.fused:
+            return self._dense_block_fused(p, D, F_)
         B, T = self.B, self.T
         for i in range(1, 5):
             dil = 2 ** (i - 1)
@@ -1722,10 +1775,14 @@ class AiaPlan(PlanBase):
         B, T, FH, sd = self.B, self.T, self.FH, self.sd
         self._pw(src_t, cin, lambda: dict(wk0=self.w(p + ".inp_conv.weight")[:, :, 0, 0].T, bias0=self.w(p + ".inp_conv.bias")),
                  self.tmp161, 64, F0, label=p + ".inp")
-        self._rowln(self.tmp161, self.D161, 320 * T * F0, 64, F0, p + ".inp_norm", p + ".inp_prelu", dst_off=256 * T * F0)
+        if self.fused:
+            self._to_dense(self.tmp161, self.D161, F0, 32, p + ".inp_norm", p + ".inp_prelu")
+        else:
+            self._rowln(self.tmp161, self.D161, 320 * T * F0, 64, F0, p + ".inp_norm", p + ".inp_prelu", dst_off=256 * T * F0)
         self._dense_block(p + ".enc_dense1", self.D161, F0, self.tmp161)
         kk, taps = P.conv_taps(1, 3, 0)
-        self.gconv(in0=self.src(self.D161, 64, *nchw(320, T, F0)), Tin=T, Fin=F0, taps=taps, sf_in=2,
+        out4 = self._d_src(self.D161, F0, 0, 64) if self.fused else self.src(self.D161, 64, *nchw(320, T, F0))
+        self.gconv(in0=out4, Tin=T, Fin=F0, taps=taps, sf_in=2,
                    W=lambda: dict(wk0=P.conv_kmat(sd[p + ".enc_conv1.weight"], kk), bias0=self.w(p + ".enc_conv1.bias")),
                    Cout=64, out=self.tmp80, out_strides=nchw_out(64, T, FH), B=B, Tout=T, Fout=FH, tag=TAG_PRIOR,
                    label=p + ".enc_conv1", s3g=self.split_bf16)
@@ -1746,16 +1803,22 @@ class AiaPlan(PlanBase):
         channel ``out_off // (T*161)`` of ``out`` [B,out_C,T,161].  (The masking decoder :551-584 is the same up to
         its scalar gate, which the CRM operator applies.)"""
         B, T, FH, sd = self.B, self.T, self.FH, self.sd
-        for b in range(B):                # merged -> channel block 4 of every batch item (one strided copy per item)
-            c = L.EwDesc()
-            c.a, c.out = Ctx.ptr(merged, b * 64 * T * FH), Ctx.ptr(self.D80, (b * 320 + 256) * T * FH)
-            c.n, c.op = 64 * T * FH, L.EW_COPY
-            self.add(c, TAG_EW)
+        if self.fused:
+            if self._d80_holds is not merged:     # the decoders of one merge share their input: re-laid out once (layers write groups 0..31)
+                self._to_dense(merged, self.D80, FH, 32)
+                self._d80_holds = merged
+        else:
+            for b in range(B):            # merged -> channel block 4 of every batch item (one strided copy per item)
+                c = L.EwDesc()
+                c.a, c.out = Ctx.ptr(merged, b * 64 * T * FH), Ctx.ptr(self.D80, (b * 320 + 256) * T * FH)
+                c.n, c.op = 64 * T * FH, L.EW_COPY
+                self.add(c, TAG_EW)
         self._dense_block(de + ".dec_dense1", self.D80, FH, self.tmp80)
         taps = [(0, kf - 1) for kf in range(3)]                   # pad (1,1) in bins
         kk = [(0, kf) for kf in range(3)]
         # co = r*64 + c  ->  channel c, bin 1 + 2w + r   (sub-pixel r = 2, then one zero bin on the left)
-        self.gconv(in0=self.src(self.D80, 64, *nchw(320, T, FH)), Tin=T, Fin=FH, taps=taps, sf_in=1,
+        out4 = self._d_src(self.D80, FH, 0, 64) if self.fused else self.src(self.D80, 64, *nchw(320, T, FH))
+        self.gconv(in0=out4, Tin=T, Fin=FH, taps=taps, sf_in=1,
                    W=lambda: dict(wk0=P.conv_kmat(sd[de + ".dec_conv1.conv.weight"], kk), bias0=self.w(de + ".dec_conv1.conv.bias")),
                    Cout=128, out=self.dec_up, out_strides=(64 * T * F0, 1, T * F0, F0, 2), out_cr=64, out_off=1, B=B, Tout=T,
                    Fout=FH, tag=TAG_PRIOR, label=de + ".dec_conv1", s3g=self.split_bf16)

@@ -424,6 +424,17 @@ def s3_gemm_krows(ntaps, c0, c1):
     return np.asarray(rows, np.int64)
 
 
+def _pack_gemm_rows(ordered, npl):
+    """ordered [nkb*16, mt*32] (K rows already in K-step order) -> uint16 [nkb][mt][npl][64 lanes][8]."""
+    nkb, mt = ordered.shape[0] // 16, ordered.shape[1] // 32
+    frag = ordered.reshape(nkb, 2, 8, mt, 32).transpose(0, 3, 1, 4, 2)    # [kb, mt, h, row, j]
+    frag = frag.reshape(nkb, mt, 64, 8)
+    if npl == 1:
+        return np.ascontiguousarray(bf16_rne(frag)[:, :, None])           # [kb, mt, 1, 64, 8]
+    p = split_bf16x3(frag)
+    return np.ascontiguousarray(np.stack(p, 2))                           # [kb, mt, 3, 64, 8]
+
+
 def pack_s3_gemm(wk, ntaps, c0, c1, npl=3):
     """wk [ntaps*(c0+c1), Cout] (k-major) -> uint16 [K blocks][ceil(Cout/32)][npl planes][64 lanes][8]
     (npl 3: exact three-way bf16 split, korder 3; 1: the RNE bf16 value, korder 4 - the opt-in bf16 mode)."""
@@ -433,14 +444,25 @@ def pack_s3_gemm(wk, ntaps, c0, c1, npl=3):
     mt = (M + 31) // 32
     pad = np.zeros((K, mt * 32), np.float32)
     pad[:, :M] = wk
-    ordered = pad[s3_gemm_krows(ntaps, c0, c1)]                           # [nkb*16, mt*32]
-    nkb = K // 16
-    frag = ordered.reshape(nkb, 2, 8, mt, 32).transpose(0, 3, 1, 4, 2)    # [kb, mt, h, row, j]
-    frag = frag.reshape(nkb, mt, 64, 8)
-    if npl == 1:
-        return np.ascontiguousarray(bf16_rne(frag)[:, :, None])           # [kb, mt, 1, 64, 8]
-    p = split_bf16x3(frag)
-    return np.ascontiguousarray(np.stack(p, 2))                           # [kb, mt, 3, 64, 8]
+    return _pack_gemm_rows(pad[s3_gemm_krows(ntaps, c0, c1)], npl)
+
+
+def dense_krows(cin):
+    """K-step order of csrc/dense.hip for the (2,3) kernel of a dense-block layer: (16-channel block, time tap kt, bin tap kf);
+    rows index the k-major matrix of conv_kmat with taps [(kt, kf) for kt in 0..1 for kf in 0..2]."""
+    rows = []
+    for kb in range(cin // 16):
+        for kt in range(2):
+            for kf in range(3):
+                rows.extend((kt * 3 + kf) * cin + 16 * kb + np.arange(16))
+    return np.asarray(rows, np.int64)
+
+
+def pack_dense(wk, cin, npl=3):
+    """wk [6*cin, 64] (k-major, conv_kmat order) -> uint16 [cin/16 * 6 K steps][2][npl][64][8] (pdse_dense_desc.w)."""
+    wk = np.asarray(wk, np.float64).astype(np.float32)
+    assert wk.shape == (6 * cin, 64) and cin % 16 == 0
+    return _pack_gemm_rows(wk[dense_krows(cin)], npl)
 
 
 def unpack_s3_gemm(packed, ntaps, c0, c1, M, npl=3):

@@ -273,3 +273,95 @@ def test_bf16_mode_of_the_priors_one_plane_gemm_convolutions(L, weights, prior):
         err[planes] = rel_l2(net.out.cpu(), g["out"])
     print("%s: exact split %.2e | one bf16 plane %.2e" % (prior, err[3], err[1]))
     assert err[3] < 5e-5 and 1e-4 < err[1] < 2e-2
+
+
+# ---- DB-AIAT dense-block layers as one launch each (csrc/dense.hip; reference model/dbaiat.py:605-631) ------------------------
+def _dense_block_reference(x, ws, bs, gs, bes, sls):
+    """fp64 restatement of DenseBlock.forward for depth 4 (pad (1,1,dil,0) -> conv (2,3) dilation (dil,1) -> LayerNorm(F) -> PReLU)."""
+    F_ = x.shape[-1]
+    skip, outs = x, []
+    for i in range(4):
+        dil = 2 ** i
+        out = torch.nn.functional.pad(skip, (1, 1, dil, 0))
+        out = torch.nn.functional.conv2d(out, ws[i], bs[i], dilation=(dil, 1))
+        out = torch.nn.functional.layer_norm(out, (F_,), gs[i], bes[i], 1e-5)
+        out = torch.where(out > 0, out, sls[i].view(1, -1, 1, 1) * out)
+        outs.append(out)
+        skip = torch.cat([out, skip], 1)
+    return outs
+
+
+@pytest.mark.parametrize("B,T,F_,npl", [(2, 21, 161, 3), (3, 50, 80, 3), (1, 7, 161, 3), (2, 37, 80, 1), (1, 30, 36, 3)])
+def test_dense_layers_and_relayout_vs_fp64(L, B, T, F_, npl):
+    """pdse_rowln_blocked_f32 (copy and LayerNorm + PReLU forms) and four pdse_dense_layer_bf16x3 launches - every dilation, frame
+    counts that are no multiple of the row block, rows cut by tile boundaries, both bin widths of the model and the smallest
+    the kernel takes - against an fp64 restatement of the reference's DenseBlock.  Pads of the buffer must still be zero."""
+    P = pkg("packing")
+    gen = torch.Generator().manual_seed(B * 1000 + T * 10 + F_)
+    rnd = lambda *s: torch.randn(*s, generator=gen, dtype=torch.float64)   # noqa: E731
+    x = rnd(B, 64, T, F_)
+    ws = [rnd(64, 64 * (i + 1), 2, 3) / np.sqrt(6 * 64 * (i + 1)) for i in range(4)]
+    bs = [0.1 * rnd(64) for _ in range(4)]
+    gs = [1 + 0.1 * rnd(F_) for _ in range(4)]
+    bes = [0.1 * rnd(F_) for _ in range(4)]
+    sls = [0.25 + 0.05 * rnd(64) for _ in range(4)]
+    # the block's input: LayerNorm + PReLU of a raw tensor (the encoder's inp_norm / inp_prelu), fp64
+    g0, b0, s0 = 1 + 0.1 * rnd(F_), 0.1 * rnd(F_), 0.25 + 0.05 * rnd(64)
+    xin = torch.nn.functional.layer_norm(x, (F_,), g0, b0, 1e-5)
+    xin = torch.where(xin > 0, xin, s0.view(1, -1, 1, 1) * xin)
+    want = _dense_block_reference(xin, ws, bs, gs, bes, sls)
+
+    G, TP = 40, 8
+    Tp, Fp = T + TP, F_ + 2
+    dev = lambda a: a.to(torch.float32).contiguous().to(DEV)   # noqa: E731
+    D = torch.zeros(B, G, Tp, Fp, 8, device=DEV)
+    off = lambda g: ((g * Tp + TP) * Fp + 1) * 8               # noqa: E731
+    xd = dev(x)
+    keep = [xd]
+    r = L.RowlnbDesc()
+    r.in_, r.out = xd.data_ptr(), D.data_ptr() + 4 * off(32)
+    for name, t in (("gamma", g0), ("beta", b0), ("slope", s0)):
+        keep.append(dev(t))
+        setattr(r, name, keep[-1].data_ptr())
+    r.in_sb, r.in_sc, r.in_st = 64 * T * F_, T * F_, F_
+    r.out_sb, r.out_sg, r.out_st = G * Tp * Fp * 8, Tp * Fp * 8, Fp * 8
+    r.B, r.C, r.T, r.F, r.eps = B, 64, T, F_, 1e-5
+    st = torch.cuda.current_stream().cuda_stream
+    L.launch(r, st)
+
+    def groups(g, n):   # [B, 8n, T, F] view of groups g..g+n
+        return D[:, g:g + n, TP:, 1:F_ + 1].permute(0, 1, 4, 2, 3).reshape(B, 8 * n, T, F_)
+
+    torch.cuda.synchronize()
+    assert rel_l2(groups(32, 8).cpu(), xin) < 1e-6
+    kk = [(kt, kf) for kt in range(2) for kf in range(3)]
+    for i in range(1, 5):
+        d = L.DenseDesc()
+        d.D = D.data_ptr()
+        w = torch.from_numpy(P.pack_dense(P.conv_kmat(ws[i - 1], kk), 64 * i, npl).view(np.int16)).to(DEV)
+        keep.append(w)
+        d.w = w.data_ptr()
+        for name, t in (("bias", bs[i - 1]), ("gamma", gs[i - 1]), ("beta", bes[i - 1]), ("slope", sls[i - 1])):
+            keep.append(dev(t))
+            setattr(d, name, keep[-1].data_ptr())
+        d.B, d.T, d.F, d.G, d.tpad = B, T, F_, G, TP
+        d.g_in, d.cin, d.g_out, d.dil, d.np, d.eps = (5 - i) * 8, 64 * i, (4 - i) * 8, 2 ** (i - 1), npl, 1e-5
+        L.launch(d, st)
+    torch.cuda.synchronize()
+    tol = 1e-5 if npl == 3 else 3e-2
+    errs = [rel_l2(groups((4 - i) * 8, 8).cpu(), want[i - 1]) for i in range(1, 5)]
+    print("dense layers B %d T %d F %d planes %d: %s" % (B, T, F_, npl, " ".join("%.2e" % e for e in errs)))
+    assert max(errs) < tol, errs
+    assert float(D[:, :, :TP].abs().max()) == 0.0 and float(D[:, :, :, 0].abs().max()) == 0.0 and float(D[:, :, :, -1].abs().max()) == 0.0
+    # plain re-layout (the decoders' input) and the refusals
+    r.gamma = r.beta = r.slope = None
+    r.out = D.data_ptr() + 4 * off(0)
+    L.launch(r, st)
+    torch.cuda.synchronize()
+    assert torch.equal(groups(0, 8), xd)
+    d.g_out = d.g_in
+    with pytest.raises(L.PdseError, match="overlap"):
+        L.launch(d, st)
+    d.g_out, d.dil = 0, 16
+    with pytest.raises(L.PdseError, match="dilation"):
+        L.launch(d, st)
