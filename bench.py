@@ -95,6 +95,10 @@ def main():
                          "eps-net's BIGLU blocks run on the bf16 matrix cores with exact three-way bf16 operand splits "
                          "(six products, fp32 accumulate) - fp32-level accuracy, parity-tested against the same goldens "
                          "and tolerances; the full 50-step schedule always runs exact fp32")
+    ap.add_argument("--split", choices=["bf16x3", "f16x2"], default=None,
+                    help="the fp32-equivalent operand split of the matrix-core kernels (SamplerPipeline.default_split when omitted): "
+                         "bf16x3 = exact three-way bf16 split, six bf16 products; f16x2 = fp16 hi + lo of the power-of-two scaled "
+                         "operand, three f16 products (same goldens and tolerances)")
     ap.add_argument("--bf16", action="store_true",
                     help="the opt-in bf16 mode (BASELINE configs 2/4/5): plain bf16 operands and bf16 conv1 tensors in the "
                          "eps-net's BiConv(Trans)GLU blocks (SamplerPipeline(dtype='bf16')); own tolerance (3e-2), dtype 'bf16' "
@@ -172,6 +176,11 @@ def main():
 
     use_graph = not args.no_graph
     dtype = "bf16" if args.bf16 else "f32"
+    if args.split is not None:
+        pipeline.SamplerPipeline.default_split = args.split
+    args.split = pipeline.SamplerPipeline.default_split
+    f16 = args.split == "f16x2" and args.split_bf16 and not args.bf16      # three f16 products per fp32-equivalent multiply-add
+    products = 3 if f16 else 6
     if args.overlap:
         runner = pipeline.PipelinedSampler(dev, args.prior, gs, ds, B, L_, depth=args.depth, by_batch=args.by_batch,
                                            graph=use_graph, fast_sampling=fast, split_bf16=args.split_bf16, dtype=dtype)
@@ -313,13 +322,14 @@ def main():
         traffic = round((pj["fetch_size_bytes_x2"] + pj["write_size_bytes"]) / pj["launches"])
     # split-bf16 mode: an fp32-equivalent FMA costs six bf16 MFMA products, so the roof of the algorithmic FLOP rate is the
     # dense bf16 peak / 6 (2.5 PF / 6); the TCM blocks inside the family still run on the fp32 matrix cores
-    peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if args.split_bf16 else FP32_MFMA_PEAK_TFLOPS
+    peak = BF16_MFMA_PEAK_TFLOPS / products if args.split_bf16 else FP32_MFMA_PEAK_TFLOPS
     if args.bf16:
         peak = BF16_MFMA_PEAK_TFLOPS
     roofline = {"bound": "mfma", "kernel": ("bglu_kernel (split-bf16 BIGLU blocks on plane tensors) + tcm2_kernel" if args.split_bf16 else
                                             "gconv2_kernel + tcm_block_kernel") + " (eps-net: BiConvGLU/BiConvTransGLU/TCM launches)",
                 "achieved": round(achieved, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
-                "peak_note": ("dense bf16 MFMA 2500 TFLOP/s / 6 products per fp32-equivalent multiply-add" if args.split_bf16
+                "peak_note": (("dense f16 MFMA 2500 TFLOP/s / 3 products per fp32-equivalent multiply-add (f16x2 split)" if f16 else
+                               "dense bf16 MFMA 2500 TFLOP/s / 6 products per fp32-equivalent multiply-add") if args.split_bf16
                               else "fp32 MFMA (v_mfma_f32_32x32x2_f32)"),
                 "frac": round(achieved / peak, 4),
                 "frac_of_fp32_mfma_peak": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
@@ -474,7 +484,7 @@ def main():
                            "the in-flight pass)" % (tcm_stack_ms, per_tag["tcm"]["ms"], per_tag["tcm"]["launches"]),
         "value_sequential": round(B * args.seconds / (ms_sequential * 1e-3), 2),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16" if args.bf16 else ("bf16x3" if args.split_bf16 else "f32"), "data": "synthetic",
+        "dtype": "bf16" if args.bf16 else (args.split if args.split_bf16 else "f32"), "data": "synthetic",
         "dtype_note": ("OPT-IN bf16 mode: plain bf16 operands (one MFMA product, fp32 accumulate) and bf16 conv1 / bottleneck tensors in the eps-net's "
                        "BiConv(Trans)GLU and TCM blocks; prior as in the default; tolerance 3e-2 rel-L2 (tests/test_gpu_round2.py::"
                        "test_bf16_mode_tolerance) - not the graded line") if args.bf16 else ("eps-net blocks: fp32 operands split exactly into three bf16 terms, six-product bf16 MFMA, fp32 accumulate "

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define PDSE_ABI_VERSION 7
+#define PDSE_ABI_VERSION 8
 
 typedef void* pdse_stream_t; /* hipStream_t */
 
@@ -125,7 +125,11 @@ typedef struct pdse_gconv_desc {
      transform): w0 (w1) [K blocks][ceil(Cout/32) tiles][3 planes][64 lanes][8 bf16], K blocks of 16 channels in the
      order (source, tap, channel block); lane (row, h), element j = W[tap*Cin + cbase + 16cb + 8h + j][32 tile + row].
      4 (ABI 6): the same kernel on ONE plane - plain bf16 operands (weights and gathered activations rounded to nearest even),
-     one product, fp32 accumulation: w0 (w1) [K blocks][tiles][1][64][8].  The opt-in bf16 mode; its own tolerance. */
+     one product, fp32 accumulation: w0 (w1) [K blocks][tiles][1][64][8].  The opt-in bf16 mode; its own tolerance.
+     5 (ABI 8): the same kernel on TWO fp16 planes (f16x2, see PDSE_F16_ACT_EXP): w0 (w1) [K blocks][tiles][2][64][8] hold hi / lo
+     of W * 2^wexp, the gathered activations are scaled by 2^PDSE_F16_ACT_EXP and split in registers, three f16 products per
+     multiply-add, fp32 accumulation; the accumulators are scaled back before the epilogue.  fp32-equivalent (same tolerances
+     as korder 3). */
   int32_t korder;
   /* Dual-phase stride-(1,2) ConvTranspose2d (BIGLU only, korder 1): one launch computes the even
      output bins f_o = 2j (weights w0/w1 over all ntaps taps) AND the odd bins 2j+1 (weights w2/w3
@@ -152,7 +156,8 @@ typedef struct pdse_gconv_desc {
   float* nx_out[3];
   int64_t nx_bias_sb[3];
   int64_t nx_sb[3], nx_sc[3], nx_st[3], nx_sf[3], nx_off[3];
-  int32_t nx_n, nx_keep, nx_row0, nx_pad_;
+  int32_t nx_n, nx_keep, nx_row0;
+  int32_t wexp;   /* korder 5: power-of-two exponent the host scaled w0 / w1 by (packing.f16_wexp); otherwise unused */
   /* BIGLU, chained form only: biases of the two gather convolutions for OUTPUT FRAME 0 (batch stride bias0_sb /
      bias1_sb like bias0 / bias1); NULL: frame 0 uses bias0 / bias1 like every other frame.  Needed when conv1 is
      composed into the gather weights (encoder stage 1): frame 0 sees the zero pad frame, whose conv1 value is the
@@ -562,9 +567,10 @@ typedef struct pdse_tcm2_desc {
   const float* par;
   float slope2, slope_main_next, slope_mask_next;
   int32_t dil, B, T, mode;
-  int32_t np;            /* planes of hs and of every packed weight: 3 (exact three-way split; 0 means 3) or 1 (plain bf16,
-                            round to nearest even: the opt-in bf16 mode) - hs is then [B][2][4][2][np][T + 128][8] */
-  int32_t pad_;
+  int32_t np;            /* planes of hs and of every packed weight: 3 (exact three-way split; 0 means 3), 1 (plain bf16,
+                            round to nearest even: the opt-in bf16 mode) or 2 (ABI 8, f16x2: fp16 hi + lo of the operand scaled by
+                            a power of two - hs by 2^PDSE_F16_ACT_EXP, the weights by 2^qexp) - hs is [B][2][4][2][np][T + 128][8] */
+  int32_t qexp[3];       /* np == 2: exponents of wbr (both branches), wc2, wn1 (packing.f16_wexp); par stays in true scale */
 } pdse_tcm2_desc;
 
 /* The residual blocks of the TCM stack as ONE launch (ABI 6, csrc/tcm2.hip: tcm2s_kernel): blk[0..n-1] are the mode-0
@@ -648,6 +654,10 @@ typedef struct pdse_aham_desc {
  *   Encoder stage 1 (x0.ptr != NULL): K = 10 taps x 4 channels of the fp32 inputs (x, x_init), split in the kernel,
  *   three blocks (packing.pack_s3_gather(.., 3, 16)).
  * ------------------------------------------------------------------------------------------------------------- */
+/* f16x2 planes (np == 2) hold (value * 2^PDSE_F16_ACT_EXP) as hi = RN16(.), lo = RN16(. - hi): exact to half an fp32 ulp for
+ * 2^-8 <= |value| < 1023 (lo a normal fp16), absolute error <= 2^-31 below, saturating at +-1023.98 (MODE.FP16_OVFL) above. */
+#define PDSE_F16_ACT_EXP 6
+
 typedef struct pdse_bglu_desc {
   const uint16_t* hp;      /* input planes, or NULL for encoder stage 1 */
   int64_t hp_sb;           /* batch stride, uint16 units */
@@ -708,6 +718,11 @@ typedef struct pdse_bglu_desc {
      the last position store unconditionally into a dump item at index B, so B + 1 are required; the launcher refuses fewer (a
      B-item tensor handed to this public entry point would otherwise be written past its end, silently). */
   int32_t nx_items;
+  /* ABI 8, np == 2 (the f16x2 form: every operand as hi + lo fp16 planes, three f16 MFMA products per multiply-add, fp32
+     accumulation; see PDSE_F16_ACT_EXP): the power-of-two exponents the host scaled the four weight groups by before it split
+     them (packing.f16_wexp) - [0] gather weights w0..w3, [1] wlc / wrc, [2] wc2, [3] nx_w.  Biases and every fp32 tensor in
+     HBM stay in true scale; the kernel moves them to the accumulators' exponent itself.  Ignored for np 1 / 3. */
+  int32_t qexp[4];
 } pdse_bglu_desc;
 
 /* fp32 [B, 32, T, F] -> hp planes (the standalone conv1 of the first decoder stage) */

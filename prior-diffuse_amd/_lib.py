@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PDSE_LIB") or os.path.join(_HERE, "libpdse.so")   # PDSE_LIB: diagnostic builds only
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 ACT_NONE, ACT_PRELU, ACT_ELU, ACT_SIGMOID = 0, 1, 2, 3
 EPI_LINEAR, EPI_GLU, EPI_BIGLU = 0, 1, 2
@@ -48,7 +48,7 @@ class GconvDesc(C.Structure):
         ("korder", _i32), ("ksteps1", _i32), ("w2", _fp), ("w3", _fp), ("p1mask", _i32), ("Fout1", _i32),
         ("nx_w", _fp), ("nx_bias", _fp * 3), ("nx_add", _fp * 3), ("nx_out", _fp * 3), ("nx_bias_sb", _i64 * 3),
         ("nx_sb", _i64 * 3), ("nx_sc", _i64 * 3), ("nx_st", _i64 * 3), ("nx_sf", _i64 * 3), ("nx_off", _i64 * 3),
-        ("nx_n", _i32), ("nx_keep", _i32), ("nx_row0", _i32), ("nx_pad_", _i32),
+        ("nx_n", _i32), ("nx_keep", _i32), ("nx_row0", _i32), ("wexp", _i32),
         ("bias0_t0", _fp), ("bias1_t0", _fp),
         ("tap_dt", _i32 * 12), ("tap_df", _i32 * 12),
     ]
@@ -177,7 +177,7 @@ class TcmDesc(C.Structure):
 class Tcm2Desc(C.Structure):
     _fields_ = [("x", _fp), ("x_out", _fp), ("hs", _fp), ("hs_out", _fp), ("wbr", _fp), ("wc2", _fp), ("wn1", _fp),
                 ("par", _fp), ("slope2", _f32), ("slope_main_next", _f32), ("slope_mask_next", _f32),
-                ("dil", _i32), ("B", _i32), ("T", _i32), ("mode", _i32), ("np", _i32), ("pad_", _i32)]
+                ("dil", _i32), ("B", _i32), ("T", _i32), ("mode", _i32), ("np", _i32), ("qexp", _i32 * 3)]
 
 
 TCM2S_MAX = 20
@@ -203,7 +203,7 @@ class BgluDesc(C.Structure):
                 ("nx_row0", _i32), ("nx_par", _i32),
                 ("nx_add", _fp), ("add_sb", _i64), ("add_sc", _i64), ("add_st", _i64), ("add_sf", _i64),
                 ("nx_out", _fp * 2), ("nx_sb", _i64 * 2), ("nx_sc", _i64 * 2), ("nx_st", _i64 * 2), ("nx_sf", _i64 * 2),
-                ("nx_bias", _fp * 3), ("nx_bias_sb", _i64 * 3), ("skip_Fh", _i32), ("nx_items", _i32)]
+                ("nx_bias", _fp * 3), ("nx_bias_sb", _i64 * 3), ("skip_Fh", _i32), ("nx_items", _i32), ("qexp", _i32 * 4)]
 
 
 class PlanesDesc(C.Structure):

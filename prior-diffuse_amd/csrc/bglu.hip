@@ -59,6 +59,11 @@ __device__ __forceinline__ f32x16 mm(const uint4* w, const uint4 (&b)[NP], f32x1
     acc = mfma_bf16(a1, b[1], acc);
     acc = mfma_bf16(a2, b[0], acc);
     acc = mfma_bf16(a1, b[0], acc);
+  } else if constexpr (NP == 2) {   // f16x2: a2 b1, a1 b2, a1 b1
+    const uint4 a1 = w[0], a2 = w[64];
+    acc = mfma_f16(a2, b[0], acc);
+    acc = mfma_f16(a1, b[1], acc);
+    acc = mfma_f16(a1, b[0], acc);
   } else {
     acc = mfma_bf16(w[0], b[0], acc);
   }
@@ -75,6 +80,10 @@ __device__ __forceinline__ f32x16 mmf(const uint4 (&a)[NP], const uint4 (&b)[NP]
     acc = mfma_bf16(a[0], b[1], acc);
     acc = mfma_bf16(a[1], b[0], acc);
     acc = mfma_bf16(a[0], b[0], acc);
+  } else if constexpr (NP == 2) {
+    acc = mfma_f16(a[1], b[0], acc);
+    acc = mfma_f16(a[0], b[1], acc);
+    acc = mfma_f16(a[0], b[0], acc);
   } else {
     acc = mfma_bf16(a[0], b[0], acc);
   }
@@ -91,8 +100,9 @@ __device__ __forceinline__ uint32_t pack_bf16(const float a, const float b) {
   return c.u;
 }
 
+// sc: the power of two that takes the values to the plane exponent (NP == 2 only; gconv_common.h: split8h)
 template <int NP>
-__device__ __forceinline__ void split8p(const float (&x)[8], uint4 (&p)[NP]) {
+__device__ __forceinline__ void split8p(const float (&x)[8], uint4 (&p)[NP], const float sc = 1.0f) {
 #if defined(BGLU_DIAG) && defined(BGLU_NO_SPLIT)   // timing ablation: no split arithmetic (results wrong)
   p[0] = make_uint4(__float_as_uint(x[0]), __float_as_uint(x[1]), __float_as_uint(x[2]), __float_as_uint(x[3]));
   if constexpr (NP == 3) {
@@ -103,6 +113,8 @@ __device__ __forceinline__ void split8p(const float (&x)[8], uint4 (&p)[NP]) {
 #endif
   if constexpr (NP == 3) {
     split8(x, p[0], p[1], p[2]);
+  } else if constexpr (NP == 2) {
+    split8h(x, sc, p[0], p[1]);
   } else {
     p[0] = make_uint4(pack_bf16(x[0], x[1]), pack_bf16(x[2], x[3]), pack_bf16(x[4], x[5]), pack_bf16(x[6], x[7]));
   }
@@ -110,13 +122,13 @@ __device__ __forceinline__ void split8p(const float (&x)[8], uint4 (&p)[NP]) {
 
 // a 32-channel accumulator tile as the B operand of the next contraction: two K blocks of 8 registers
 template <int NP>
-__device__ __forceinline__ void split16p(const f32x16& X, uint4 (&p)[2][NP]) {
+__device__ __forceinline__ void split16p(const f32x16& X, uint4 (&p)[2][NP], const float sc = 1.0f) {
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     float x[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) x[j] = X[8 * s + j];
-    split8p<NP>(x, p[s]);
+    split8p<NP>(x, p[s], sc);
   }
 }
 
@@ -168,6 +180,13 @@ __global__ __launch_bounds__(PIPE ? 256 : 512, PIPE ? 1 : 2) void bglu_kernel(co
   const int col = lane & 31, h = lane >> 5;
   const int b = blockIdx.y;
   const int P = d.Tout * d.Fout;
+  // NP == 2 (f16x2): the powers of two between the exponents of the planes (2^PDSE_F16_ACT_EXP), of the four weight groups
+  // (d.qexp: gather, l_conv / r_conv, conv2, chained tiles) and of the accumulators (plane exponent + weight exponent)
+  constexpr int PE = NP == 2 ? PDSE_F16_ACT_EXP : 0;
+  const int qG = NP == 2 ? d.qexp[0] : 0, qLC = NP == 2 ? d.qexp[1] : 0, qC2 = NP == 2 ? d.qexp[2] : 0, qNX = NP == 2 ? d.qexp[3] : 0;
+  [[maybe_unused]] const float s_in = pow2i(PE), s_G = pow2i(-qG), s_LC = pow2i(-(PE + qLC)), s_C2 = pow2i(-qC2), s_NX = pow2i(-qNX),
+                               s_C2out = pow2i(-(PE + qC2)), s_NXout = pow2i(-(PE + qNX)), s_NXin = pow2i(PE + qNX);
+  if constexpr (NP == 2) f16_saturate_mode();
 
   // ---- the LDS image: every weight fragment of the launch by LDS-DMA (1 KB per wave instruction), then the floats
   {
@@ -204,6 +223,10 @@ __global__ __launch_bounds__(PIPE ? 256 : 512, PIPE ? 1 : 2) void bglu_kernel(co
         const int i = (s - 256) >> 5;
         v = (i < NXN && d.nx_bias[i]) ? d.nx_bias[i][(int64_t)b * d.nx_bias_sb[i] + k] : 0.f;
       } else if (s < 384) v = (C2 == 1) ? d.wc2v[k] : 0.f;
+      if constexpr (NP == 2) {   // biases seed accumulators: they carry the accumulator's exponent (exact: powers of two)
+        v *= s < 128 ? pow2i(PE + qG) : s < 192 ? pow2i(PE + qLC) : s < 256 ? (C2 == 64 ? pow2i(PE + qC2) : 1.0f)
+             : s < 352 ? pow2i(PE + qNX) : pow2i(-(PE + qG));   // wc2v (C2 == 1) multiplies G, which is at the gather exponent
+      }
       fo[s] = v;
     }
   }
@@ -324,7 +347,7 @@ __global__ __launch_bounds__(PIPE ? 256 : 512, PIPE ? 1 : 2) void bglu_kernel(co
 #pragma unroll
       for (int e = 0; e < 8; ++e) x[e] = ((in.live >> (2 * q + (e >> 2))) & 1u) ? in.raw[2 * q + (e >> 2)][e & 3] : 0.f;
       uint4 bp[NP];
-      split8p<NP>(x, bp);
+      split8p<NP>(x, bp, s_in);
       const int blk = q * BS + lane;
       a.L = mm<NP>(img + CF::o_gL + blk, bp, a.L);
       a.R = mm<NP>(img + CF::o_gR + blk, bp, a.R);
@@ -378,9 +401,19 @@ __global__ __launch_bounds__(PIPE ? 256 : 512, PIPE ? 1 : 2) void bglu_kernel(co
     const int jp = d.skip_Fh ? (ps.j & 1) * d.skip_Fh + (ps.j >> 1) : ps.j;   // bins split by parity (pdse_bglu_desc.skip_Fh)
     const uint32_t o = (uint32_t)(((int64_t)(ps.valid ? b : d.B) * d.nx_sb[i] + (ps.valid ? (int64_t)ps.t * d.nx_st[i] + (int64_t)jp * d.nx_sf[i] : 0) +
                                    (int64_t)h * d.nx_sc[i]) << 2);
+    // NP == 2: HBM holds true values - all sixteen are re-scaled into registers of their own BEFORE the first store.  (Scaled four at
+    // a time into one temporary, hipcc re-used that temporary right behind each 16-byte store, and on gfx950 a v_pk_mul_f32 issued
+    // directly behind a buffer_store_dwordx4 with a scalar offset overwrote dword 1 of the store's data: LLVM models that hazard
+    // for stores without a scalar offset only.  tests/test_isa_guards.py checks every kernel for the pattern.)
+    f32x16 zs = z;
+    if constexpr (NP == 2) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) zs[r] = z[r] * s_NXout;
+      asm volatile("" : "+v"(zs));
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-      bstore16<BGLU_ST_AUX>(make_uint4(__float_as_uint(z[4 * q]), __float_as_uint(z[4 * q + 1]), __float_as_uint(z[4 * q + 2]), __float_as_uint(z[4 * q + 3])),
+      bstore16<BGLU_ST_AUX>(make_uint4(__float_as_uint(zs[4 * q]), __float_as_uint(zs[4 * q + 1]), __float_as_uint(zs[4 * q + 2]), __float_as_uint(zs[4 * q + 3])),
                i == 0 ? r_sk0 : r_sk1, o, (int)((2 * q * d.nx_sc[i]) << 2));
   };
   auto stores_masked = [&](const pos_t& ps, const auto& o0, const auto& o1) {
@@ -405,7 +438,7 @@ __global__ __launch_bounds__(PIPE ? 256 : 512, PIPE ? 1 : 2) void bglu_kernel(co
 #pragma unroll
       for (int m2 = 0; m2 < 2; ++m2)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) po[(int64_t)(32 * m2 + 4 * h + PDSE_KR(r)) * d.out_sc] = (m2 ? o0.O1 : o0.O0)[r];
+        for (int r = 0; r < 16; ++r) po[(int64_t)(32 * m2 + 4 * h + PDSE_KR(r)) * d.out_sc] = (m2 ? o0.O1 : o0.O0)[r] * (NP == 2 ? s_C2out : 1.0f);
     }
   };
 
@@ -418,11 +451,11 @@ __global__ __launch_bounds__(PIPE ? 256 : 512, PIPE ? 1 : 2) void bglu_kernel(co
     float v;
     uint32_t zo, so;   // spread schedules: byte offsets of the addend loads / the plane stores of this phase
   };
-  auto split_half = [&](const f32x16& X, const int s_, uint4 (&p)[NP]) {
+  auto split_half = [&](const f32x16& X, const int s_, uint4 (&p)[NP], const float sc = 1.0f) {
     float x[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) x[j] = X[8 * s_ + j];
-    split8p<NP>(x, p);
+    split8p<NP>(x, p, sc);
   };
   // addend of chained tile 0 (decoders: the encoder's skip half of this conv1; its bias is part of it).  Lanes without a
   // valid position (or without an odd bin) read a position that exists.
@@ -436,6 +469,7 @@ __global__ __launch_bounds__(PIPE ? 256 : 512, PIPE ? 1 : 2) void bglu_kernel(co
     for (int q = 0; q < 4; ++q) {   // groups of four channels (store_skip's layout): four 16-byte loads
       const uint4 v = bload16(r_add, o, (int)((2 * q * d.add_sc) << 2));
       z[4 * q] = __uint_as_float(v.x), z[4 * q + 1] = __uint_as_float(v.y), z[4 * q + 2] = __uint_as_float(v.z), z[4 * q + 3] = __uint_as_float(v.w);
+      if constexpr (NP == 2) z[4 * q] *= s_NXin, z[4 * q + 1] *= s_NXin, z[4 * q + 2] *= s_NXin, z[4 * q + 3] *= s_NXin;   // seeds an accumulator
     }
   };
 
@@ -448,6 +482,7 @@ __global__ __launch_bounds__(PIPE ? 256 : 512, PIPE ? 1 : 2) void bglu_kernel(co
   auto zload = [&](const uint32_t o, const int q, f32x16& z) {
     const uint4 v = bload16(r_add, o, (int)((2 * q * d.add_sc) << 2));
     z[4 * q] = __uint_as_float(v.x), z[4 * q + 1] = __uint_as_float(v.y), z[4 * q + 2] = __uint_as_float(v.z), z[4 * q + 3] = __uint_as_float(v.w);
+    if constexpr (NP == 2) z[4 * q] *= s_NXin, z[4 * q + 1] *= s_NXin, z[4 * q + 2] *= s_NXin, z[4 * q + 3] *= s_NXin;
   };
 
 #define FRAG(buf, ptr)                                         \
@@ -472,16 +507,16 @@ __global__ __launch_bounds__(PIPE ? 256 : 512, PIPE ? 1 : 2) void bglu_kernel(co
 #define V_SL(S, s_)                                      \
   {                                                      \
     if ((s_) == 0) S.mL = ld16(fop + F_BLC + 4 * h);     \
-    split_half(S.L, s_, S.lp[s_]);                       \
+    split_half(S.L, s_, S.lp[s_], s_G);                  \
   }
 #define V_SR(S, s_)                                      \
   {                                                      \
     if ((s_) == 0) S.mR = ld16(fop + F_BRC + 4 * h);     \
-    split_half(S.R, s_, S.rp[s_]);                       \
+    split_half(S.R, s_, S.rp[s_], s_G);                  \
   }
 #define V_SG(S, lo, hi)                                                                                       \
   {                                                                                                           \
-    _Pragma("unroll") for (int r = lo; r < hi; ++r) S.G[r] = S.L[r] * sigm2(S.mR[r]) + S.R[r] * sigm2(S.mL[r]); \
+    _Pragma("unroll") for (int r = lo; r < hi; ++r) S.G[r] = S.L[r] * sigm2(NP == 2 ? S.mR[r] * s_LC : S.mR[r]) + S.R[r] * sigm2(NP == 2 ? S.mL[r] * s_LC : S.mL[r]); \
   }
 #define V_SPG(S, s_)                                          \
   {                                                           \
@@ -489,7 +524,7 @@ __global__ __launch_bounds__(PIPE ? 256 : 512, PIPE ? 1 : 2) void bglu_kernel(co
       S.O0 = ld16(fop + F_BC2 + 4 * h);                       \
       S.O1 = ld16(fop + F_BC2 + 32 + 4 * h);                  \
     }                                                         \
-    split_half(S.G, s_, S.gp[s_]);                            \
+    split_half(S.G, s_, S.gp[s_], s_G);                       \
   }
 #define V_PR(S, m2)                                                                                        \
   {                                                                                                        \
@@ -502,10 +537,10 @@ __global__ __launch_bounds__(PIPE ? 256 : 512, PIPE ? 1 : 2) void bglu_kernel(co
       if constexpr (NXN > 1) S.Z1 = ld16(fop + F_NXB + 32 + 4 * h);         \
       if constexpr (NXN > 2) S.Z2 = ld16(fop + F_NXB + 64 + 4 * h);         \
     }                                                                       \
-    split_half(S.O##m2, s_, S.yp[m2][s_]);                                  \
+    split_half(S.O##m2, s_, S.yp[m2][s_], s_C2);                            \
   }
 #define V_ZSEED(S, ph) zseed(pc, ph, S.Z0);
-#define V_SZ(S, s_) split_half(S.Z0, s_, S.zp[s_]);
+#define V_SZ(S, s_) split_half(S.Z0, s_, S.zp[s_], s_NX);
 #define V_ST0(S, ph)                                                                                   \
   {                                                                                                    \
     if constexpr (DUAL) {                                                                              \
@@ -514,7 +549,7 @@ __global__ __launch_bounds__(PIPE ? 256 : 512, PIPE ? 1 : 2) void bglu_kernel(co
       store_planes(S.zp, pc.valid, pc.t, pc.j);                                                        \
       if (d.nx_row0) { /* uniform: the explicit pad frame of the next encoder stage = the folded bias */ \
         uint4 bp_[2][NP];                                                                              \
-        split16p<NP>(ld16(fop + F_NXB + 4 * h), bp_);                                                  \
+        split16p<NP>(ld16(fop + F_NXB + 4 * h), bp_, s_NX);                                            \
         store_planes(bp_, pc.valid && pc.t == 0, -1, pc.j);                                            \
       }                                                                                                \
     }                                                                                                  \
@@ -529,7 +564,7 @@ __global__ __launch_bounds__(PIPE ? 256 : 512, PIPE ? 1 : 2) void bglu_kernel(co
     if constexpr (!DUAL) {                                                                             \
       if ((q) == 1 && d.nx_row0) {                                                                     \
         uint4 bp_[2][NP];                                                                              \
-        split16p<NP>(ld16(fop + F_NXB + 4 * h), bp_);                                                  \
+        split16p<NP>(ld16(fop + F_NXB + 4 * h), bp_, s_NX);                                            \
         store_planes(bp_, pc.valid && pc.t == 0, -1, pc.j);                                            \
       }                                                                                                \
     }                                                                                                  \
@@ -547,7 +582,7 @@ __global__ __launch_bounds__(PIPE ? 256 : 512, PIPE ? 1 : 2) void bglu_kernel(co
   {                                                                                                                               \
     float x_[8];                                                                                                                  \
     _Pragma("unroll") for (int e = 0; e < 8; ++e) x_[e] = ((in.live >> (2 * (q) + (e >> 2))) & 1u) ? in.raw[2 * (q) + (e >> 2)][e & 3] : 0.f; \
-    split8p<NP>(x_, kb[q]);                                                                                                       \
+    split8p<NP>(x_, kb[q], s_in);                                                                                                 \
   }
 #define REQ(tap) request_tap(p_req, in, tap);
 #define REQ_CUR(tap) request_tap(pc, in, tap);
@@ -627,6 +662,11 @@ __global__ __launch_bounds__(PIPE ? 256 : 512, PIPE ? 1 : 2) void bglu_kernel(co
 #define SLOT_END(hasm, hasv)                                                       \
   if constexpr (NP == 3) {                                                         \
     _Pragma("unroll") for (int g_ = 0; g_ < 6; ++g_) {                             \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                           \
+      __builtin_amdgcn_sched_group_barrier(0x002, BGLU_VPER, 0);                   \
+    }                                                                              \
+  } else if constexpr (NP == 2) {                                                  \
+    _Pragma("unroll") for (int g_ = 0; g_ < 3; ++g_) {                             \
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                           \
       __builtin_amdgcn_sched_group_barrier(0x002, BGLU_VPER, 0);                   \
     }                                                                              \
@@ -1229,7 +1269,8 @@ __global__ __launch_bounds__(256) void planes_kernel(const pdse_planes_desc d) {
     x[e] = d.in[(int64_t)b * d.in_sb + (int64_t)c * d.in_sc + (int64_t)t * d.in_st + (int64_t)f * d.in_sf];
   }
   uint4 p[NP];
-  split8p<NP>(x, p);
+  if constexpr (NP == 2) f16_saturate_mode();
+  split8p<NP>(x, p, NP == 2 ? pow2i(PDSE_F16_ACT_EXP) : 1.0f);
   uint4* const base = reinterpret_cast<uint4*>(d.hp + (int64_t)b * d.hp_sb) + ((int64_t)(t + d.hp_t0) * 4 + g) * (NP * d.hp_Fp) + f + d.hp_f0;
 #pragma unroll
   for (int pl = 0; pl < NP; ++pl) base[pl * d.hp_Fp] = p[pl];
@@ -1309,7 +1350,7 @@ int launch(const pdse_bglu_desc* d, hipStream_t s) {
   // on every geometry and for both plane counts: a wave issues at most one instruction per four cycles whatever its type,
   // so two waves per SIMD double the issue rate, which the interleaving inside one wave does not make up for
 #ifdef BGLU_FORMS   // the forms that were measured and not kept (profiles/r03_bglu_forms.txt, r04_bglu_forms.txt): diagnostic builds only
-  const int form = g_bglu_form;
+  const int form = NP == 2 ? -1 : g_bglu_form;   // the experimental forms know the bf16 plane counts only
   if (form == 1) return launch_<NT, P1MASK, C2, NXN, IN4, NP, true>(d, s);
   if (form == 2) return launch16_<NT, P1MASK, C2, NXN, IN4, NP, 16>(d, s);
   if (form == 3) return launch16_<NT, P1MASK, C2, NXN, IN4, NP, 12>(d, s);
@@ -1344,9 +1385,9 @@ int pdse_bglu_launch(const pdse_bglu_desc* d, hipStream_t s) {
     pdse_set_error("bglu: PReLU slope must be <= 1 (max form); use the korder 2 kernels otherwise");
     return 1;
   }
-  if (d->B < 1 || d->Tout < 1 || d->Fout < 1 || !(d->np == 3 || d->np == 1) || !(d->C2 == 64 || d->C2 == 1) || d->nx_n < 0 ||
+  if (d->B < 1 || d->Tout < 1 || d->Fout < 1 || !(d->np == 3 || d->np == 2 || d->np == 1) || !(d->C2 == 64 || d->C2 == 1) || d->nx_n < 0 ||
       d->nx_n > 3 || d->ntaps < 1 || d->ntaps > 10) {
-    pdse_set_error("bglu: bad geometry (np in {1, 3}, C2 in {64, 1}, nx_n <= 3, ntaps <= 10)");
+    pdse_set_error("bglu: bad geometry (np in {1, 2, 3}, C2 in {64, 1}, nx_n <= 3, ntaps <= 10)");
     return 1;
   }
   if (d->p1mask && d->Fout1 > d->Fout) {
@@ -1421,6 +1462,14 @@ int pdse_bglu_launch(const pdse_bglu_desc* d, hipStream_t s) {
       }
     }
   }
+  if (d->np == 2) {
+    for (int i = 0; i < 4; ++i)
+      if (d->qexp[i] < -40 || d->qexp[i] > 40) {
+        pdse_set_error("bglu: qexp (f16x2 weight exponents) out of range");
+        return 1;
+      }
+    return dispatch<2>(d, s);
+  }
   return d->np == 3 ? dispatch<3>(d, s) : dispatch<1>(d, s);
 }
 
@@ -1437,7 +1486,7 @@ int pdse_bglu_set_form(int form) {
 }
 
 int pdse_planes_launch(const pdse_planes_desc* d, hipStream_t s) {
-  if (!d || !d->in || !d->hp || d->B < 1 || d->T < 1 || d->F < 1 || !(d->np == 3 || d->np == 1)) {
+  if (!d || !d->in || !d->hp || d->B < 1 || d->T < 1 || d->F < 1 || !(d->np == 3 || d->np == 2 || d->np == 1)) {
     pdse_set_error("planes: bad argument");
     return 1;
   }
@@ -1448,6 +1497,7 @@ int pdse_planes_launch(const pdse_planes_desc* d, hipStream_t s) {
   const int64_t n = (int64_t)d->B * d->T * d->F * 4;
   const dim3 grid((unsigned)((n + 255) / 256)), block(256);
   if (d->np == 3) hipLaunchKernelGGL(planes_kernel<3>, grid, block, 0, s, *d);
+  else if (d->np == 2) hipLaunchKernelGGL(planes_kernel<2>, grid, block, 0, s, *d);
   else hipLaunchKernelGGL(planes_kernel<1>, grid, block, 0, s, *d);
   return pdse_check_launch("planes");
 }

@@ -165,9 +165,9 @@ int pdse_gconv_launch(const pdse_gconv_desc* d, hipStream_t s) {
     PDSE_REQUIRE(d->in1.C == 0 || d->in1.ptr, "in1 has channels but no pointer");
     if (d->korder == 0) PDSE_REQUIRE(d->ksteps == d->ntaps * (Cin / 2), "ksteps != ntaps*Cin/2");
     else PDSE_REQUIRE(d->ksteps >= d->ntaps * (Cin / 2), "ksteps < ntaps*Cin/2");
-    PDSE_REQUIRE(d->korder < 3 || d->epi != PDSE_EPI_BIGLU, "korder 3 / 4 have LINEAR / GLU epilogues only");
+    PDSE_REQUIRE(d->korder < 3 || d->epi != PDSE_EPI_BIGLU, "korder 3 / 4 / 5 have LINEAR / GLU epilogues only");
   }
-  PDSE_REQUIRE((d->in0.blk == 0 && d->in1.blk == 0) || d->korder == 3 || d->korder == 4, "channel-blocked sources (pdse_src.blk) are read by the korder 3 kernel only");
+  PDSE_REQUIRE((d->in0.blk == 0 && d->in1.blk == 0) || d->korder == 3 || d->korder == 4 || d->korder == 5, "channel-blocked sources (pdse_src.blk) are read by the korder 3 kernel only");
   if (d->xf_mode) {
     PDSE_REQUIRE(d->xf_scale0 && d->xf_shift0, "xf_mode set without scale/shift");
     PDSE_REQUIRE(d->xf_mode != 2 || (d->xf_scale1 && d->xf_shift1), "xf_mode 2 without second set");
@@ -198,7 +198,7 @@ int pdse_gconv_launch(const pdse_gconv_desc* d, hipStream_t s) {
     PDSE_REQUIRE(!d->cin1, "korder 1 needs Cin >= 2");
     return pdse_gconv2_launch(d, s);
   }
-  if (d->korder == 3 || d->korder == 4) return pdse_gconv4_launch(d, s);   // split-bf16 (3) / plain bf16 (4) GEMM-shaped convolutions (gconv4.hip)
+  if (d->korder >= 3 && d->korder <= 5) return pdse_gconv4_launch(d, s);   // split-bf16 (3) / plain bf16 (4) / f16x2 (5) GEMM-shaped convolutions (gconv4.hip)
   if (d->korder == 2) {   // split-bf16 BIGLU blocks (gconv3.hip)
     PDSE_REQUIRE(d->resid == nullptr, "BIGLU has no residual input");
     PDSE_REQUIRE(d->act == PDSE_ACT_NONE || d->act == PDSE_ACT_PRELU, "BIGLU stages end in PReLU or no activation");

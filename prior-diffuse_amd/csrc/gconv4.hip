@@ -96,6 +96,9 @@ __device__ __forceinline__ void g4_lds_read3(const unsigned addr, u32x4 (&a)[3])
                : "v"(addr)
                : "memory");
 }
+__device__ __forceinline__ void g4_lds_read3(const unsigned addr, u32x4 (&a)[2]) {   // f16x2: hi and lo planes
+  asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024" : "=&v"(a[0]), "=&v"(a[1]) : "v"(addr) : "memory");
+}
 __device__ __forceinline__ void g4_lds_read3(const unsigned addr, u32x4 (&a)[1]) {
   asm volatile("ds_read_b128 %0, %1" : "=&v"(a[0]) : "v"(addr) : "memory");
 }
@@ -118,6 +121,13 @@ __device__ __forceinline__ f32x16 g4_mfma6(const u32x4 (&a)[3], const uint4 (&b)
   acc = mfma_bf16(a1, b[0], acc);
   return acc;
 }
+__device__ __forceinline__ f32x16 g4_mfma6(const u32x4 (&a)[2], const uint4 (&b)[2], f32x16 acc) {   // a2 b1, a1 b2, a1 b1 (gconv_common.h)
+  const uint4 a1 = make_uint4(a[0][0], a[0][1], a[0][2], a[0][3]), a2 = make_uint4(a[1][0], a[1][1], a[1][2], a[1][3]);
+  acc = mfma_f16(a2, b[0], acc);
+  acc = mfma_f16(a1, b[1], acc);
+  acc = mfma_f16(a1, b[0], acc);
+  return acc;
+}
 __device__ __forceinline__ f32x16 g4_mfma6(const u32x4 (&a)[1], const uint4 (&b)[1], f32x16 acc) {
   return mfma_bf16(make_uint4(a[0][0], a[0][1], a[0][2], a[0][3]), b[0], acc);
 }
@@ -130,6 +140,7 @@ __device__ __forceinline__ uint32_t g4_pack_bf16(const float a, const float b) {
   return c.u;
 }
 __device__ __forceinline__ void g4_split(const float (&x)[8], uint4 (&b)[3]) { split8(x, b[0], b[1], b[2]); }
+__device__ __forceinline__ void g4_split(const float (&x)[8], uint4 (&b)[2]) { split8h(x, pow2i(PDSE_F16_ACT_EXP), b[0], b[1]); }
 __device__ __forceinline__ void g4_split(const float (&x)[8], uint4 (&b)[1]) {
   b[0] = make_uint4(g4_pack_bf16(x[0], x[1]), g4_pack_bf16(x[2], x[3]), g4_pack_bf16(x[4], x[5]), g4_pack_bf16(x[6], x[7]));
 }
@@ -167,6 +178,7 @@ __global__ __launch_bounds__(512, 2) void gconv4_kernel(const pdse_gconv_desc d)
   const int mtiles = (d.Cout + 31) >> 5;
   const int mt0 = blockIdx.z * MT;
 
+  if constexpr (NP == 2) f16_saturate_mode();
   const int cbn0 = d.in0.C >> 4, cbn1 = d.in1.C >> 4;                    // 16-channel blocks per source
   const int cps0 = (cbn0 + G4_CH - 1) / G4_CH, cps1 = (cbn1 + G4_CH - 1) / G4_CH;   // chunks per (source, tap)
   const int nch0 = d.ntaps * cps0, nch = nch0 + d.ntaps * cps1;
@@ -320,6 +332,16 @@ __global__ __launch_bounds__(512, 2) void gconv4_kernel(const pdse_gconv_desc d)
     g4_landed(rawA);
   }
   const long long c_loop = trace ? clock64() : 0;
+  if constexpr (NP == 2) {   // f16x2: the accumulators hold (true value) * 2^(activation exponent + weight exponent)
+    const float us = pow2i(-(PDSE_F16_ACT_EXP + d.wexp));
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        acc0[m][r] *= us;
+        if (DUAL) acc1[m][r] *= us;
+      }
+  }
   gconv_epilogue<EPI, MT>(d, tail_from_desc(d), acc0, acc1, b, t, j, pvalid, lane, h, mt0, mtiles);
   if (trace && lane == 0) {
     long long* q = trace + ((size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + wave) * 8;
@@ -369,6 +391,8 @@ static int launch4b(const pdse_gconv_desc* d, hipStream_t s, const int mtiles) {
 
 template <int EPI, int MT>
 static int launch4(const pdse_gconv_desc* d, hipStream_t s, const int mtiles) {
+  if (d->korder == 5)   // two planes: fp16 hi + lo of the power-of-two scaled operands, three f16 products (f16x2)
+    return d->in0.blk ? launch4b<EPI, MT, true, 2>(d, s, mtiles) : launch4b<EPI, MT, false, 2>(d, s, mtiles);
   if (d->korder == 4)   // one plane: plain bf16 operands, one product (the opt-in bf16 mode)
     return d->in0.blk ? launch4b<EPI, MT, true, 1>(d, s, mtiles) : launch4b<EPI, MT, false, 1>(d, s, mtiles);
   return d->in0.blk ? launch4b<EPI, MT, true, 3>(d, s, mtiles) : launch4b<EPI, MT, false, 3>(d, s, mtiles);
@@ -389,7 +413,7 @@ int pdse_gconv4_launch(const pdse_gconv_desc* d, hipStream_t s) {
   }
   if (!(d->epi == PDSE_EPI_LINEAR || d->epi == PDSE_EPI_GLU) || (d->in0.C & 15) || (d->in1.C & 15) || d->in0.C == 0 || d->cin1 ||
       d->xf_mode != 0 || d->padrow != nullptr || d->ntaps > 12 || span0 >= (1ll << 32) || span1 >= (1ll << 32) ||
-      (d->epi == PDSE_EPI_GLU && !d->w1)) {
+      (d->epi == PDSE_EPI_GLU && !d->w1) || (d->korder == 5 && (d->wexp < -40 || d->wexp > 40))) {
     pdse_set_error("gconv4: split-bf16 GEMM convolutions need LINEAR / GLU, channel counts in multiples of 16, <= 12 taps, "
                    "no load transform / pad row, 32-bit gather offsets");
     return 1;

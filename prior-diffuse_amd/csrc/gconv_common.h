@@ -142,6 +142,53 @@ __device__ __forceinline__ void split8(const float (&x)[8], uint4& p1, uint4& p2
   p3 = make_uint4(q3[0], q3[1], q3[2], q3[3]);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Split-f16 operands (round 4; include/pdse.h "f16x2"): an fp32 value x, scaled by a power of two into the fp16 range,
+// is carried as hi = RN16(x), lo = RN16(x - hi): 11 + 11 significand bits and the sign of lo, |x - hi - lo| <= 2^-23 |x|
+// (half an fp32 ulp at worst) while lo is a normal fp16, i.e. for |x| >= 2^-2 in scaled units; below that the absolute
+// error is <= 2^-25 of the scaled unit.  A product is its three leading cross terms (a1 b1, a1 b2, a2 b1; what is dropped
+// is a2 b2 <= 2^-22 |a b|) on the f16 matrix cores with fp32 accumulation: half the matrix instructions and two thirds
+// of the operand bytes of the three-plane bf16 split.  Every product of two fp16 numbers is exact in fp32.
+// Scaling is by exact powers of two: activations by 2^PDSE_F16_ACT_EXP, every weight matrix by its own 2^q chosen on
+// the host (packing.f16_wexp); accumulators therefore hold (true value) * 2^(P + q) and are re-scaled where they are
+// split for the next contraction (one multiply, merged with the split's own).
+// ---------------------------------------------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ f32x16 mfma_f16(const uint4& a, const uint4& b, const f32x16 c) {
+  union { uint4 u; f16x8 v; } A, B;
+  A.u = a;
+  B.u = b;
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(A.v, B.v, c, 0, 0, 0);
+}
+
+// 2^e as a float (|e| < 127)
+__device__ __forceinline__ float pow2i(const int e) { return __uint_as_float((uint32_t)(127 + e) << 23); }
+
+// MODE.FP16_OVFL = 1: a conversion to fp16 that overflows gives +-65504 instead of +-infinity (the planes of a value beyond
+// the fp16 range saturate instead of poisoning every sum they enter)
+__device__ __forceinline__ void f16_saturate_mode() { __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1); }
+
+// x[0..7] * sc -> two planes of 8 fp16 (element j in the low / high half of dword j >> 1): v_pk_mul, v_cvt_pk_f16_f32,
+// two v_cvt_f32_f16, v_pk_add, v_cvt_pk_f16_f32 per pair of values (the bf16 three-way split takes eleven)
+__device__ __forceinline__ void split8h(const float (&x)[8], const float sc, uint4& p1, uint4& p2) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+  uint32_t q1[4], q2[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const f32x2 t = {x[2 * i] * sc, x[2 * i + 1] * sc};
+    union { f16x2 h; uint32_t u; } hi, lo;
+    hi.h = __builtin_convertvector(t, f16x2);
+    const f32x2 r = t - __builtin_convertvector(hi.h, f32x2);
+    lo.h = __builtin_convertvector(r, f16x2);
+    q1[i] = hi.u;
+    q2[i] = lo.u;
+  }
+  p1 = make_uint4(q1[0], q1[1], q1[2], q1[3]);
+  p2 = make_uint4(q2[0], q2[1], q2[2], q2[3]);
+}
+
 // acc += A B with A given as three fragment planes at w[0], w[64], w[128] (uint4 units, this lane's entry) and B as
 // the three planes of an exact split: smallest terms first
 __device__ __forceinline__ f32x16 mfma6(const uint4* w, const uint4& b1, const uint4& b2, const uint4& b3, f32x16 acc) {

@@ -57,10 +57,15 @@ constexpr int GL_ROW = 144;        // bytes of one frame of one plane of the con
 
 __device__ __forceinline__ float prelu2(float v, float slope) { return v > 0.f ? v : slope * v; }
 
-// NP = 3: exact three-way splits, six products; NP = 1: plain bf16 operands, one product (the opt-in bf16 mode, round 3)
+// NP = 3: exact three-way splits, six products; NP = 1: plain bf16 operands, one product (the opt-in bf16 mode, round 3);
+// NP = 2 (round 4): fp16 hi + lo of the power-of-two scaled operands, three f16 products (gconv_common.h: split8h)
 template <int NP>
 __device__ __forceinline__ f32x16 mfma6r(const uint4 (&a)[NP], const uint4 (&b)[NP], f32x16 acc) {
-  if constexpr (NP == 3) {
+  if constexpr (NP == 2) {
+    acc = mfma_f16(a[1], b[0], acc);
+    acc = mfma_f16(a[0], b[1], acc);
+    acc = mfma_f16(a[0], b[0], acc);
+  } else if constexpr (NP == 3) {
     acc = mfma_bf16(a[0], b[2], acc);
     acc = mfma_bf16(a[2], b[0], acc);
     acc = mfma_bf16(a[1], b[1], acc);
@@ -82,13 +87,14 @@ __device__ __forceinline__ uint32_t pack_bf16_rne(const float a, const float b) 
   return c.u;
 }
 template <int NP>
-__device__ __forceinline__ void split8n(const float (&x)[8], uint4 (&p)[NP]) {
+__device__ __forceinline__ void split8n(const float (&x)[8], uint4 (&p)[NP], const float sc = 1.0f) {
   if constexpr (NP == 3) split8(x, p[0], p[1], p[2]);
+  else if constexpr (NP == 2) split8h(x, sc, p[0], p[1]);
   else p[0] = make_uint4(pack_bf16_rne(x[0], x[1]), pack_bf16_rne(x[2], x[3]), pack_bf16_rne(x[4], x[5]), pack_bf16_rne(x[6], x[7]));
 }
 
 template <int NP>
-__device__ __forceinline__ void split4n(const float (&x)[4], uint2 (&p)[NP]);
+__device__ __forceinline__ void split4n(const float (&x)[4], uint2 (&p)[NP], const float sc = 1.0f);
 // four values -> their three bf16 planes, 8 bytes each (element i in half i & 1 of dword i >> 1)
 __device__ __forceinline__ void split4(const float (&x)[4], uint2& p1, uint2& p2, uint2& p3) {
   uint32_t q[3][2];
@@ -108,9 +114,29 @@ __device__ __forceinline__ void split4(const float (&x)[4], uint2& p1, uint2& p2
   p3 = make_uint2(q[2][0], q[2][1]);
 }
 
+// four values * sc -> fp16 hi / lo planes, 8 bytes each
+__device__ __forceinline__ void split4h(const float (&x)[4], const float sc, uint2& p1, uint2& p2) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+  uint32_t q1[2], q2[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const f32x2 t = {x[2 * i] * sc, x[2 * i + 1] * sc};
+    union { f16x2 h; uint32_t u; } hi, lo;
+    hi.h = __builtin_convertvector(t, f16x2);
+    const f32x2 r = t - __builtin_convertvector(hi.h, f32x2);
+    lo.h = __builtin_convertvector(r, f16x2);
+    q1[i] = hi.u;
+    q2[i] = lo.u;
+  }
+  p1 = make_uint2(q1[0], q1[1]);
+  p2 = make_uint2(q2[0], q2[1]);
+}
+
 template <int NP>
-__device__ __forceinline__ void split4n(const float (&x)[4], uint2 (&p)[NP]) {
+__device__ __forceinline__ void split4n(const float (&x)[4], uint2 (&p)[NP], const float sc) {
   if constexpr (NP == 3) split4(x, p[0], p[1], p[2]);
+  else if constexpr (NP == 2) split4h(x, sc, p[0], p[1]);
   else p[0] = make_uint2(pack_bf16_rne(x[0], x[1]), pack_bf16_rne(x[2], x[3]));
 }
 
@@ -145,6 +171,12 @@ __device__ __forceinline__ void tcm2_block(const pdse_tcm2_desc& d, float* const
   const int col = lane & 31, hh = lane >> 5;
   const int b = blockIdx.y, t0 = (blockIdx.x * TW + team) * (32 * NT), T = d.T, TP = T + 2 * HS_PAD;
   const bool chain = d.hs_out != nullptr;
+  // NP == 2 (f16x2): planes hold value * 2^PDSE_F16_ACT_EXP, the weights of the branches / conv2 / the next conv1 were scaled by
+  // 2^qexp[0..2] on the host; an accumulator holds (true value) * 2^(PE + q) and is brought back where it meets fp32 operands
+  constexpr int PE = NP == 2 ? PDSE_F16_ACT_EXP : 0;
+  [[maybe_unused]] const float s_pl = pow2i(PE), s_A = pow2i(-(PE + (NP == 2 ? d.qexp[0] : 0))), s_2 = pow2i(-(PE + (NP == 2 ? d.qexp[1] : 0))),
+                               s_N = pow2i(-(PE + (NP == 2 ? d.qexp[2] : 0)));
+  if constexpr (NP == 2) f16_saturate_mode();
 #ifdef PDSE_DIAG
   long long* trace = (HSA == 0) ? g_trace : nullptr;
 #else
@@ -297,12 +329,15 @@ __device__ __forceinline__ void tcm2_block(const pdse_tcm2_desc& d, float* const
       for (int i = 0; i < 4; ++i) {
         const int c = 4 * cg + i;
         const f32x4 gp = *(const f32x4*)&par[4 * c];
-        const float m = (part[n][0][c][f] + part[n][1][c][f]) + gp[0];
-        const float k = (part[n][2][c][f] + part[n][3][c][f]) + gp[1];
+        float m = part[n][0][c][f] + part[n][1][c][f];
+        float k = part[n][2][c][f] + part[n][3][c][f];
+        if constexpr (NP == 2) m *= s_A, k *= s_A;
+        m += gp[0];
+        k += gp[1];
         v[i] = gp[2] * prelu2(m * sigmoid_f(k), d.slope2) + gp[3];
       }
       uint2 pp[NP];
-      split4n<NP>(v, pp);
+      split4n<NP>(v, pp, s_pl);
       char* g = gls[n] + f * GL_ROW + cg * 8;
 #pragma unroll
       for (int p = 0; p < NP; ++p) *(uint2*)(g + p * 32 * GL_ROW) = pp[p];
@@ -330,7 +365,10 @@ __device__ __forceinline__ void tcm2_block(const pdse_tcm2_desc& d, float* const
 #pragma unroll
       for (int n = 0; n < NT; ++n)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a2[n][4 * r4 + i] += bb[i] + xres[n][4 * r4 + i];
+        for (int i = 0; i < 4; ++i) {
+          if constexpr (NP == 2) a2[n][4 * r4 + i] = a2[n][4 * r4 + i] * s_2 + (bb[i] + xres[n][4 * r4 + i]);
+          else a2[n][4 * r4 + i] += bb[i] + xres[n][4 * r4 + i];
+        }
     }
   } else {
     const __amdgpu_buffer_rsrc_t r_x = make_rsrc(d.x + ((size_t)b * 256 + 32 * wave) * T, (uint32_t)(32 * T * 4));
@@ -380,7 +418,7 @@ __device__ __forceinline__ void tcm2_block(const pdse_tcm2_desc& d, float* const
 #pragma unroll
       for (int j = 0; j < 8; ++j) xv[j] = a2[n][8 * s + j];
       uint4 bp[NP];
-      split8n<NP>(xv, bp);
+      split8n<NP>(xv, bp, s_pl);
       a1[n][0] = mfma6r<NP>(wn[0][s], bp, a1[n][0]);
       a1[n][1] = mfma6r<NP>(wn[1][s], bp, a1[n][1]);
     }
@@ -417,7 +455,9 @@ __device__ __forceinline__ void tcm2_block(const pdse_tcm2_desc& d, float* const
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int c = 8 * cg + i;
-        const float s = ((part[n][0][c][f] + part[n][1][c][f]) + (part[n][2][c][f] + part[n][3][c][f])) + par[512 + c];
+        float s = (part[n][0][c][f] + part[n][1][c][f]) + (part[n][2][c][f] + part[n][3][c][f]);
+        if constexpr (NP == 2) s *= s_N;
+        s += par[512 + c];
         const f32x4 xp = *(const f32x4*)&par[576 + 4 * c];
         vm[i] = xp[0] * prelu2(s, d.slope_main_next) + xp[1];
         vk[i] = xp[2] * prelu2(s, d.slope_mask_next) + xp[3];
@@ -425,10 +465,10 @@ __device__ __forceinline__ void tcm2_block(const pdse_tcm2_desc& d, float* const
       const int plane = TP * 16;
       const uint32_t ho = (uint32_t)(cg * NP * plane + (t + HS_PAD) * 16);
       uint4 pq[NP];
-      split8n<NP>(vm, pq);
+      split8n<NP>(vm, pq, s_pl);
 #pragma unroll
       for (int p = 0; p < NP; ++p) bstore16<TCM2_ST_AUX>(pq[p], r_ho, ho, p * plane);
-      split8n<NP>(vk, pq);
+      split8n<NP>(vk, pq, s_pl);
 #pragma unroll
       for (int p = 0; p < NP; ++p) bstore16<TCM2_ST_AUX>(pq[p], r_ho, ho, (8 * NP + p) * plane);
     }
@@ -555,7 +595,7 @@ int pdse_tcm2s_launch(const pdse_tcm2s_desc* d, hipStream_t s) {
   REQ(d && d->flags && d->status, "tcm2s: null pointer");
   REQ(d->n >= 1 && d->n <= PDSE_TCM2S_MAX, "tcm2s: 1 .. PDSE_TCM2S_MAX blocks");
   const int B = d->blk[0].B, T = d->blk[0].T, np = d->blk[0].np ? d->blk[0].np : 3;
-  REQ(B > 0 && B <= 65535 && T > 0 && (np == 3 || np == 1), "tcm2s: bad sizes");
+  REQ(B > 0 && B <= 65535 && T > 0 && (np == 3 || np == 2 || np == 1), "tcm2s: bad sizes");
   for (int i = 0; i < d->n; ++i) {
     const pdse_tcm2_desc& k = d->blk[i];
     REQ(k.x && k.par && k.B == B && k.T == T && (k.np ? k.np : 3) == np, "tcm2s: blocks of one stack share B, T and the plane count");
@@ -573,6 +613,7 @@ int pdse_tcm2s_launch(const pdse_tcm2s_desc* d, hipStream_t s) {
   if (pdse_check_hip(hipMemsetAsync(d->flags, 0, (size_t)B * ntiles * sizeof(int), s), "tcm2s: memset")) return 1;
   const dim3 grid(ntiles, B);
   if (np == 1) hipLaunchKernelGGL((tcm2s_kernel<1>), grid, dim3(512), 0, s, *d);
+  else if (np == 2) hipLaunchKernelGGL((tcm2s_kernel<2>), grid, dim3(512), 0, s, *d);
   else hipLaunchKernelGGL((tcm2s_kernel<3>), grid, dim3(512), 0, s, *d);
   return pdse_check_launch("tcm2s");
 }
@@ -591,8 +632,12 @@ int pdse_tcm2_launch(const pdse_tcm2_desc* d, hipStream_t s) {
   // workgroup shape 10 NT + TW.  Measured at B=32, T=401 (us per forward, 18 blocks): 11 -> 592, 21 (64 frames, two
   // tiles per wave) -> 730, 12 (64 frames, two teams of 8 waves) -> 769: the shapes that halve the weight bytes per
   // CU lose more to their longer dependent chains / simultaneous identical requests.  PDSE_TCM2_SHAPE: ablation.
-  REQ(d->np == 0 || d->np == 3 || d->np == 1, "tcm2: np is 3 (exact splits; 0 means 3) or 1 (plain bf16)");
+  REQ(d->np == 0 || d->np == 3 || d->np == 2 || d->np == 1, "tcm2: np is 3 (exact splits; 0 means 3), 2 (f16x2) or 1 (plain bf16)");
   if (d->np == 1) return launch_tcm2<1, 1, 1>(d, s);   // the opt-in bf16 mode
+  if (d->np == 2) {
+    REQ(d->qexp[0] >= -40 && d->qexp[0] <= 40 && d->qexp[1] >= -40 && d->qexp[1] <= 40 && d->qexp[2] >= -40 && d->qexp[2] <= 40, "tcm2: qexp out of range");
+    return launch_tcm2<1, 1, 2>(d, s);
+  }
   static const int force = PDSE_DIAG_ENV("PDSE_TCM2_SHAPE") ? atoi(PDSE_DIAG_ENV("PDSE_TCM2_SHAPE")) : 0;
   const int shape = force ? force : 11;
   switch (shape) {

@@ -94,7 +94,8 @@ class Ctx:
 class PlanBase:
     force_generic = False   # tests: route every convolution through the un-pipelined kernel
     gemm_planes = 3         # operand planes of the GEMM-shaped convolutions (csrc/gconv4.hip): 3 = exact three-way bf16 split
-                            # (korder 3), 1 = plain bf16, one product (korder 4: the opt-in bf16 mode, its own tolerance)
+                            # (korder 3), 2 = fp16 hi + lo of the scaled operands (korder 5, f16x2: fp32-equivalent), 1 = plain
+                            # bf16, one product (korder 4: the opt-in bf16 mode, its own tolerance)
 
     def __init__(self, ctx, plan=None, ns=()):
         self.ctx = ctx
@@ -177,9 +178,11 @@ class PlanBase:
         up = lambda a: ctx.up(a).data_ptr()   # noqa: E731
         up16 = lambda a: ctx.up(np.ascontiguousarray(a).view(np.int16), np.int16).data_ptr()   # noqa: E731
         npl = self.gemm_planes
-        f = {"korder": 3 if npl == 3 else 4, "ksteps": ntaps * (c0 + c1) // 2, "w0": up16(P.pack_s3_gemm(w["wk0"], ntaps, c0, c1, npl))}
+        qe = P.f16_wexp(*[w[k_] for k_ in ("wk0", "wk1") if w.get(k_) is not None]) if npl == 2 else 0     # f16x2: one exponent per launch
+        f = {"korder": {3: 3, 1: 4, 2: 5}[npl], "ksteps": ntaps * (c0 + c1) // 2, "w0": up16(P.pack_s3_gemm(w["wk0"], ntaps, c0, c1, npl, qe)),
+             "wexp": qe}
         if w.get("wk1") is not None:
-            f["w1"] = up16(P.pack_s3_gemm(w["wk1"], ntaps, c0, c1, npl))
+            f["w1"] = up16(P.pack_s3_gemm(w["wk1"], ntaps, c0, c1, npl, qe))
         for k in ("bias0", "bias1"):
             if w.get(k) is not None:
                 f[k] = up(w[k])
@@ -369,7 +372,13 @@ class EpsNetPlan(PlanBase):
     # built with exclusive=True (see __init__).
     tcm_stack = True
     parity_planes = True    # the encoders' plane tensors with their bins split by parity (contiguous stride-2 taps; pdse_bglu_desc.hp_par)
-    planes = 3              # 3: exact three-way bf16 split (fp32-equivalent); 1: plain bf16 operands (the opt-in bf16 mode)
+    # operand planes of the block kernels (csrc/bglu.hip) and of their plane tensors - 3: exact three-way bf16 split, six bf16 products
+    # per multiply-add; 2: fp16 hi + lo of the power-of-two scaled operand ("f16x2": within half an fp32 ulp inside the fp16 window,
+    # three f16 products; include/pdse.h PDSE_F16_ACT_EXP) - both fp32-equivalent, held to the same goldens and tolerances;
+    # 1: plain bf16 operands (the opt-in bf16 mode, its own tolerance).  Default since round 4: 2 (profiles/r04_*: the same launches
+    # in 0.69 of the three-plane form's time, parity margins equal or better)
+    planes = 2
+    TCM_F16 = True          # with planes 2 the TCM stack runs its two-plane form too (False: it keeps the three-plane split)
     NSLOT = 20  # 15 stages + en1 real-row bias + 4 composed encoder-stage-1 biases (l/r x frame >= 1 / frame 0)
 
     def __init__(self, ctx, sd, B, T, time_cond=True, nsteps=1, plan=None, table=None, with_pre=None, split_bf16=None,
@@ -385,11 +394,14 @@ class EpsNetPlan(PlanBase):
         if split_bf16 is not None:
             self.split_bf16 = bool(split_bf16)
         if planes is not None:
+            if int(planes) not in (1, 2, 3):
+                raise ValueError("planes is 3 (bf16x3), 2 (f16x2) or 1 (bf16 mode)")
             self.planes = int(planes)
         if plane_h is not None:
             self.plane_h = bool(plane_h)
         if self.planes == 1:
             self.plane_h = True
+        self.tcm_planes = 3 if (self.planes == 2 and not self.TCM_F16) else self.planes
         self.use_tcm_stack = bool(self.tcm_stack and exclusive)
         self.sd = sd
         ok = (self.split_bf16 and self.chain_conv1 and self.compose_stage1 and time_cond and with_pre and not self.force_generic
@@ -398,6 +410,8 @@ class EpsNetPlan(PlanBase):
             if self.planes == 1:
                 raise ValueError("bf16 mode needs the chained split-bf16 DiffUNet1 path (PReLU slopes <= 1)")
             self.plane_h = False
+            if self.planes == 2:       # the csrc/gconv3.hip fallback knows the three-plane split only
+                self.planes = self.tcm_planes = 3
         super().__init__(ctx, plan, ns=(ctx.bank.token(sd), bool(time_cond), bool(with_pre), self.fused_tcm, self.chain_conv1,
                                         self.compose_stage1, self.split_bf16, self.split_tcm,
                                         ctx.bank.token(table), str(self.plane_h), self.planes, self.parity_planes))
@@ -416,7 +430,7 @@ class EpsNetPlan(PlanBase):
         self.tcm_a, self.tcm_b = a(B, 256, T), a(B, 256, T)
         self.tcm_h, self.tcm_g = a(B, 64, T), a(B, 64, T)
         # the same bottleneck tensor as the split-bf16 blocks exchange it (pdse_tcm2_desc.hs; its margins stay zero)
-        self.tcm_hs = [ctx.alloc_u16(*P.tcm2_hs_shape(B, T, self.planes)) for _ in range(2)]
+        self.tcm_hs = [ctx.alloc_u16(*P.tcm2_hs_shape(B, T, self.tcm_planes)) for _ in range(2)]
         self._tcm_stack = None
         self.tcm_flags = torch.zeros(B * ((T + 31) // 32), dtype=torch.int32, device=ctx.device)   # progress counters of the stack launch
         self.tcm_status = torch.zeros(4, dtype=torch.int32, device=ctx.device)                     # [0]: 0, or block + 1 a workgroup gave up at
@@ -758,34 +772,41 @@ class EpsNetPlan(PlanBase):
             up16 = lambda a: self.ctx.up(np.asarray(a).view(np.int16), np.int16).data_ptr()   # noqa: E731
             par = np.zeros(832, np.float32)
             f = dict(slope2=0.0, slope_main_next=0.0, slope_mask_next=0.0)
+            npl = self.tcm_planes
+            qof = (lambda *m: P.f16_wexp(*m)) if npl == 2 else (lambda *m: 0)     # f16x2: one power-of-two exponent per weight group
+            qA = q2 = qN = 0
             if mode == 0:
                 kmain, kmask = self._tcm_branch_mats(p)
                 s2, h2 = P.bn_fold(self.sd, p + ".conv2.1")
                 par[:256] = np.stack([self.w(p + ".mainbranch.2.bias"), self.w(p + ".maskbranch.2.bias"), s2, h2], 1).reshape(-1)
                 par[256:512] = self.w(p + ".conv2.2.bias")
-                f.update(wbr=up16(P.pack_tcm2_branch(kmain, kmask, self.planes)),
-                         wc2=up16(P.pack_tcm2_conv2(self.w(p + ".conv2.2.weight")[:, :, 0].T, self.planes)),
+                k2 = self.w(p + ".conv2.2.weight")[:, :, 0].T
+                qA, q2 = qof(kmain, kmask), qof(k2)
+                f.update(wbr=up16(P.pack_tcm2_branch(kmain, kmask, npl, qA)), wc2=up16(P.pack_tcm2_conv2(k2, npl, q2)),
                          slope2=float(self.w(p + ".conv2.0.weight")[0]))
             if p_next is not None:
                 sm, hm = P.bn_fold(self.sd, p_next + ".mainbranch.1")
                 sk, hk = P.bn_fold(self.sd, p_next + ".maskbranch.1")
                 par[512:576] = self.w(p_next + ".conv1.bias")
                 par[576:] = np.stack([sm, hm, sk, hk], 1).reshape(-1)
-                f.update(wn1=up16(P.pack_bglu_chain(self.w(p_next + ".conv1.weight")[:, :, 0], self.planes)),
+                wn1 = self.w(p_next + ".conv1.weight")[:, :, 0]
+                qN = qof(wn1)
+                f.update(wn1=up16(P.pack_bglu_chain(wn1, npl, qN)),
                          slope_main_next=float(self.w(p_next + ".mainbranch.0.weight")[0]),
                          slope_mask_next=float(self.w(p_next + ".maskbranch.0.weight")[0]))
             f["par"] = self.ctx.up(par).data_ptr()
+            f["qexp"] = (qA, q2, qN)
             return f
 
         d = L.Tcm2Desc()
-        for k, v in self.memo("%s.split%d.np%d" % (p if mode == 0 else p_next, mode, self.planes), make).items():
+        for k, v in self.memo("%s.split%d.np%d" % (p if mode == 0 else p_next, mode, self.tcm_planes), make).items():
             setattr(d, k, v)
         d.x = xin.data_ptr()
         if mode == 0:
             d.x_out, d.hs = xout.data_ptr(), hin.data_ptr()
         if p_next is not None:
             d.hs_out = hout.data_ptr()
-        d.dil, d.B, d.T, d.mode, d.np = dil, self.B, self.T, mode, self.planes
+        d.dil, d.B, d.T, d.mode, d.np = dil, self.B, self.T, mode, self.tcm_planes
         if mode == 0 and self._tcm_stack is not None:
             self._tcm_stack.append(d)          # collected: one pdse_tcm2s_desc for the whole stack (build_step)
         else:
@@ -799,28 +820,39 @@ class EpsNetPlan(PlanBase):
         return self.plane_h is True
 
     def _bglu_weights(self, p, transposed, C2, bn_prefix, gather, nx_w):
-        """Weight side of one pdse_bglu_desc: gather = dict(w0, w1[, w2, w3]) already packed; folds -log2 e into
-        l_conv / r_conv and the BatchNorm behind the block into conv2 (float64), packs the chained tiles."""
+        """Weight side of one pdse_bglu_desc: gather = dict(w0, w1[, w2, w3]) of k-major matrices (ntaps x 32 rows; the
+        composed stage 1: 40 rows); folds -log2 e into l_conv / r_conv and the BatchNorm behind the block into conv2
+        (float64), packs the gather weights and the chained tiles.  Plane count 2 (f16x2): every weight group is scaled by its
+        own power of two before the split (packing.f16_wexp; pdse_bglu_desc.qexp)."""
         npl = self.planes
         ctx = self.ctx
         up = lambda a_: ctx.up(a_).data_ptr()   # noqa: E731
         up16 = lambda a_: ctx.up(np.ascontiguousarray(a_).view(np.int16), np.int16).data_ptr()   # noqa: E731
+        qof = (lambda *m: P.f16_wexp(*m)) if npl == 2 else (lambda *m: 0)
         ch = self._chain(p, C2, transposed)
-        f = {k: up16(v) for k, v in gather.items()}
-        f["wlc"] = up16(P.pack_bglu_chain(-P.LOG2E * np.asarray(ch["wlc"], np.float64), npl))
-        f["wrc"] = up16(P.pack_bglu_chain(-P.LOG2E * np.asarray(ch["wrc"], np.float64), npl))
+        qG = qof(*gather.values())
+        f = {k: up16(P.pack_bglu_in4(v, npl, qG) if v.shape[0] == 40 else P.pack_bglu_gather(v, v.shape[0] // 32, npl, qG))
+             for k, v in gather.items()}
+        wlc, wrc = (-P.LOG2E * np.asarray(ch[k_], np.float64) for k_ in ("wlc", "wrc"))
+        qLC = qof(wlc, wrc)
+        f["wlc"] = up16(P.pack_bglu_chain(wlc, npl, qLC))
+        f["wrc"] = up16(P.pack_bglu_chain(wrc, npl, qLC))
         f["blc"] = up(-P.LOG2E * np.asarray(ch["blc"], np.float64))
         f["brc"] = up(-P.LOG2E * np.asarray(ch["brc"], np.float64))
         wc2, bc2 = np.asarray(ch["wc2"], np.float64), np.asarray(ch["bc2"], np.float64)
         if bn_prefix is not None:                       # y = (Wc2 g + bc2) s + t = (diag(s) Wc2) g + (s bc2 + t)
             sc, sh = (np.asarray(v, np.float64) for v in P.bn_fold(self.sd, bn_prefix))
             wc2, bc2 = wc2 * sc[:, None], bc2 * sc + sh
+        qC2 = qNX = 0
         if C2 == 1:
             f["wc2v"], f["bc2"] = up(wc2.reshape(32)), up(np.concatenate([bc2.reshape(1), np.zeros(63)]))
         else:
-            f["wc2"], f["bc2"] = up16(P.pack_bglu_chain(wc2, npl)), up(bc2)
+            qC2 = qof(wc2)
+            f["wc2"], f["bc2"] = up16(P.pack_bglu_chain(wc2, npl, qC2)), up(bc2)
         if nx_w:
-            f["nx_w"] = up16(np.stack([P.pack_bglu_chain(w, npl)[0] for w in nx_w], 0))
+            qNX = qof(*nx_w)
+            f["nx_w"] = up16(np.stack([P.pack_bglu_chain(w, npl, qNX)[0] for w in nx_w], 0))
+        f["qexp"] = (qG, qLC, qC2, qNX)
         return f
 
     def _bglu(self, label, make, *, hp=None, F_in=None, x0=None, x1=None, taps, sf_in, Fout, p1mask=0, Fout1=0, slope, C2,
@@ -905,14 +937,13 @@ class EpsNetPlan(PlanBase):
                     W1 = self.w(p + ".conv1.weight")[:, :, 0, 0] @ self.w("preprocess.conv.weight")[:, :, 0, 0]   # [32, 4]
                     comp = {br: np.einsum("ockf,ci->oikf", self.w("%s.%s.weight" % (p, br)).astype(np.float64), W1.astype(np.float64))
                             for br in ("l", "r")}
-                    g = dict(w0=P.pack_bglu_in4(P.conv_kmat(comp["l"], kk), npl), w1=P.pack_bglu_in4(P.conv_kmat(comp["r"], kk), npl))
+                    g = dict(w0=P.conv_kmat(comp["l"], kk), w1=P.conv_kmat(comp["r"], kk))
                     return self._bglu_weights(p, False, 64, "en.en1.0", g, nx_weights())
                 bias = (tb, slot(16), slot(18), slot(17), slot(19), sbb)
                 src = dict(x0=self.src(x, 2, *nchw(2, T, F0)), x1=self.src(x_init, 2, *nchw(2, T, F0)), F_in=F0)
             else:
                 def make(p=p, kk=kk, k=k, nx_weights=nx_weights):
-                    g = dict(w0=P.pack_bglu_gather(P.conv_kmat(self.sd[p + ".l.weight"], kk), len(kk), npl),
-                             w1=P.pack_bglu_gather(P.conv_kmat(self.sd[p + ".r.weight"], kk), len(kk), npl))
+                    g = dict(w0=P.conv_kmat(self.sd[p + ".l.weight"], kk), w1=P.conv_kmat(self.sd[p + ".r.weight"], kk))
                     f = self._bglu_weights(p, False, 64, "en.en%d.0" % k, g, nx_weights())
                     f["bias0"], f["bias1"] = self.ctx.up(self.w(p + ".l.bias")).data_ptr(), self.ctx.up(self.w(p + ".r.bias")).data_ptr()
                     return f
@@ -957,10 +988,8 @@ class EpsNetPlan(PlanBase):
                 bn = "%s.de%d.2" % (de, k) if k > 1 else None
 
                 def make(p=p, k=k, de=de, kk0=kk0, kk1=kk1, C2=C2, bn=bn):
-                    g = dict(w0=P.pack_bglu_gather(P.convT_kmat(self.sd[p + ".l.weight"], kk0), len(kk0), npl),
-                             w1=P.pack_bglu_gather(P.convT_kmat(self.sd[p + ".r.weight"], kk0), len(kk0), npl),
-                             w2=P.pack_bglu_gather(P.convT_kmat(self.sd[p + ".l.weight"], kk1), len(kk1), npl),
-                             w3=P.pack_bglu_gather(P.convT_kmat(self.sd[p + ".r.weight"], kk1), len(kk1), npl))
+                    g = dict(w0=P.convT_kmat(self.sd[p + ".l.weight"], kk0), w1=P.convT_kmat(self.sd[p + ".r.weight"], kk0),
+                             w2=P.convT_kmat(self.sd[p + ".l.weight"], kk1), w3=P.convT_kmat(self.sd[p + ".r.weight"], kk1))
                     nxw = [self.w("%s.de%d.0.conv1.weight" % (de, k - 1))[:, :, 0, 0].T[:, :64]] if k > 1 else []
                     f = self._bglu_weights(p, True, C2, bn, g, nxw)
                     f["bias0"], f["bias1"] = self.ctx.up(self.w(p + ".l.bias")).data_ptr(), self.ctx.up(self.w(p + ".r.bias")).data_ptr()
@@ -1142,7 +1171,8 @@ class EpsNetPlan(PlanBase):
 class GcrnPlan(PlanBase):
     fused_last = True       # last decoder stage + Linear(161,161) as one persistent launch (pdse_gcrnlast_desc)
     fused_glstm = True      # both LSTM layers + LayerNorm 1 as a layer wavefront, T + 2 launches (pdse_glstm_desc)
-    split_bf16 = True       # gated (transposed) convolutions and the LSTM input projection as split-bf16 GEMMs (csrc/gconv4.hip)
+    split_bf16 = True       # gated (transposed) convolutions and the LSTM input projection as split-operand GEMMs (csrc/gconv4.hip)
+    gemm_planes = 2         # ... in the f16x2 form (korder 5; 3: the three-plane bf16 split, korder 3 - both fp32-equivalent)
     block8 = True           # tensors between those GEMMs in blocks of 8 channels (16-byte gathers and stores)
     persist_lstm = True     # B <= PERSIST_MAX_B and a plan that owns the GPU while it runs: the grouped LSTM as ONE persistent
                             # launch with register-resident weights (pdse_glstmp_desc, csrc/lstmp.hip) instead of T + 2 launches
@@ -1151,7 +1181,8 @@ class GcrnPlan(PlanBase):
     ENC_F = [161, 80, 39, 19, 9, 4]
 
     def __init__(self, ctx, sd, B, T, plan=None, split_bf16=None, exclusive=False, planes=None):
-        """planes 1: the opt-in bf16 mode - the gated (transposed) convolutions and the LSTM input projection multiply plain
+        """planes 3 / 2: the fp32-equivalent operand splits of the GEMM-shaped convolutions (bf16x3: korder 3; f16x2: korder 5, the
+        default); planes 1: the opt-in bf16 mode - the gated (transposed) convolutions and the LSTM input projection multiply plain
         bf16 operands (csrc/gconv4.hip, korder 4); tensors, LSTM and the last stage stay fp32.
         exclusive: nothing else runs on the GPU beside this plan (one batch in flight) - the condition under which the
         persistent LSTM may be used (its 256 workgroups wait for each other and must all be resident).  Off by default: a
@@ -1160,8 +1191,8 @@ class GcrnPlan(PlanBase):
         if split_bf16 is not None:
             self.split_bf16 = bool(split_bf16)
         if planes is not None:
-            if planes not in (1, 3) or (planes == 1 and not self.split_bf16):
-                raise ValueError("planes is 3 or 1; the one-plane bf16 mode runs on the GEMM kernels (split_bf16)")
+            if planes not in (1, 2, 3) or (planes in (1, 2) and not self.split_bf16):
+                raise ValueError("planes is 3 (bf16x3), 2 (f16x2) or 1 (bf16 mode); the one- and two-plane forms run on the GEMM kernels (split_bf16)")
             self.gemm_planes = int(planes)
         self.persist = bool(self.persist_lstm and self.fused_glstm and exclusive and B <= self.PERSIST_MAX_B and not self.force_generic)
         super().__init__(ctx, plan, ns=(ctx.bank.token(sd), self.fused_last, self.fused_glstm, self.split_bf16, self.block8, self.persist,

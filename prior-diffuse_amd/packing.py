@@ -304,7 +304,7 @@ def rho_bf16(s, j, h):
     return (r & 3) + 8 * (r >> 2) + 4 * h
 
 
-def pack_s3_gather(wk, ntaps, cin=32, npl=3):
+def pack_s3_gather(wk, ntaps, cin=32, npl=3, qe=0):
     """wk [ntaps*cin, 32] (k = tap*cin + c, k-major) -> uint16 [ntaps*cin/16 blocks][npl planes][64 lanes][8]:
     block tap*(cin/16) + q, lane (row = lane & 31, h = lane >> 5), element j = wk[tap*cin + 16q + 8h + j][row].
     npl 3: exact three-way bf16 split; 1: the RNE bf16 value (bf16 mode)."""
@@ -316,15 +316,17 @@ def pack_s3_gather(wk, ntaps, cin=32, npl=3):
     frag = frag.reshape(nb, 64, 8)
     if npl == 1:
         return np.ascontiguousarray(bf16_rne(frag)[:, None])             # [nb, 1, 64, 8]
+    if npl == 2:                                                         # f16x2: fp16 hi + lo of frag * 2^qe
+        return np.ascontiguousarray(np.stack(split_f16x2(np.ldexp(frag, qe)), 1))
     p = split_bf16x3(frag)
     return np.ascontiguousarray(np.stack(p, 1))                          # [nb, 3, 64, 8]
 
 
-def unpack_s3_gather(packed, ntaps, cin=32):
+def unpack_s3_gather(packed, ntaps, cin=32, qe=0):
     packed = np.asarray(packed, np.uint16)
     npl = packed.size // (ntaps * cin // 16 * 512)
     packed = packed.reshape(ntaps * cin // 16, npl, 2, 32, 8)                          # [nb, plane, h, row, j]
-    f = sum(bf16_to_f32(packed[:, i]) for i in range(npl))                             # [nb, h, row, j]
+    f = from_planes(packed.transpose(1, 0, 2, 3, 4), qe)                                # [nb, h, row, j]
     return f.transpose(0, 1, 3, 2).reshape(ntaps * cin, 32)                             # k = 16 nb + 8h + j
 
 
@@ -365,27 +367,27 @@ def tcm2_hs_shape(B, T, npl=3):
     return (B, 2, 4, 2, npl, T + 2 * TCM2_HS_PAD, 8)
 
 
-def pack_tcm2_branch(k_main, k_mask, npl=3):
+def pack_tcm2_branch(k_main, k_mask, npl=3, qe=0):
     """k_* [320, 64] (row = tap*64 + channel) -> uint16 [2 main|mask][2 mi][20 blocks][npl][64][8]."""
-    return np.ascontiguousarray(np.stack([np.stack([pack_s3_gather(np.asarray(k)[:, 32 * mi:32 * mi + 32], 5, 64, npl)
+    return np.ascontiguousarray(np.stack([np.stack([pack_s3_gather(np.asarray(k)[:, 32 * mi:32 * mi + 32], 5, 64, npl, qe)
                                                     for mi in range(2)]) for k in (k_main, k_mask)]))
 
 
-def unpack_tcm2_branch(packed):
+def unpack_tcm2_branch(packed, qe=0):
     packed = np.asarray(packed, np.uint16)
     packed = packed.reshape(2, 2, 20, packed.size // (2 * 2 * 20 * 512), 64, 8)
-    return [np.concatenate([unpack_s3_gather(packed[br, mi], 5, 64) for mi in range(2)], axis=1) for br in range(2)]
+    return [np.concatenate([unpack_s3_gather(packed[br, mi], 5, 64, qe) for mi in range(2)], axis=1) for br in range(2)]
 
 
-def pack_tcm2_conv2(k2, npl=3):
+def pack_tcm2_conv2(k2, npl=3, qe=0):
     """k2 [64, 256] (row = gate channel) -> uint16 [8 mt][4 kb][npl][64][8]."""
-    return np.ascontiguousarray(np.stack([pack_s3_gather(np.asarray(k2)[:, 32 * mt:32 * mt + 32], 1, 64, npl) for mt in range(8)]))
+    return np.ascontiguousarray(np.stack([pack_s3_gather(np.asarray(k2)[:, 32 * mt:32 * mt + 32], 1, 64, npl, qe) for mt in range(8)]))
 
 
-def unpack_tcm2_conv2(packed):
+def unpack_tcm2_conv2(packed, qe=0):
     packed = np.asarray(packed, np.uint16)
     packed = packed.reshape(8, 4, packed.size // (8 * 4 * 512), 64, 8)
-    return np.concatenate([unpack_s3_gather(packed[mt], 1, 64) for mt in range(8)], axis=1)
+    return np.concatenate([unpack_s3_gather(packed[mt], 1, 64, qe) for mt in range(8)], axis=1)
 
 
 def tcm2_split_h(v_main, v_mask, npl=3):
@@ -393,7 +395,7 @@ def tcm2_split_h(v_main, v_mask, npl=3):
     B, C, T = v_main.shape
     hs = np.zeros(tcm2_hs_shape(B, T, npl), np.uint16)
     for br, v in enumerate((v_main, v_mask)):
-        p = to_planes(np.asarray(v, np.float32).reshape(B, 4, 2, 8, T).transpose(0, 1, 2, 4, 3), npl)   # [npl][B, kb, kg, T, j]
+        p = to_planes(np.asarray(v, np.float32).reshape(B, 4, 2, 8, T).transpose(0, 1, 2, 4, 3), npl, F16_ACT_EXP)   # [npl][B, kb, kg, T, j]
         for i in range(npl):
             hs[:, br, :, :, i, TCM2_HS_PAD:TCM2_HS_PAD + T, :] = p[i]
     return hs
@@ -407,7 +409,7 @@ def tcm2_join_h(hs, B, T):
     assert not hs[..., :TCM2_HS_PAD, :].any() and not hs[..., TCM2_HS_PAD + T:, :].any(), "hs: the margins must stay zero"
     out = []
     for br in range(2):
-        v = sum(bf16_to_f32(hs[:, br, :, :, i, TCM2_HS_PAD:TCM2_HS_PAD + T, :]) for i in range(npl))    # [B, kb, kg, T, j]
+        v = from_planes(np.stack([hs[:, br, :, :, i, TCM2_HS_PAD:TCM2_HS_PAD + T, :] for i in range(npl)], 0), F16_ACT_EXP)    # [B, kb, kg, T, j]
         out.append(np.ascontiguousarray(v.transpose(0, 1, 2, 4, 3).reshape(B, 64, T)))
     return out
 
@@ -424,18 +426,21 @@ def s3_gemm_krows(ntaps, c0, c1):
     return np.asarray(rows, np.int64)
 
 
-def _pack_gemm_rows(ordered, npl):
-    """ordered [nkb*16, mt*32] (K rows already in K-step order) -> uint16 [nkb][mt][npl][64 lanes][8]."""
+def _pack_gemm_rows(ordered, npl, qe=0):
+    """ordered [nkb*16, mt*32] (K rows already in K-step order) -> uint16 [nkb][mt][npl][64 lanes][8] (npl 2: fp16 hi / lo of
+    the value * 2^qe)."""
     nkb, mt = ordered.shape[0] // 16, ordered.shape[1] // 32
     frag = ordered.reshape(nkb, 2, 8, mt, 32).transpose(0, 3, 1, 4, 2)    # [kb, mt, h, row, j]
     frag = frag.reshape(nkb, mt, 64, 8)
     if npl == 1:
         return np.ascontiguousarray(bf16_rne(frag)[:, :, None])           # [kb, mt, 1, 64, 8]
+    if npl == 2:
+        return np.ascontiguousarray(np.stack(split_f16x2(np.ldexp(frag.astype(np.float32), qe)), 2))
     p = split_bf16x3(frag)
     return np.ascontiguousarray(np.stack(p, 2))                           # [kb, mt, 3, 64, 8]
 
 
-def pack_s3_gemm(wk, ntaps, c0, c1, npl=3):
+def pack_s3_gemm(wk, ntaps, c0, c1, npl=3, qe=0):
     """wk [ntaps*(c0+c1), Cout] (k-major) -> uint16 [K blocks][ceil(Cout/32)][npl planes][64 lanes][8]
     (npl 3: exact three-way bf16 split, korder 3; 1: the RNE bf16 value, korder 4 - the opt-in bf16 mode)."""
     wk = np.asarray(wk, np.float64).astype(np.float32)
@@ -444,7 +449,7 @@ def pack_s3_gemm(wk, ntaps, c0, c1, npl=3):
     mt = (M + 31) // 32
     pad = np.zeros((K, mt * 32), np.float32)
     pad[:, :M] = wk
-    return _pack_gemm_rows(pad[s3_gemm_krows(ntaps, c0, c1)], npl)
+    return _pack_gemm_rows(pad[s3_gemm_krows(ntaps, c0, c1)], npl, qe)
 
 
 def dense_krows(cin):
@@ -465,11 +470,12 @@ def pack_dense(wk, cin, npl=3):
     return _pack_gemm_rows(wk[dense_krows(cin)], npl)
 
 
-def unpack_s3_gemm(packed, ntaps, c0, c1, M, npl=3):
+def unpack_s3_gemm(packed, ntaps, c0, c1, M, npl=3, qe=0):
     K = ntaps * (c0 + c1)
     mt = (M + 31) // 32
     packed = np.asarray(packed, np.uint16).reshape(K // 16, mt, npl, 2, 32, 8)    # [kb, mt, plane, h, row, j]
-    f = join_bf16x3([packed[:, :, i] for i in range(3)]) if npl == 3 else bf16_to_f32(packed[:, :, 0])   # [kb, mt, h, row, j]
+    f = (join_bf16x3([packed[:, :, i] for i in range(3)]) if npl == 3 else
+         from_planes(np.stack([packed[:, :, 0], packed[:, :, 1]], 0), qe) if npl == 2 else bf16_to_f32(packed[:, :, 0]))   # [kb, mt, h, row, j]
     ordered = f.transpose(0, 2, 4, 1, 3).reshape(K, mt * 32)                       # k within block = 8h + j
     out = np.zeros((K, mt * 32), np.float32)
     out[s3_gemm_krows(ntaps, c0, c1)] = ordered
@@ -493,16 +499,51 @@ def bf16_to_f32(u):
     return (np.asarray(u, np.uint16).astype(np.uint32) << np.uint32(16)).view(np.float32)
 
 
-def to_planes(frag, npl):
-    """float array [...] -> uint16 [npl, ...]: the exact three-way bf16 split (npl 3) or the RNE bf16 value (npl 1)."""
+# f16x2 operands (np == 2; include/pdse.h: PDSE_F16_ACT_EXP, csrc/gconv_common.h: split8h): a value, scaled by a power of two
+# into the fp16 range, is hi = RN16(x), lo = RN16(x - hi) - 22 significand bits and the sign of lo, |x - hi - lo| <= 2^-23 |x|
+# while lo is a normal fp16 - and a product is a1 b1 + a1 b2 + a2 b1 on the f16 matrix cores (fp32 accumulation).
+F16_ACT_EXP = 6            # activations: planes hold value * 2^6 (exact for 2^-8 <= |value| < 1023)
+F16_MAX = 65504.0
+
+
+def f16_wexp(*mats):
+    """Power-of-two exponent q for a group of weight matrices that share one accumulator: max |w| * 2^q in [2^13, 2^14), so
+    every weight down to 2^-16 of the largest keeps a normal lo part (the kernel undoes 2^q where it re-scales the
+    accumulator; exact)."""
+    m = max((float(np.max(np.abs(np.asarray(w, np.float64)))) if np.asarray(w).size else 0.0) for w in mats)
+    if not np.isfinite(m) or m <= 0.0:
+        return 0
+    return int(np.clip(13 - int(np.floor(np.log2(m))), -40, 40))
+
+
+def split_f16x2(x):
+    """float32 array (already scaled) -> (hi, lo) uint16 fp16 bit patterns: hi = RN16(x) saturated at +-65504 (what the
+    kernels' MODE.FP16_OVFL conversion does), lo = RN16(x - hi)."""
+    x = np.ascontiguousarray(x, np.float32)
+    hi = np.clip(x, -F16_MAX, F16_MAX).astype(np.float16)
+    lo = np.clip(x - hi.astype(np.float32), -F16_MAX, F16_MAX).astype(np.float16)      # beyond the window: lo saturates too
+    return hi.view(np.uint16), lo.view(np.uint16)
+
+
+def f16_to_f32(u):
+    return np.asarray(u, np.uint16).view(np.float16).astype(np.float32)
+
+
+def to_planes(frag, npl, q=0):
+    """float array [...] -> uint16 [npl, ...]: the exact three-way bf16 split (npl 3), the RNE bf16 value (npl 1), or the
+    fp16 hi / lo pair of frag * 2^q (npl 2)."""
     if npl == 3:
         return np.stack(split_bf16x3(frag), 0)
+    if npl == 2:
+        return np.stack(split_f16x2(np.ldexp(np.asarray(frag, np.float32), q)), 0)
     return bf16_rne(frag)[None]
 
 
-def from_planes(planes):
-    """Inverse of to_planes on a leading plane axis."""
+def from_planes(planes, q=0):
+    """Inverse of to_planes on a leading plane axis (two planes: fp16 hi + lo, scaled back by 2^-q)."""
     planes = np.asarray(planes, np.uint16)
+    if planes.shape[0] == 2:
+        return np.ldexp(f16_to_f32(planes[0]) + f16_to_f32(planes[1]), -q).astype(np.float32)
     return sum(bf16_to_f32(planes[i]) for i in range(planes.shape[0]))
 
 
@@ -532,7 +573,7 @@ def hp_split(x, npl):
     q, h, e = np.meshgrid(np.arange(2), np.arange(2), np.arange(8), indexing="ij")
     ch = bglu_chan(q, h, e).reshape(4, 8)                                   # [g, e]
     v = x[:, ch]                                                            # [B, g, e, T, F]
-    p = to_planes(v.transpose(0, 3, 1, 4, 2), npl)                          # [npl, B, T, g, F, e]
+    p = to_planes(v.transpose(0, 3, 1, 4, 2), npl, F16_ACT_EXP)             # [npl, B, T, g, F, e]
     hp[:, HP_T0:, :, :, HP_F0:HP_F0 + F, :] = p.transpose(1, 2, 3, 0, 4, 5)
     return hp
 
@@ -541,7 +582,7 @@ def hp_join(hp, with_margins=False):
     """hp uint16 -> float [B, 32, Tp, Fp] (with_margins) or [B, 32, T, F]."""
     hp = np.asarray(hp, np.uint16)
     B, Tp, _, npl, Fp, _ = hp.shape
-    v = from_planes(hp.transpose(3, 0, 1, 2, 4, 5))                         # [B, Tp, g, Fp, e]
+    v = from_planes(hp.transpose(3, 0, 1, 2, 4, 5), F16_ACT_EXP)            # [B, Tp, g, Fp, e]
     out = np.zeros((B, 32, Tp, Fp), np.float32)
     for g in range(4):
         for e in range(8):
@@ -549,7 +590,7 @@ def hp_join(hp, with_margins=False):
     return out if with_margins else out[:, :, HP_T0:, HP_F0:Fp - HP_F0]
 
 
-def pack_bglu_gather(wk, ntaps, npl):
+def pack_bglu_gather(wk, ntaps, npl, qe=0):
     """wk [ntaps*32, 32] (k = tap*32 + channel, k-major) -> uint16 [ntaps*2 blocks][npl][64 lanes][8]: block tap*2 + q,
     lane (row, h), element e = wk[tap*32 + bglu_chan(q, h, e)][row]."""
     wk = np.asarray(wk, np.float64).astype(np.float32)
@@ -557,13 +598,13 @@ def pack_bglu_gather(wk, ntaps, npl):
     tap, q, h, e = np.meshgrid(np.arange(ntaps), np.arange(2), np.arange(2), np.arange(8), indexing="ij")
     k = tap * 32 + bglu_chan(q, h, e)                                       # [tap, q, h, e]
     frag = wk[k].transpose(0, 1, 2, 4, 3).reshape(ntaps * 2, 64, 8)         # [.., h, row, e] -> lane = h*32 + row
-    return np.ascontiguousarray(to_planes(frag, npl).transpose(1, 0, 2, 3))  # [nb, npl, 64, 8]
+    return np.ascontiguousarray(to_planes(frag, npl, qe).transpose(1, 0, 2, 3))  # [nb, npl, 64, 8]
 
 
-def unpack_bglu_gather(packed, ntaps):
+def unpack_bglu_gather(packed, ntaps, qe=0):
     packed = np.asarray(packed, np.uint16)
     npl = packed.shape[1]
-    f = from_planes(packed.transpose(1, 0, 2, 3)).reshape(ntaps, 2, 2, 32, 8)   # [tap, q, h, row, e]
+    f = from_planes(packed.transpose(1, 0, 2, 3), qe).reshape(ntaps, 2, 2, 32, 8)   # [tap, q, h, row, e]
     out = np.zeros((ntaps * 32, 32), np.float32)
     for q in range(2):
         for h in range(2):
@@ -572,22 +613,22 @@ def unpack_bglu_gather(packed, ntaps):
     return out
 
 
-def pack_bglu_in4(wk, npl):
+def pack_bglu_in4(wk, npl, q=0):
     """Encoder stage 1: wk [40, 32] (k = tap*4 + channel over (x 0, x 1, x_init 0, x_init 1)) -> [3 blocks][npl][64][8],
     block q, lane (row, h), element e = wk[16q + 8h + e][row] (rows >= 40 zero)."""
     wk = np.concatenate([np.asarray(wk, np.float64), np.zeros((8, 32))], 0).astype(np.float32)
     k = 16 * np.arange(3)[:, None, None] + 8 * np.arange(2)[None, :, None] + np.arange(8)[None, None, :]
     frag = wk[k].transpose(0, 1, 3, 2).reshape(3, 64, 8)
-    return np.ascontiguousarray(to_planes(frag, npl).transpose(1, 0, 2, 3))
+    return np.ascontiguousarray(to_planes(frag, npl, q).transpose(1, 0, 2, 3))
 
 
-def unpack_bglu_in4(packed):
+def unpack_bglu_in4(packed, q=0):
     packed = np.asarray(packed, np.uint16)
-    f = from_planes(packed.transpose(1, 0, 2, 3)).reshape(3, 2, 32, 8)          # [q, h, row, e]
+    f = from_planes(packed.transpose(1, 0, 2, 3), q).reshape(3, 2, 32, 8)       # [q, h, row, e]
     return f.transpose(0, 1, 3, 2).reshape(48, 32)[:40]
 
 
-def pack_bglu_chain(w, npl):
+def pack_bglu_chain(w, npl, q=0):
     """w [Mout, Kin] -> uint16 [mtiles][Kin/16 blocks][npl][64][8] in the k order of an accumulator tile used as B operand
     (pack_s3_chain with a plane count)."""
     w = np.asarray(w, np.float64).astype(np.float32)
@@ -598,13 +639,13 @@ def pack_bglu_chain(w, npl):
     s_, h_, j_ = np.meshgrid(np.arange(K // 16), np.arange(2), np.arange(8), indexing="ij")
     kk = 32 * (s_ >> 1) + ((8 * (s_ & 1) + j_) & 3) + 8 * ((8 * (s_ & 1) + j_) >> 2) + 4 * h_
     frag = pad.reshape(mt, 32, K)[:, :, kk].transpose(0, 2, 3, 1, 4).reshape(mt, K // 16, 64, 8)
-    return np.ascontiguousarray(to_planes(frag, npl).transpose(1, 2, 0, 3, 4))   # [mt, nb, npl, 64, 8]
+    return np.ascontiguousarray(to_planes(frag, npl, q).transpose(1, 2, 0, 3, 4))   # [mt, nb, npl, 64, 8]
 
 
-def unpack_bglu_chain(packed, M, K):
+def unpack_bglu_chain(packed, M, K, q=0):
     packed = np.asarray(packed, np.uint16)
     mt = packed.shape[0]
-    f = from_planes(packed.transpose(2, 0, 1, 3, 4)).reshape(mt, K // 16, 2, 32, 8)   # [mt, nb, h, row, j]
+    f = from_planes(packed.transpose(2, 0, 1, 3, 4), q).reshape(mt, K // 16, 2, 32, 8)   # [mt, nb, h, row, j]
     out = np.zeros((mt * 32, K), np.float32)
     for s in range(K // 16):
         for h in range(2):

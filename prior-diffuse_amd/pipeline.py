@@ -30,9 +30,12 @@ def _expect(t, like, name):
 
 
 class SamplerPipeline:
+    # the fp32-equivalent operand split of the matrix-core kernels (see ``split``)
+    default_split = "f16x2"
+
     def __init__(self, device, prior_name, prior_sd, ddpm_sd, B, T=None, L_=None, fast_sampling=True,
                  use_sigma=False, params=default_params, with_signal=None, deltamu=False, cond="init", bank=None,
-                 split_bf16=None, xT_plus_init=None, dtype="f32", exclusive=False):
+                 split_bf16=None, xT_plus_init=None, dtype="f32", exclusive=False, split=None):
         """deltamu: the alternative parameterisation of utils/params.py:36 — ddpm_sd is a ``Nocon`` state_dict,
         x_T = noise + X_init/11 (:947-948), eps = Nocon(x, t) (:970-971), no final ``+ X_init`` (:995).
         cond (deltamu False): what conditions DiffUNet1 — "init": X_init/11 (pirorgrad, :967-969, + X_init at the end,
@@ -56,7 +59,11 @@ class SamplerPipeline:
         ``ConcurrentSampler`` / ``PipelinedSampler`` and the sharded path keep False.
         split_bf16: the eps-net's BIGLU blocks and the priors' GEMM-shaped convolutions on the bf16 matrix cores with exact three-way
         operand splits - fp32-level accuracy at 16/6 of the fp32 MFMA rate (csrc/gconv3.hip); None: on for fast sampling,
-        off (exact fp32 MFMA) for the full 50-step schedule."""
+        off (exact fp32 MFMA) for the full 50-step schedule.
+        split (with split_bf16, dtype "f32"): which fp32-equivalent operand split the matrix-core kernels use - "bf16x3": the exact
+        three-way bf16 split, six bf16 products per multiply-add; "f16x2": fp16 hi + lo of the power-of-two scaled operand (within
+        half an fp32 ulp inside the fp16 window, see include/pdse.h PDSE_F16_ACT_EXP), three f16 products, two thirds of the plane
+        bytes.  Both are held to the same goldens and tolerances.  None: ``SamplerPipeline.default_split``."""
         if L_ is not None:
             T = 1 + L_ // 160
         if with_signal is None:
@@ -68,6 +75,10 @@ class SamplerPipeline:
         if dtype == "bf16" and (deltamu or split_bf16 is False):
             raise ValueError("the bf16 mode runs the DiffUNet1 blocks on the bf16 matrix cores (split_bf16 False / Nocon: no)")
         self.dtype = dtype
+        split = self.default_split if split is None else split
+        if split not in ("bf16x3", "f16x2"):
+            raise ValueError("split must be 'bf16x3' or 'f16x2'")
+        self.split = split
         if split_bf16 is None:
             # 6-step fast sampling: split-bf16 blocks (2e-6 from the fp32 CPU path, tolerance 1e-4).  The full 50-step
             # schedule amplifies rounding noise ~500x (the fp32 CPU path itself sits 4-7e-5 from the exact answer), so
@@ -94,8 +105,9 @@ class SamplerPipeline:
         self.stft = adopt(nets.StftPlan(ctx, B, L_, plan=self.plan, split_bf16=split_bf16)) if with_signal else None
         pplanes = 1 if dtype == "bf16" else None     # bf16 mode: the priors' GEMM-shaped convolutions on plain bf16 operands too (korder 4)
         if prior_name == "GCRN":
+            gplanes = pplanes if pplanes is not None else ((2 if split == "f16x2" else 3) if split_bf16 else None)   # korder 5 / 3 (csrc/gconv4.hip)
             self.prior = adopt(nets.GcrnPlan(ctx, prior_sd, B, T, plan=self.plan, split_bf16=split_bf16 or dtype == "bf16", exclusive=exclusive,
-                                             planes=pplanes))
+                                             planes=gplanes))
         elif prior_name == "DiffUNet":
             self.prior = adopt(nets.EpsNetPlan(ctx, prior_sd, B, T, time_cond=False, plan=self.plan, split_bf16=split_bf16, exclusive=exclusive))
         elif prior_name == "aia_complex_trans_ri":
@@ -107,7 +119,8 @@ class SamplerPipeline:
         if dtype == "bf16":
             split_bf16 = True
         self.eps = adopt(nets.EpsNetPlan(ctx, ddpm_sd, B, T, time_cond=True, nsteps=S, plan=self.plan,
-                                         with_pre=not deltamu, split_bf16=split_bf16, planes=1 if dtype == "bf16" else None,
+                                         with_pre=not deltamu, split_bf16=split_bf16,
+                                         planes=1 if dtype == "bf16" else (2 if split == "f16x2" else 3),
                                          exclusive=exclusive))
         self.split_bf16 = self.eps.split_bf16
         self.deltamu = deltamu

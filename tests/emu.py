@@ -89,13 +89,13 @@ def run_gconv(d, mem):
             out[rows[rows >= 0]] = wk[rows >= 0]
             assert np.all(wk[rows < 0] == 0)
             return out
-    elif d.korder in (3, 4):   # split-bf16 (3) / plain bf16 (4) GEMM-shaped convolution (csrc/gconv4.hip): weights streamed through LDS
+    elif d.korder in (3, 4, 5):   # split-bf16 (3) / plain bf16 (4) / f16x2 (5) GEMM-shaped convolution (csrc/gconv4.hip): weights streamed through LDS
         assert d.epi in (L.EPI_LINEAR, L.EPI_GLU) and not d.cin1 and d.xf_mode == 0
 
         def unpack(ptr):
-            npl = 3 if d.korder == 3 else 1
+            npl = {3: 3, 4: 1, 5: 2}[d.korder]
             n = d.ntaps * Cin // 16 * mtiles * npl * 64 * 8
-            wk = P.unpack_s3_gemm(mem.arr(ptr, n, np.int16).view(np.uint16), d.ntaps, d.in0.C, d.in1.C, mtiles * 32, npl)
+            wk = P.unpack_s3_gemm(mem.arr(ptr, n, np.int16).view(np.uint16), d.ntaps, d.in0.C, d.in1.C, mtiles * 32, npl, d.wexp)
             return wk
     elif d.korder == 2:   # split-bf16 BIGLU block (csrc/gconv3.hip): exact 3-way bf16 splits in bf16 MFMA fragment order
         assert d.epi == L.EPI_BIGLU and Cin in (32, 4) and d.Cout == 32
@@ -145,7 +145,7 @@ def run_gconv(d, mem):
             flat, off = mem.view(S.ptr)
             cI = np.arange(S.C)[None, :, None, None]
             if S.blk:   # channel-blocked source (pdse_src.blk = 8, korder 3 only)
-                assert S.blk == 8 and d.korder in (3, 4), "blocked sources are read by the korder 3 / 4 kernel only"
+                assert S.blk == 8 and d.korder in (3, 4, 5), "blocked sources are read by the korder 3 / 4 / 5 kernel only"
                 idx = off + bI * S.sb + (cI >> 3) * S.sc + (cI & 7) + tin * S.st + fin * S.sf
             else:
                 idx = off + bI * S.sb + cI * S.sc + tin * S.st + fin * S.sf
@@ -523,13 +523,14 @@ def run_tcm(d, mem):
 def run_tcm2(d, mem):
     """pdse_tcm2_desc: the same block on split operands; h travels as the bf16 planes of both branches' transforms."""
     B, T, dil = d.B, d.T, d.dil
-    npl = d.np or 3                                                  # 1: plain bf16 operands (the opt-in bf16 mode)
+    npl = d.np or 3                                                  # 1: plain bf16 operands (the opt-in bf16 mode); 2: f16x2
+    qA, q2, qN = (tuple(d.qexp) if npl == 2 else (0, 0, 0))
     rnd = _bf16_round if npl == 1 else (lambda v_: v_)
     par = mem.arr(d.par, 832)
     u16 = lambda ptr, n: mem.arr(ptr, n, np.int16).view(np.uint16)   # noqa: E731
     x = mem.arr(d.x, B * 256 * T).reshape(B, 256, T).astype(np.float64)
     if d.mode == 0:
-        km = P.unpack_tcm2_branch(u16(d.wbr, 2 * 2 * 20 * npl * 64 * 8))
+        km = P.unpack_tcm2_branch(u16(d.wbr, 2 * 2 * 20 * npl * 64 * 8), qA)
         v = P.tcm2_join_h(u16(d.hs, int(np.prod(P.tcm2_hs_shape(B, T, npl)))), B, T)
         pre = []
         for which in range(2):
@@ -541,13 +542,13 @@ def run_tcm2(d, mem):
         g = (pre[0] + gp[:, 0][None, :, None]) * _sig(pre[1] + gp[:, 1][None, :, None])
         g = np.where(g > 0, g, np.float32(d.slope2) * g) * gp[:, 2][None, :, None] + gp[:, 3][None, :, None]
         g = rnd(g.astype(np.float32)).astype(np.float64)        # the kernel splits (or rounds) the fp32 value
-        k2 = P.unpack_tcm2_conv2(u16(d.wc2, 8 * 4 * npl * 64 * 8)).astype(np.float64)
+        k2 = P.unpack_tcm2_conv2(u16(d.wc2, 8 * 4 * npl * 64 * 8), q2).astype(np.float64)
         xo = np.einsum("bkt,ko->bot", g, k2) + par[256:512][None, :, None] + x
         mem.arr(d.x_out, B * 256 * T)[:] = xo.astype(np.float32).reshape(-1)
     else:
         xo = x
     if d.hs_out:
-        w1 = P.unpack_bglu_chain(np.asarray(u16(d.wn1, 2 * 16 * npl * 64 * 8)).reshape(2, 16, npl, 64, 8), 64, 256).astype(np.float64)
+        w1 = P.unpack_bglu_chain(np.asarray(u16(d.wn1, 2 * 16 * npl * 64 * 8)).reshape(2, 16, npl, 64, 8), 64, 256, qN).astype(np.float64)
         ho = (np.einsum("bkt,ok->bot", rnd(xo.astype(np.float32)).astype(np.float64), w1) + par[512:576][None, :, None]).astype(np.float32)
         xn = par[576:].reshape(64, 4)
         vm = xn[:, 0][None, :, None] * np.where(ho > 0, ho, np.float32(d.slope_main_next) * ho) + xn[:, 1][None, :, None]
@@ -605,6 +606,7 @@ def run_bglu(d, mem):
     u16 = lambda ptr, n: mem.arr(ptr, n, np.int16).view(np.uint16)   # noqa: E731
     blk = npl * 64 * 8
     nt = d.ntaps
+    qG, qLC, qC2, qNX = (tuple(d.qexp) if npl == 2 else (0, 0, 0, 0))    # f16x2: the power-of-two scale of each weight group
     taps = [(d.tap_dt[i], d.tap_df[i]) for i in range(nt)]
     bI, tI, jI = np.meshgrid(np.arange(B), np.arange(T), np.arange(Fo), indexing="ij")
 
@@ -612,7 +614,7 @@ def run_bglu(d, mem):
         return np.asarray(u16(ptr, nb * blk)).reshape(nb, npl, 64, 8)
 
     if d.x0.ptr:
-        W0, W1 = P.unpack_bglu_in4(unp(d.w0, 3)), P.unpack_bglu_in4(unp(d.w1, 3))     # [40, 32], k = tap*4 + channel
+        W0, W1 = P.unpack_bglu_in4(unp(d.w0, 3), qG), P.unpack_bglu_in4(unp(d.w1, 3), qG)     # [40, 32], k = tap*4 + channel
         accL = np.zeros((B, 32, T, Fo), np.float32)
         accR = np.zeros_like(accL)
         for ti, (dt, df) in enumerate(taps):
@@ -634,11 +636,11 @@ def run_bglu(d, mem):
             assert d.sf_in == 2
             hp = hp[:, :, :, :, P.hp_par_pos(d.hp_Fp), :]                                     # natural[i] = stored[pos[i]]
         H = P.hp_join(hp, with_margins=True)                                                 # [B, 32, Tp, Fp]
-        W = [P.unpack_bglu_gather(unp(p_, 2 * nt), nt) for p_ in (d.w0, d.w1)]
+        W = [P.unpack_bglu_gather(unp(p_, 2 * nt), nt, qG) for p_ in (d.w0, d.w1)]
         ph_taps = [list(range(nt))]
         if d.p1mask:
             t1 = [i for i in range(nt) if (d.p1mask >> i) & 1]
-            W += [P.unpack_bglu_gather(unp(p_, 2 * len(t1)), len(t1)) for p_ in (d.w2, d.w3)]
+            W += [P.unpack_bglu_gather(unp(p_, 2 * len(t1)), len(t1), qG) for p_ in (d.w2, d.w3)]
             ph_taps.append(t1)
         accs = []
         for ph, tl in enumerate(ph_taps):
@@ -658,16 +660,16 @@ def run_bglu(d, mem):
         return flat[off + np.arange(B)[:, None] * sb + np.arange(n)[None, :]][:, :, None, None]
 
     bl, br = vec(d.bias0, d.bias_sb, 32), vec(d.bias1, d.bias_sb, 32)
-    Wlc = P.unpack_bglu_chain(unp(d.wlc, 2)[None], 32, 32)
-    Wrc = P.unpack_bglu_chain(unp(d.wrc, 2)[None], 32, 32)
+    Wlc = P.unpack_bglu_chain(unp(d.wlc, 2)[None], 32, 32, qLC)
+    Wrc = P.unpack_bglu_chain(unp(d.wrc, 2)[None], 32, 32, qLC)
     blc, brc = mem.arr(d.blc, 32)[None, :, None, None], mem.arr(d.brc, 32)[None, :, None, None]
     if d.C2 == 64:
-        Wc2 = P.unpack_bglu_chain(np.asarray(u16(d.wc2, 4 * blk)).reshape(2, 2, npl, 64, 8), 64, 32)
+        Wc2 = P.unpack_bglu_chain(np.asarray(u16(d.wc2, 4 * blk)).reshape(2, 2, npl, 64, 8), 64, 32, qC2)
         bc2 = mem.arr(d.bc2, 64)[None, :, None, None]
     Wn = []
     if d.nx_n:
         nxw = np.asarray(u16(d.nx_w, d.nx_n * 4 * blk)).reshape(d.nx_n, 1, 4, npl, 64, 8)
-        Wn = [P.unpack_bglu_chain(nxw[i], 32, 64) for i in range(d.nx_n)]
+        Wn = [P.unpack_bglu_chain(nxw[i], 32, 64, qNX) for i in range(d.nx_n)]
     slope = np.float32(d.slope)
     assert slope <= 1.0
     for ph, (aL, aR) in enumerate(accs):

@@ -1,0 +1,173 @@
+"""GPU parity of the f16x2 form of the matrix-core kernels (round 4): every operand as fp16 hi + lo of its power-of-two scaled
+value, three f16 MFMA products per multiply-add (csrc/gconv_common.h: split8h; include/pdse.h: PDSE_F16_ACT_EXP,
+pdse_bglu_desc.qexp).  It replaces arithmetic of the reference's fp32 blocks (model/diff3.py:215-351) and is held to the SAME
+goldens and tolerances as the exact three-way bf16 split and the fp32 MFMA kernels; everything through the C-ABI."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import full_pair, golden, pkg, rel_l2, seeded
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def L():
+    import __graft_entry__ as ge
+
+    ge.build()
+    lib = pkg("_lib")
+    lib.load()
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return lib
+
+
+def _eps_plan(weights, B, T, planes):
+    nets = pkg("nets")
+    net = nets.EpsNetPlan(nets.Ctx(DEV), weights("DiffUNet1"), B, T, time_cond=True, nsteps=1, planes=planes)
+    net.build_time()
+    net.build_step(0)
+    net.finish()
+    return net
+
+
+def test_f16x2_blocks_vs_goldens(L, weights):
+    """DiffUNet1 forward with all 15 BiConv(Trans)GLU stages in the f16x2 form against the reference's golden vectors (small T
+    with the TCM input as an intermediate; T = 401), tolerance 2e-5 as for every fp32-equivalent arithmetic of the block; the
+    distance to the three-plane bf16 split is printed beside it."""
+    g = golden("diffunet1_small")
+    B, T = int(g["B"]), int(g["T"])
+    x = seeded((B, 2, T, 161), g["seed_x"])
+    xi = seeded((B, 2, T, 161), g["seed_init"]) * float(g["init_scale"])
+    outs = {}
+    for planes in (2, 3):
+        net = _eps_plan(weights, B, T, planes)
+        net.x.copy_(x)
+        net.x_init.copy_(xi)
+        net.tsteps.copy_(torch.from_numpy(g["t"]).view(1, B))
+        net.plan.run()
+        torch.cuda.synchronize()
+        bg = [d for d, _ in net.descs if isinstance(d, L.BgluDesc)]
+        assert len(bg) == 15 and all(d.np == planes for d in bg)
+        e5 = rel_l2(net.en[4].cpu().permute(0, 1, 3, 2), g["en5"])
+        e = rel_l2(net.out.cpu(), g["out"])
+        print("planes %d: encoder output vs golden %.2e | eps-net vs golden %.2e" % (planes, e5, e))
+        assert e5 < 2e-5 and e < 2e-5
+        outs[planes] = net.out.cpu().clone()
+        if planes == 2:
+            Pk = pkg("packing")
+            for hp, enc in [(hp, True) for hp in net.hp_en.values()] + [(hp, False) for hp in net.hp_de.values()]:   # margins stay zero
+                raw = hp.cpu().numpy().view(np.uint16)[:B]
+                if enc and net.parity_planes:
+                    raw = raw[:, :, :, :, Pk.hp_par_pos(raw.shape[4]), :]
+                full = Pk.hp_join(raw, with_margins=True)
+                assert not full[:, :, :, :2].any() and not full[:, :, :, -2:].any() and (enc or not full[:, :, 0].any())
+    print("f16x2 vs bf16x3: %.2e" % rel_l2(outs[2], outs[3]))
+    assert rel_l2(outs[2], outs[3]) < 1e-5
+    g4 = golden("diffunet1_t401")
+    net = _eps_plan(weights, 1, 401, 2)
+    net.x.copy_(seeded((1, 2, 401, 161), g4["seed_x"]))
+    net.x_init.copy_(seeded((1, 2, 401, 161), g4["seed_init"]) * 0.3)
+    net.tsteps.fill_(float(g4["t"]))
+    net.plan.run()
+    torch.cuda.synchronize()
+    out4 = net.out.cpu()
+    assert rel_l2(out4[0, :, ::16, :], g4["rows"]) < 2e-5
+    assert abs(float(out4.double().pow(2).sum()) - float(g4["sumsq"])) < 4e-5 * float(g4["sumsq"])
+
+
+def test_f16x2_gcrn_prior_vs_goldens(L, weights):
+    """GCRN's gated (transposed) convolutions and LSTM input projection as f16x2 GEMMs (csrc/gconv4.hip, korder 5: two fp16 planes of
+    W * 2^wexp streamed through the ring, activations scaled and split in registers) against the reference's golden (2e-5, as the
+    three-plane form), with the intermediates the fixture holds, and at T = 401."""
+    nets = pkg("nets")
+    g = golden("gcrn_small")
+    x = seeded((2, 2, 20, 161), g["seed_x"])
+    outs = {}
+    for planes in (2, 3):
+        net = nets.GcrnPlan(nets.Ctx(DEV), weights("GCRN"), 2, 20, planes=planes)
+        net.build()
+        net.finish()
+        net.x.copy_(x)
+        net.plan.run()
+        torch.cuda.synchronize()
+        k = [d.korder for d, _ in net.descs if isinstance(d, L.GconvDesc) and d.korder >= 3]
+        assert len(k) == 22 and all(v == (5 if planes == 2 else 3) for v in k)
+        outs[planes] = net.out.cpu().clone()
+        e, e5, el = rel_l2(outs[planes], g["out"]), rel_l2(net.enc_out(5).cpu(), g["e5"]), rel_l2(net.glstm_out().cpu(), g["glstm"])
+        print("GCRN planes %d: encoder %.2e | LSTM block %.2e | output vs golden %.2e" % (planes, e5, el, e))
+        assert e < 2e-5 and e5 < 2e-5 and el < 2e-5
+    print("GCRN f16x2 vs bf16x3: %.2e" % rel_l2(outs[2], outs[3]))
+    assert rel_l2(outs[2], outs[3]) < 5e-6
+    g4 = golden("gcrn_t401")
+    net = nets.GcrnPlan(nets.Ctx(DEV), weights("GCRN"), 1, 401, planes=2)
+    net.build()
+    net.finish()
+    net.x.copy_(seeded((1, 2, 401, 161), g4["seed_x"]))
+    net.plan.run()
+    torch.cuda.synchronize()
+    assert rel_l2(net.out.cpu()[0, :, ::16, :], g4["rows"]) < 5e-5          # 401 recurrent frames: the bound of test_gcrn_golden
+
+
+def test_f16x2_sampling_full_size_b32(L, weights):
+    """BASELINE config 2 (B = 32, T = 401, GCRN + 6 reverse steps) with split="f16x2": utterances 0 / 17 / 31 bit-identical to their
+    B = 1 runs, utterance 0 against the reference's own fp32 loop and its float64 evaluation (<= 1e-4, as the bf16x3 pass);
+    the small sampling goldens (6 and 50 steps)."""
+    B, T = 32, 401
+    feat, x_T = pkg("synth").synthetic_spectrogram(B, T, seed=1234)
+    P = pkg("pipeline").SamplerPipeline
+    big = P(DEV, "GCRN", weights("GCRN"), weights("DiffUNet1"), B, T=T, split="f16x2")
+    assert big.split == "f16x2" and all(d.np == 2 for d, _ in big.descs if isinstance(d, L.BgluDesc))
+    assert sum(1 for d, _ in big.descs if isinstance(d, L.GconvDesc) and d.korder == 5) == 22 and not any(isinstance(d, L.GconvDesc) and d.korder == 3 and d.epi == L.EPI_GLU for d, _ in big.descs)
+    spec, init = big.sample(feat.to(DEV), x_T.to(DEV))
+    bank = big.bank
+    del big
+    one = P(DEV, "GCRN", weights("GCRN"), weights("DiffUNet1"), 1, T=T, split="f16x2", bank=bank)
+    for b in (0, 17, 31):
+        s1, _ = one.sample(feat[b:b + 1].to(DEV), x_T[b:b + 1].to(DEV))
+        assert torch.equal(s1[0], spec[b]), b
+    ref, exact, _ = full_pair("full_gcrn_seed1234_t401_6step")
+    e_ref, e_exact, e_ref_exact = rel_l2(spec[:1].cpu(), ref), rel_l2(spec[:1].cpu(), exact), rel_l2(ref, exact)
+    print("f16x2, 6 steps, B=32: vs the reference's fp32 run %.2e | vs its float64 evaluation %.2e | fp32 run vs float64 %.2e" % (e_ref, e_exact, e_ref_exact))
+    assert e_ref < 1e-4 and e_exact < 1e-4
+    for tag, fast in (("gcrn_fast", True), ("gcrn_full", False)):        # the reference's small sampling fixtures: 6 and 50 steps
+        g = golden("sample_" + tag)
+        f2, x2 = seeded((2, 2, 16, 161), g["seed_feat"]), seeded((2, 2, 16, 161), g["seed_xT"])
+        pipe = P(DEV, "GCRN", weights("GCRN"), weights("DiffUNet1"), 2, T=16, fast_sampling=fast, split="f16x2", split_bf16=True)
+        assert all(d.np == 2 for d, _ in pipe.descs if isinstance(d, L.BgluDesc))
+        out, _ = pipe.sample(f2.to(DEV), x2.to(DEV))
+        e = rel_l2(out.cpu(), g["out"])
+        print("f16x2 sampling golden %s: %.2e" % (tag, e))
+        assert e < 1e-4
+
+
+def test_f16x2_planes_saturate(L):
+    """A value beyond the fp16 window (|x| * 2^6 > 65504) leaves finite, saturated planes (MODE.FP16_OVFL), never an infinity; values
+    inside it come back within half an fp32 ulp."""
+    Pk = pkg("packing")
+    B, T, F = 1, 3, 5
+    x = seeded((B, 32, T, F), 21)
+    x[0, 3, 1, 2] = 1.0e6
+    x[0, 4, 1, 2] = -3.0e4
+    x[torch.abs(x) < 2.0 ** -8] = 0.5
+    shp = Pk.hp_shape(B, T, F, 2)
+    hp = torch.zeros(*shp, dtype=torch.int16, device=DEV)
+    d = L.PlanesDesc()
+    xd = x.to(DEV)
+    d.in_, (d.in_sb, d.in_sc, d.in_st, d.in_sf) = xd.data_ptr(), (32 * T * F, T * F, F, 1)
+    d.hp, d.hp_sb, d.hp_Tp, d.hp_Fp, d.hp_t0, d.hp_f0 = hp.data_ptr(), int(np.prod(shp[1:])), shp[1], shp[4], Pk.HP_T0, Pk.HP_F0
+    d.B, d.T, d.F, d.np = B, T, F, 2
+    plan = L.Plan(torch.device(DEV))
+    plan.add(d)
+    plan.run()
+    torch.cuda.synchronize()
+    raw = hp.cpu().numpy().view(np.uint16)
+    back = Pk.hp_join(raw)
+    assert np.all(np.isfinite(back))
+    assert np.array_equal(raw, Pk.hp_split(x.numpy(), 2))                     # the host restatement of the split, bit for bit
+    xs = x.numpy().copy()
+    inside = np.abs(xs) < 1000.0
+    assert np.max(np.abs(back - xs)[inside] / np.abs(xs)[inside]) <= 2.0 ** -23
+    assert 1023.0 < back[0, 3, 1, 2] < 2048.0 and -2048.0 < back[0, 4, 1, 2] < -1023.0

@@ -97,7 +97,7 @@ def test_gcrn_and_diffunet_prior_plans_vs_oracle(weights, fused_glstm, split, bl
     net = nets.GcrnPlan(ctx, weights("GCRN"), B, T, exclusive=True)
     net.build()
     assert sum(1 for d, _ in net.descs if isinstance(d, pkg("_lib").GlstmpDesc)) == (1 if persist else 0)
-    n3 = sum(1 for d, _ in net.descs if isinstance(d, pkg("_lib").GconvDesc) and d.korder == 3)
+    n3 = sum(1 for d, _ in net.descs if isinstance(d, pkg("_lib").GconvDesc) and d.korder == 5)       # the default split: f16x2 (korder 5)
     assert n3 == ((4 + 16 + (2 if fused_glstm else 4)) if split else 0)   # encoder 2-5, 2 x 4 x 2 decoder phases, projections
     nblk = sum(1 for d, _ in net.descs if isinstance(d, pkg("_lib").GconvDesc) and d.in0.blk)
     assert nblk == (3 + 2 + 16 if (split and block8) else 0)               # encoders 3-5, the layer-1 projections, every decoder launch
@@ -222,6 +222,43 @@ def test_eps_net_plan_bf16_mode_vs_oracle(weights):
         nets.EpsNetPlan(nets.Ctx("cpu"), weights("Nocon"), B, T, time_cond=True, nsteps=1, with_pre=False, planes=1)
 
 
+def test_eps_net_plan_f16x2_mode_vs_oracle(weights):
+    """The f16x2 form of the block kernels (two planes: fp16 hi + lo of the power-of-two scaled operand, three f16 products
+    per multiply-add): weights packed with their per-group exponents (pdse_bglu_desc.qexp), plane tensors at
+    2^PDSE_F16_ACT_EXP, replayed on the interpreter - fp32-equivalent: the SAME tolerance as the three-plane split."""
+    nets, Lb, Pk = pkg("nets"), pkg("_lib"), pkg("packing")
+    B, T = 2, 12
+    sd = weights("DiffUNet1")
+    ctx = nets.Ctx("cpu")
+    net = nets.EpsNetPlan(ctx, sd, B, T, time_cond=True, nsteps=1, planes=2)
+    net.build_time()
+    net.build_step(0)
+    bg = [d for d, _ in net.descs if isinstance(d, Lb.BgluDesc)]
+    assert len(bg) == 15 and all(d.np == 2 for d in bg) and all(d.np == 2 for d, _ in net.descs if isinstance(d, Lb.PlanesDesc))
+    assert all(d.np == 2 for d in tcm2_blocks(net.descs)) and all(5 <= d.qexp[2] <= 30 for d in tcm2_blocks(net.descs) if d.hs_out)
+    assert all(5 <= q <= 30 for d in bg for q in (d.qexp[0], d.qexp[1])), [tuple(d.qexp) for d in bg]    # weights below 1: scaled up
+    x, xi = seeded((B, 2, T, 161), 3), seeded((B, 2, T, 161), 4) * 0.3
+    t = torch.tensor([4.086654, 22.992493])
+    net.x.copy_(x)
+    net.x_init.copy_(xi)
+    net.tsteps.copy_(t.view(1, B))
+    emu.run(net.descs, ctx.all_tensors())
+    with torch.no_grad():
+        ref = R.diffunet1_forward(sd, x, xi, t)
+    e = rel_l2(net.out, ref)
+    assert e < 2e-5, e
+    # the split itself: hi + lo reproduces a scaled weight to half an fp32 ulp, an activation inside the fp16 window likewise
+    w = np.asarray(seeded((96, 32), 9)) * 0.07
+    q = Pk.f16_wexp(w)
+    back = Pk.unpack_bglu_gather(Pk.pack_bglu_gather(w, 3, 2, q), 3, q)
+    assert 2.0 ** 13 <= np.abs(w).max() * 2.0 ** q < 2.0 ** 14 and np.max(np.abs(back - w) / np.abs(w)) <= 2.0 ** -23
+    h = np.asarray(seeded((1, 32, 3, 9), 10))
+    h[np.abs(h) < 2.0 ** -8] = 0.25
+    assert np.max(np.abs(Pk.hp_join(Pk.hp_split(h, 2)) - h) / np.abs(h)) <= 2.0 ** -23
+    big = np.full((1, 32, 1, 1), 1e6, np.float32)                                # beyond the window: saturates, no infinity
+    assert np.all(np.isfinite(Pk.hp_join(Pk.hp_split(big, 2)))) and Pk.hp_join(Pk.hp_split(big, 2)).max() < 2100.0
+
+
 def test_priors_one_plane_gemm_mode_vs_oracle(weights):
     """The bf16 mode of the priors (round 4): the GEMM-shaped convolutions packed as ONE bf16 plane (korder 4, packing.pack_s3_gemm
     with npl = 1), replayed on the interpreter with both operands rounded to bf16: within the mode's prior tolerance of the fp32
@@ -240,4 +277,13 @@ def test_priors_one_plane_gemm_mode_vs_oracle(weights):
     e = rel_l2(net.out, ref)
     assert 1e-4 < e < 1e-2, e
     with pytest.raises(ValueError):
-        nets.GcrnPlan(nets.Ctx("cpu"), weights("GCRN"), B, T, planes=2)
+        nets.GcrnPlan(nets.Ctx("cpu"), weights("GCRN"), B, T, planes=4)
+    # the f16x2 form of the same launches (korder 5: fp16 hi + lo planes of W * 2^wexp): fp32-equivalent on the interpreter
+    ctx2 = nets.Ctx("cpu")
+    net2 = nets.GcrnPlan(ctx2, weights("GCRN"), B, T, planes=2)
+    net2.build()
+    k5 = [d for d, _ in net2.descs if isinstance(d, pkg("_lib").GconvDesc) and d.korder == 5]
+    assert len(k5) == 22 and all(5 <= d.wexp <= 30 for d in k5)
+    net2.x.copy_(x)
+    emu.run(net2.descs, ctx2.all_tensors())
+    assert rel_l2(net2.out, ref) < 2e-5

@@ -52,6 +52,10 @@ if __name__ == "__main__":
         for B_ in (32, 16, 8, 4):
             run(True, B=B_)
         sys.exit(0)
+    if os.environ.get("PLANES"):          # PLANES=3,2: the block kernels' plane forms side by side (bf16x3 / f16x2 / bf16)
+        for p_ in os.environ["PLANES"].split(","):
+            run(True, planes=int(p_))
+        sys.exit(0)
     run(False)
     run(True, plane_h=False)
     run(True)
