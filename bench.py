@@ -3,12 +3,14 @@
 Metric (BASELINE.json): enhanced-audio seconds per wall second (real-time factor) of
 6-step fast sampling; workload = configs[1] restated at the shapes the reference can
 actually run: B=32 utterances of 4 s at 16 kHz per GPU, spectrograms
-[32,2,401,161], GCRN prior + DiffUNet1 x 6.  Arithmetic of the graded line ("dtype": "bf16x3"): every fp32 operand of
-the contractions is split EXACTLY into three bf16 terms and the six leading cross products run on the bf16 matrix cores
-with fp32 accumulation - fp32-equivalent (dropped terms < 2^-23 |ab|), parity-tested against the same fixtures and
-tolerances as exact fp32.  The same pass with v_mfma_f32_32x32x2_f32 everywhere is measured beside it in the same run
-("fp32_exact", sequential AND in flight; ``--fp32`` makes it the main line).  ``--bf16`` is the opt-in single-product bf16
-mode with bf16 block-boundary storage (BASELINE configs 2/4/5 name bf16; its own tolerance, never the graded line).
+[32,2,401,161], GCRN prior + DiffUNet1 x 6.  Arithmetic of the graded line ("dtype": "f16x2", round 4): every fp32 operand of
+the contractions is scaled by a power of two into the fp16 window and carried as hi = RN16(x), lo = RN16(x - hi) - within
+half an fp32 ulp of x - and the three leading cross products run on the f16 matrix cores with fp32 accumulation:
+fp32-equivalent (what is dropped is <= 2^-22 |ab|), parity-tested against the same fixtures and tolerances as exact fp32
+(tests/test_gpu_f16x2.py).  Measured beside it in the same run: "bf16x3" (the exact three-way bf16 split with six products,
+the default until round 4; ``--split bf16x3`` makes it the main line) and "fp32_exact" (v_mfma_f32_32x32x2_f32 everywhere;
+``--fp32``), each sequential AND in flight.  ``--bf16`` is the opt-in single-product bf16 mode with bf16 block-boundary
+storage (BASELINE configs 2/4/5 name bf16; its own tolerance, never the graded line).
 
 A "step" is one pass of the whole hot path over one batch: waveforms already resident in
 HBM -> STFT -> prior -> 6 reverse steps -> ISTFT -> waveforms in HBM, replayed from one
@@ -268,39 +270,43 @@ def main():
     tcm_stack_ms = pseq.plan.time_tag(nets.TAG_TCM, stream)[0]
     del pseq
     torch.cuda.empty_cache()
-    fp32_exact = None
-    if args.split_bf16 and not args.no_fp32_compare:   # the same pass with exact fp32 MFMA arithmetic everywhere, measured in the same run
-        p32 = pipeline.SamplerPipeline(dev, args.prior, gs, ds, B, L_=L_, fast_sampling=fast, split_bf16=False)
-        p32.enhance(wav, x_T, graph=use_graph)
+    def compare_pass(note_, **kw):
+        """The same workload under another arithmetic (sequential, and in flight when the main line is), measured in the same run."""
+        pc = pipeline.SamplerPipeline(dev, args.prior, gs, ds, B, L_=L_, fast_sampling=fast, **kw)
+        pc.enhance(wav, x_T, graph=use_graph)
         torch.cuda.synchronize()
-        ts = time.perf_counter()
+        t0_ = time.perf_counter()
         for _ in range(seq_steps):
-            p32.run(graph=use_graph)
+            pc.run(graph=use_graph)
         torch.cuda.synchronize()
-        ms32 = (time.perf_counter() - ts) / seq_steps * 1e3
-        fp32_exact = {"ms_per_step_sequential": round(ms32, 3), "value_sequential": round(B * args.seconds / (ms32 * 1e-3), 2),
-                      "note": "same workload, v_mfma_f32_32x32x2_f32 everywhere (bench.py --fp32)"}
-        bank32 = p32.bank
-        del p32
+        msq = (time.perf_counter() - t0_) / seq_steps * 1e3
+        res = {"ms_per_step_sequential": round(msq, 3), "value_sequential": round(B * args.seconds / (msq * 1e-3), 2), "note": note_}
+        del pc
         torch.cuda.empty_cache()
         if args.overlap:                                # ... and with the same number of batches in flight as the main line
-            r32 = pipeline.PipelinedSampler(dev, args.prior, gs, ds, B, L_, depth=args.depth, by_batch=args.by_batch,
-                                            graph=use_graph, fast_sampling=fast, split_bf16=False)
+            rc = pipeline.PipelinedSampler(dev, args.prior, gs, ds, B, L_, depth=args.depth, by_batch=args.by_batch,
+                                           graph=use_graph, fast_sampling=fast, **kw)
             for _ in range(max(2, args.warmup)):
-                r32.submit(wav, x_T)
-            r32.drain()
+                rc.submit(wav, x_T)
+            rc.drain()
             torch.cuda.synchronize()
-            ts = time.perf_counter()
+            t0_ = time.perf_counter()
             for _ in range(args.steps):
-                r32.submit(wav, x_T)
-            r32.drain()
+                rc.submit(wav, x_T)
+            rc.drain()
             torch.cuda.synchronize()
-            ms32f = (time.perf_counter() - ts) / args.steps * 1e3
-            fp32_exact.update({"ms_per_step": round(ms32f, 3), "value": round(B * args.seconds / (ms32f * 1e-3), 2),
-                               "batches_in_flight": args.inflight})
-            del r32
-        del bank32
+            msf = (time.perf_counter() - t0_) / args.steps * 1e3
+            res.update({"ms_per_step": round(msf, 3), "value": round(B * args.seconds / (msf * 1e-3), 2), "batches_in_flight": args.inflight})
+            del rc
         torch.cuda.empty_cache()
+        return res
+
+    fp32_exact = bf16x3 = None
+    if args.split_bf16 and not args.no_fp32_compare:
+        fp32_exact = compare_pass("same workload, v_mfma_f32_32x32x2_f32 everywhere (bench.py --fp32)", split_bf16=False)
+        if f16:
+            bf16x3 = compare_pass("same workload with the exact three-way bf16 operand split, six bf16 products per multiply-add "
+                                  "(bench.py --split bf16x3; the default until round 4)", split_bf16=True, split="bf16x3")
     per_tag = {}
     for name, tag in (("eps_block", nets.TAG_EPS_BLOCK), ("eps_conv1", nets.TAG_EPS_CONV1), ("tcm", nets.TAG_TCM),
                       ("prior_conv", nets.TAG_PRIOR), ("lstm", nets.TAG_LSTM), ("signal", nets.TAG_SIGNAL),
@@ -313,9 +319,9 @@ def main():
     # HBM traffic of the same launches from the committed rocprofv3 PMC passes (FETCH_SIZE | WRITE_SIZE collected
     # separately, profiles/r01_pmc_traffic_final.json); read-side doubled as MI355X_MICROARCH.md prescribes for gfx950
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
-    if not os.path.exists(tpath):
-        tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r04_pmc_traffic_f16x2.json" if f16 else "r04_pmc_traffic.json")   # PMC passes of THIS arithmetic
+    if not os.path.exists(tpath) and not f16:
+        tpath = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
     n_eps_launch = max(1, sum(per_tag[k]["launches"] for k in ("eps_block", "eps_conv1", "tcm")))
     if os.path.exists(tpath) and B == 32 and T == 401 and fast and args.prior == "GCRN":
         pj = json.load(open(tpath))["eps_net_one_pass"]
@@ -325,7 +331,7 @@ def main():
     peak = BF16_MFMA_PEAK_TFLOPS / products if args.split_bf16 else FP32_MFMA_PEAK_TFLOPS
     if args.bf16:
         peak = BF16_MFMA_PEAK_TFLOPS
-    roofline = {"bound": "mfma", "kernel": ("bglu_kernel (split-bf16 BIGLU blocks on plane tensors) + tcm2_kernel" if args.split_bf16 else
+    roofline = {"bound": "mfma", "kernel": (("bglu_kernel (BiConv(Trans)GLU blocks on %s plane tensors) + tcm2_kernel" % ("f16x2" if f16 else "split-bf16")) if args.split_bf16 else
                                             "gconv2_kernel + tcm_block_kernel") + " (eps-net: BiConvGLU/BiConvTransGLU/TCM launches)",
                 "achieved": round(achieved, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
                 "peak_note": (("dense f16 MFMA 2500 TFLOP/s / 3 products per fp32-equivalent multiply-add (f16x2 split)" if f16 else
@@ -487,15 +493,19 @@ def main():
         "dtype": "bf16" if args.bf16 else (args.split if args.split_bf16 else "f32"), "data": "synthetic",
         "dtype_note": ("OPT-IN bf16 mode: plain bf16 operands (one MFMA product, fp32 accumulate) and bf16 conv1 / bottleneck tensors in the eps-net's "
                        "BiConv(Trans)GLU and TCM blocks; prior as in the default; tolerance 3e-2 rel-L2 (tests/test_gpu_round2.py::"
-                       "test_bf16_mode_tolerance) - not the graded line") if args.bf16 else ("eps-net blocks: fp32 operands split exactly into three bf16 terms, six-product bf16 MFMA, fp32 accumulate "
-                       "(fp32-level accuracy, same parity tolerances); everything else fp32") if args.split_bf16 else "fp32 throughout",
+                       "test_bf16_mode_tolerance) - not the graded line") if args.bf16 else (("matrix-core kernels (eps-net blocks, TCM stack, GCRN's gated convolutions): every fp32 operand scaled by a power of two and carried "
+                        "as fp16 hi + lo (within half an fp32 ulp inside the fp16 window), three f16 MFMA products per multiply-add, fp32 "
+                        "accumulate - fp32-equivalent, same goldens and tolerances as the exact-fp32 kernels (tests/test_gpu_f16x2.py); "
+                        "everything else fp32") if f16 else
+                       ("eps-net blocks: fp32 operands split exactly into three bf16 terms, six-product bf16 MFMA, fp32 accumulate "
+                        "(fp32-level accuracy, same parity tolerances); everything else fp32")) if args.split_bf16 else "fp32 throughout",
         "frames_per_s_per_gpu": round(args.steps * B * T / elapsed, 1),
         "config": {"workload": "B=%d x %.0f s 16 kHz utterances per GPU, [B,2,%d,161] spectrograms, %s prior + "
                                "DiffUNet1 %d-step sampling, STFT..ISTFT, seeded random weights" % (B, args.seconds, T, args.prior, pipe.nsteps),
                    "global_batch": B * world, "frames": T, "parallelism": "batch-shard x%d" % world,
                    "graph": use_graph and (not args.overlap or args.by_batch), "streams_per_gpu": args.streams,
                    "batches_in_flight": args.inflight},
-        "roofline": roofline, "cpu_baseline": cpu, "fp32_exact": fp32_exact, "file_loop_b1": file_loop,
+        "roofline": roofline, "cpu_baseline": cpu, "fp32_exact": fp32_exact, "bf16x3": bf16x3, "file_loop_b1": file_loop,
     }
     print(json.dumps(out))
     if dist is not None:
