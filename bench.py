@@ -107,6 +107,8 @@ def main():
                          "in the line - never the graded default")
     ap.add_argument("--tcm-launches", action="store_true",
                     help="A/B: one launch per TCM residual block (round 3) instead of the persistent stack launch (csrc/tcm2.hip: tcm2s_kernel)")
+    ap.add_argument("--inflight-stack", action="store_true",
+                    help="measurement: the in-flight pipelines take the TCM stack as ONE launch per forward (default: one launch per block)")
     ap.add_argument("--no-file-loop", action="store_true",
                     help="skip the B = 1 generate_wav file loop reported as file_loop_b1 (profiling runs: keeps its B = 1 launches "
                          "out of the kernel trace, so that per-kernel averages of the trace are B = 32 launches only)")
@@ -178,6 +180,8 @@ def main():
 
     use_graph = not args.no_graph
     dtype = "bf16" if args.bf16 else "f32"
+    if args.inflight_stack:
+        pipeline.PipelinedSampler.stack_in_flight = True
     if args.split is not None:
         pipeline.SamplerPipeline.default_split = args.split
     args.split = pipeline.SamplerPipeline.default_split

@@ -397,7 +397,8 @@ typedef struct pdse_rowln_desc {
  * (((b G + g)(T + tpad) + tpad + t)(F + 2) + f + 1) 8; the tpad leading rows and the two outer bins of every row are zero and stay
  * zero (the convolution's causal / same padding).  w: bf16 fragments of the 64 x 6 cin weights, K steps in the order (16-channel
  * block, time tap, bin tap): [cin/16][2][3][2 channel tiles][np planes][64 lanes][8] (packing.pack_dense); np = 3: exact
- * three-way split of both operands (six products, fp32-equivalent), np = 1: plain bf16 (the opt-in bf16 mode).
+ * three-way split of both operands (six products, fp32-equivalent), np = 2: f16x2 (PDSE_F16_ACT_EXP; three f16 products,
+ * fp32-equivalent), np = 1: plain bf16 (the opt-in bf16 mode).
  * Replaces pdse_gconv_f32 + pdse_rowln_prelu_f32 of one layer; input and output groups must not overlap. */
 typedef struct pdse_dense_desc {
   float* D;
@@ -411,7 +412,7 @@ typedef struct pdse_dense_desc {
   int32_t g_out;
   int32_t dil, np;
   float eps;
-  int32_t pad_;
+  int32_t wexp;       /* np == 2 (ABI 8, f16x2): w holds fp16 hi / lo planes of W * 2^wexp (packing.f16_wexp); otherwise unused */
 } pdse_dense_desc;
 
 /* Row LayerNorm + PReLU like pdse_rowln_desc - or, with gamma == NULL, a plain re-layout - from a channel-major tensor (rows of F

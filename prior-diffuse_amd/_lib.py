@@ -118,7 +118,7 @@ class RowlnDesc(C.Structure):
 class DenseDesc(C.Structure):
     _fields_ = [("D", _fp), ("w", _fp), ("bias", _fp), ("gamma", _fp), ("beta", _fp), ("slope", _fp),
                 ("B", _i32), ("T", _i32), ("F", _i32), ("G", _i32), ("tpad", _i32), ("g_in", _i32), ("cin", _i32), ("g_out", _i32),
-                ("dil", _i32), ("np", _i32), ("eps", _f32), ("pad_", _i32)]
+                ("dil", _i32), ("np", _i32), ("eps", _f32), ("wexp", _i32)]
 
 
 class RowlnbDesc(C.Structure):

@@ -102,6 +102,16 @@ __device__ __forceinline__ void dn_mm(const dn_ops<3>& o, f32x16 (&acc)[2][2]) {
 #pragma unroll
       for (int m = 0; m < 2; ++m) acc[k][m] = mfma_bf16(dn_u4(o.a[m][pa[q]]), dn_u4(o.b[k][pb[q]]), acc[k][m]);
 }
+// f16x2 (gconv_common.h: split8h): a2 b1, a1 b2, a1 b1 on the f16 matrix cores
+__device__ __forceinline__ void dn_mm(const dn_ops<2>& o, f32x16 (&acc)[2][2]) {
+  constexpr int pa[3] = {1, 0, 0}, pb[3] = {0, 1, 0};
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) acc[k][m] = mfma_f16(dn_u4(o.a[m][pa[q]]), dn_u4(o.b[k][pb[q]]), acc[k][m]);
+}
 __device__ __forceinline__ void dn_mm(const dn_ops<1>& o, f32x16 (&acc)[2][2]) {
 #pragma unroll
   for (int k = 0; k < 2; ++k)
@@ -131,6 +141,7 @@ __global__ __launch_bounds__(512, 1) void dense_kernel(const pdse_dense_desc d, 
   const unsigned lbase = (unsigned)(uintptr_t)lds;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int col = lane & 31, h = lane >> 5;
+  if constexpr (NP == 2) f16_saturate_mode();
 
   // work item: XCD x (= blockIdx % 8) walks items / row blocks x * chunkw ... in order
   const int chunkw = (gm.nwork + 7) >> 3;
@@ -216,6 +227,11 @@ __global__ __launch_bounds__(512, 1) void dense_kernel(const pdse_dense_desc d, 
           *reinterpret_cast<uint4*>(dst) = p1;
           *reinterpret_cast<uint4*>(dst + PSTR) = p2;
           *reinterpret_cast<uint4*>(dst + 2 * PSTR) = p3;
+        } else if constexpr (NP == 2) {
+          uint4 p1, p2;
+          split8h(x, pow2i(PDSE_F16_ACT_EXP), p1, p2);
+          *reinterpret_cast<uint4*>(dst) = p1;
+          *reinterpret_cast<uint4*>(dst + PSTR) = p2;
         } else {
           *reinterpret_cast<uint4*>(dst) = make_uint4(dn_pack_bf16(x[0], x[1]), dn_pack_bf16(x[2], x[3]), dn_pack_bf16(x[4], x[5]),
                                                       dn_pack_bf16(x[6], x[7]));
@@ -282,6 +298,7 @@ __global__ __launch_bounds__(512, 1) void dense_kernel(const pdse_dense_desc d, 
   // ---- epilogue: bias, staged [position][DN_SROW], LayerNorm over the bins of every (row, channel), PReLU, 32-byte entries
   float* const st = reinterpret_cast<float*>(lds);
   float* const part = st + DN_NPOS * DN_SROW;   // [parts][R * 64][2]
+  const float us = NP == 2 ? pow2i(-(PDSE_F16_ACT_EXP + d.wexp)) : 1.0f;
   float* const stats = part + 1024;             // [R * 64][2] (mean, rstd)
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
@@ -294,10 +311,10 @@ __global__ __launch_bounds__(512, 1) void dense_kernel(const pdse_dense_desc d, 
           const int c0 = 32 * m + 8 * j + 4 * h;
           const float4 bv = *reinterpret_cast<const float4*>(d.bias + c0);
           float4 v;
-          v.x = acc[k][m][4 * j + 0] + bv.x;
-          v.y = acc[k][m][4 * j + 1] + bv.y;
-          v.z = acc[k][m][4 * j + 2] + bv.z;
-          v.w = acc[k][m][4 * j + 3] + bv.w;
+          v.x = acc[k][m][4 * j + 0] * us + bv.x;   // us: 1, or (f16x2) the power of two that undoes the operand scaling
+          v.y = acc[k][m][4 * j + 1] * us + bv.y;
+          v.z = acc[k][m][4 * j + 2] * us + bv.z;
+          v.w = acc[k][m][4 * j + 3] * us + bv.w;
           *reinterpret_cast<float4*>(st + p * DN_SROW + c0) = v;
         }
     }
@@ -385,7 +402,7 @@ static int dense_launch_(const pdse_dense_desc* d, hipStream_t s) {
 int pdse_dense_launch(const pdse_dense_desc* d, hipStream_t s) {
   REQ(d && d->D && d->w && d->bias && d->gamma && d->beta && d->slope, "dense: null pointer");
   REQ(d->B > 0 && d->T > 0 && d->F >= DN_SLOTS && d->F <= 192, "dense: bad sizes (36 <= F <= 192)");
-  REQ(d->np == 1 || d->np == 3, "dense: np is 3 (exact split) or 1 (plain bf16)");
+  REQ(d->np == 1 || d->np == 3 || (d->np == 2 && d->wexp >= -40 && d->wexp <= 40), "dense: np is 3 (exact split), 2 (f16x2, wexp within +-40) or 1 (plain bf16)");
   REQ(d->dil >= 1 && d->dil <= d->tpad, "dense: dilation exceeds the time padding of the buffer");
   REQ(d->cin > 0 && (d->cin & 15) == 0, "dense: input channels in multiples of 16");
   const int gi0 = d->g_in, gi1 = d->g_in + d->cin / 8, go0 = d->g_out, go1 = d->g_out + 8;
@@ -396,6 +413,7 @@ int pdse_dense_launch(const pdse_dense_desc* d, hipStream_t s) {
       "dense: buffer, weights and bias are 16-byte aligned");
   // 32-bit lane offsets: two channel groups of one item
   REQ(2ll * (d->T + d->tpad) * (d->F + 2) * 32 < (1ll << 32), "dense: item too large for 32-bit lane offsets");
+  if (d->np == 2) return dense_launch_<2>(d, s);
   return d->np == 3 ? dense_launch_<3>(d, s) : dense_launch_<1>(d, s);
 }
 

@@ -1553,15 +1553,16 @@ class AiaPlan(PlanBase):
     split_gru = True         # (with split_bf16 and the fused form) that recurrence on split-bf16 operands (csrc/gru3.hip)
     split_bf16 = True        # dilated dense blocks and the strided / sub-pixel convolutions as split-bf16 GEMMs (csrc/gconv4.hip)
     dense_fused = True       # (with split_bf16) a dense-block layer = ONE launch on a channel-blocked buffer (csrc/dense.hip)
+    gemm_planes = 2          # operand form of those GEMMs: f16x2 (csrc/dense.hip np 2, csrc/gconv4.hip korder 5); 3: the three-plane bf16 split
     TPAD, G = 8, 40          # leading zero frames (the largest dilation) and 8-channel groups of the dense buffers
 
     def __init__(self, ctx, sd, B, T, plan=None, d=32, split_bf16=None, planes=None):
         """d: d_model of the transformer layers (32: AIA_Transformer(64, 64); 64: AIA_Transformer_merge(128, 64))."""
         if split_bf16 is not None:
             self.split_bf16 = bool(split_bf16)
-        if planes is not None:       # 1: the opt-in bf16 mode - dense blocks / strided convolutions on plain bf16 operands (korder 4)
-            if planes not in (1, 3) or (planes == 1 and not self.split_bf16):
-                raise ValueError("planes is 3 or 1; the one-plane bf16 mode runs on the GEMM kernels (split_bf16)")
+        if planes is not None:       # 3 / 2: bf16x3 / f16x2 (fp32-equivalent); 1: the opt-in bf16 mode - dense blocks / strided convolutions on plain bf16 operands
+            if planes not in (1, 2, 3) or (planes in (1, 2) and not self.split_bf16):
+                raise ValueError("planes is 3 (bf16x3), 2 (f16x2) or 1 (bf16 mode); the one- and two-plane forms run on the GEMM kernels (split_bf16)")
             self.gemm_planes = int(planes)
         self.fused = bool(self.dense_fused and self.split_bf16)
         super().__init__(ctx, plan, ns=(ctx.bank.token(sd), d, self.fused_gru_input, self.split_bf16, self.split_gru, self.gemm_planes,
@@ -1685,8 +1686,10 @@ class AiaPlan(PlanBase):
             cin = 64 * i
             d = L.DenseDesc()
             d.D = D.data_ptr()
-            d.w = self.upw("%s.conv%d.dense%d" % (p, i, npl), lambda i=i, cin=cin: P.pack_dense(
-                P.conv_kmat(self.sd["%s.conv%d.weight" % (p, i)], kk), cin, npl).view(np.int16), np.int16).data_ptr()
+            wk = P.conv_kmat(self.sd["%s.conv%d.weight" % (p, i)], kk)
+            qe = P.f16_wexp(wk) if npl == 2 else 0
+            d.w = self.upw("%s.conv%d.dense%d" % (p, i, npl), lambda wk=wk, cin=cin, qe=qe: P.pack_dense(wk, cin, npl, qe).view(np.int16), np.int16).data_ptr()
+            d.wexp = qe
             d.bias = self._wp("%s.conv%d.bias" % (p, i))
             d.gamma, d.beta = self._wp("%s.norm%d.weight" % (p, i)), self._wp("%s.norm%d.bias" % (p, i))
             d.slope = self._wp("%s.prelu%d.weight" % (p, i))

@@ -463,11 +463,11 @@ def dense_krows(cin):
     return np.asarray(rows, np.int64)
 
 
-def pack_dense(wk, cin, npl=3):
+def pack_dense(wk, cin, npl=3, qe=0):
     """wk [6*cin, 64] (k-major, conv_kmat order) -> uint16 [cin/16 * 6 K steps][2][npl][64][8] (pdse_dense_desc.w)."""
     wk = np.asarray(wk, np.float64).astype(np.float32)
     assert wk.shape == (6 * cin, 64) and cin % 16 == 0
-    return _pack_gemm_rows(wk[dense_krows(cin)], npl)
+    return _pack_gemm_rows(wk[dense_krows(cin)], npl, qe)
 
 
 def unpack_s3_gemm(packed, ntaps, c0, c1, M, npl=3, qe=0):

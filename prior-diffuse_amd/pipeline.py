@@ -104,6 +104,7 @@ class SamplerPipeline:
 
         self.stft = adopt(nets.StftPlan(ctx, B, L_, plan=self.plan, split_bf16=split_bf16)) if with_signal else None
         pplanes = 1 if dtype == "bf16" else None     # bf16 mode: the priors' GEMM-shaped convolutions on plain bf16 operands too (korder 4)
+        aplanes = pplanes if pplanes is not None else ((2 if split == "f16x2" else 3) if split_bf16 else None)   # DB-AIAT: dense blocks (np) and GEMM convolutions
         if prior_name == "GCRN":
             gplanes = pplanes if pplanes is not None else ((2 if split == "f16x2" else 3) if split_bf16 else None)   # korder 5 / 3 (csrc/gconv4.hip)
             self.prior = adopt(nets.GcrnPlan(ctx, prior_sd, B, T, plan=self.plan, split_bf16=split_bf16 or dtype == "bf16", exclusive=exclusive,
@@ -111,9 +112,9 @@ class SamplerPipeline:
         elif prior_name == "DiffUNet":
             self.prior = adopt(nets.EpsNetPlan(ctx, prior_sd, B, T, time_cond=False, plan=self.plan, split_bf16=split_bf16, exclusive=exclusive))
         elif prior_name == "aia_complex_trans_ri":
-            self.prior = adopt(nets.AiaPlan(ctx, prior_sd, B, T, plan=self.plan, split_bf16=split_bf16 or dtype == "bf16", planes=pplanes))
+            self.prior = adopt(nets.AiaPlan(ctx, prior_sd, B, T, plan=self.plan, split_bf16=split_bf16 or dtype == "bf16", planes=aplanes))
         elif prior_name == "dual_aia_trans_merge_crm":
-            self.prior = adopt(nets.DualAiaPlan(ctx, prior_sd, B, T, plan=self.plan, split_bf16=split_bf16 or dtype == "bf16", planes=pplanes))
+            self.prior = adopt(nets.DualAiaPlan(ctx, prior_sd, B, T, plan=self.plan, split_bf16=split_bf16 or dtype == "bf16", planes=aplanes))
         else:
             raise ValueError("prior %r not built (GCRN, DiffUNet, aia_complex_trans_ri, dual_aia_trans_merge_crm)" % prior_name)
         if dtype == "bf16":
@@ -332,13 +333,17 @@ class PipelinedSampler:
     Per-batch results are bit-identical to ``SamplerPipeline.enhance``; only the schedule
     differs.  ``submit`` returns immediately; ``result`` waits for that batch."""
 
+    # measurement switch (bench.py --inflight-stack): let the in-flight pipelines use the launches that wait for their own workgroups
+    # (the TCM stack as one launch; at B = 32 nothing else).  Measured slower in rounds 4 (17.8 vs 17.4 ms) - see DESIGN.md 4.1b.
+    stack_in_flight = False
+
     def __init__(self, device, prior_name, prior_sd, ddpm_sd, B, L_, depth=2, by_batch=False, graph=True, **kw):
         """depth: batches in flight (= buffer sets).  by_batch False: two stage streams (prior | loop);
         True: every batch runs start to end on its own stream, ``depth`` streams round-robin."""
         self.device = torch.device(device)
         self.depth, self.by_batch, self.graph = depth, by_batch, graph
         kw.setdefault("bank", nets.WeightBank())    # the in-flight buffer sets share one packed copy of the weights
-        kw["exclusive"] = False                     # batches in flight share the GPU: no launch may wait for its own workgroups
+        kw["exclusive"] = bool(self.stack_in_flight)   # batches in flight share the GPU: no launch may wait for its own workgroups
         self.pipes = [SamplerPipeline(device, prior_name, prior_sd, ddpm_sd, B, L_=L_, **kw) for _ in range(depth)]
         self.s_prior = torch.cuda.Stream(self.device, priority=-1)   # tiny dependent launches: schedule them first
         self.s_loop = torch.cuda.Stream(self.device)

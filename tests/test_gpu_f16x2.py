@@ -111,6 +111,32 @@ def test_f16x2_gcrn_prior_vs_goldens(L, weights):
     assert rel_l2(net.out.cpu()[0, :, ::16, :], g4["rows"]) < 5e-5          # 401 recurrent frames: the bound of test_gcrn_golden
 
 
+@pytest.mark.parametrize("name,fixture", [("aia_complex_trans_ri", "aia_small"), ("dual_aia_trans_merge_crm", "dual_aia_small")])
+def test_f16x2_aia_priors_vs_goldens(L, weights, name, fixture):
+    """Both DB-AIAT priors with their dense-block layers (csrc/dense.hip, np 2) and GEMM-shaped convolutions (korder 5) in the f16x2
+    form against the reference's goldens (5e-5, the bound of the three-plane form's test), beside the three-plane form."""
+    nets = pkg("nets")
+    g = golden(fixture)
+    x = seeded((2, 2, 12, 161), g["seed_x"])
+    cls = nets.AiaPlan if name == "aia_complex_trans_ri" else nets.DualAiaPlan
+    outs = {}
+    for planes in (2, 3):
+        net = cls(nets.Ctx(DEV), weights(name), 2, 12, planes=planes)
+        net.build()
+        net.finish()
+        net.x.copy_(x)
+        net.plan.run()
+        torch.cuda.synchronize()
+        dn = [d for d, _ in net.descs if isinstance(d, L.DenseDesc)]
+        assert dn and all(d.np == planes for d in dn) and all(d.korder != (3 if planes == 2 else 5) for d, _ in net.descs if isinstance(d, L.GconvDesc))
+        outs[planes] = net.out.cpu().clone()
+        e = rel_l2(outs[planes], g["out"])
+        print("%s planes %d: vs golden %.2e" % (name, planes, e))
+        assert e < 5e-5
+    print("%s f16x2 vs bf16x3: %.2e" % (name, rel_l2(outs[2], outs[3])))
+    assert rel_l2(outs[2], outs[3]) < 2e-5
+
+
 def test_f16x2_sampling_full_size_b32(L, weights):
     """BASELINE config 2 (B = 32, T = 401, GCRN + 6 reverse steps) with split="f16x2": utterances 0 / 17 / 31 bit-identical to their
     B = 1 runs, utterance 0 against the reference's own fp32 loop and its float64 evaluation (<= 1e-4, as the bf16x3 pass);
