@@ -31,12 +31,21 @@ def enhance_sharded(enhance_fn, wav, x_T, group=None, gather=True):
     out = enhance_fn(wav[lo:hi], x_T[lo:hi]) if hi > lo else wav.new_zeros((0, wav.shape[1]))
     if world == 1 or not gather:
         return out
-    # ragged shards: pad to the largest shard, all_gather (one bulk message per peer), trim
+    return gather_shards(out, B, group)
+
+
+def gather_shards(out, B, group=None):
+    """All-gather the per-rank shards ``out`` ([hi - lo, L] of this rank's contiguous range of a global batch of B) into the full
+    [B, L] tensor on every rank.  Ragged shards are padded to the largest shard: one bulk message per peer.  RCCL ("nccl") moves
+    the device buffers peer to peer over xGMI; gloo (CPU rehearsals, several ranks sharing one GPU) gathers host copies.  Also
+    valid for a group of one rank (the collective then runs on that rank alone)."""
+    import torch.distributed as dist
+
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    lo, hi = shard_range(B, world, rank)
     m = (B + world - 1) // world
-    pad = out.new_zeros((m, wav.shape[1]))
+    pad = out.new_zeros((m, out.shape[1]))
     pad[: hi - lo] = out
-    # RCCL ("nccl") moves device buffers peer to peer over xGMI; gloo (CPU rehearsals, several ranks sharing one GPU)
-    # gathers host copies
     via_host = pad.is_cuda and dist.get_backend(group) != "nccl"
     send = pad.cpu() if via_host else pad
     parts = [torch.empty_like(send) for _ in range(world)]

@@ -2,6 +2,10 @@
 value, three f16 MFMA products per multiply-add (csrc/gconv_common.h: split8h; include/pdse.h: PDSE_F16_ACT_EXP,
 pdse_bglu_desc.qexp).  It replaces arithmetic of the reference's fp32 blocks (model/diff3.py:215-351) and is held to the SAME
 goldens and tolerances as the exact three-way bf16 split and the fp32 MFMA kernels; everything through the C-ABI."""
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -197,3 +201,16 @@ def test_f16x2_planes_saturate(L):
     inside = np.abs(xs) < 1000.0
     assert np.max(np.abs(back - xs)[inside] / np.abs(xs)[inside]) <= 2.0 ** -23
     assert 1023.0 < back[0, 3, 1, 2] < 2048.0 and -2048.0 < back[0, 4, 1, 2] < -1023.0
+
+
+def test_rccl_leg_of_the_sharded_path_single_rank(L, weights, tmp_path):
+    """the branch of shard.gather_shards that hands DEVICE buffers to RCCL (backend "nccl"), and the barrier / max-reduce
+    of bench.py's timed region, executed on this box's one GPU in a process group of one rank (two ranks per device are refused by
+    RCCL; the gloo tests cover world size 2): the gathered tensor equals the rank's own result bit for bit."""
+    from conftest import ROOT
+
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29800 + os.getpid() % 1000), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "helpers", "rccl_worker.py"), str(tmp_path)], env=env, timeout=600)
+    assert p.returncode == 0
+    got = torch.load(os.path.join(str(tmp_path), "rccl.pt"))
+    assert got["full"].shape == (5, 4000) and torch.equal(got["full"], got["local"])
