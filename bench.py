@@ -39,6 +39,8 @@ sys.path.insert(0, ROOT)
 EPS_GFLOP_PER_UTT_STEP = 10.29
 FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md, fp32 matrix = fp32 vector peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0         # MI355X_MICROARCH.md, dense bf16 MFMA
+EPS_MB_PER_UTT_STEP = 139.3            # block-boundary bytes of one eps-net forward at T=401 (86,858 elements x T x 4 B)
+HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md, HBM3E
 
 
 def _free_port():
@@ -348,6 +350,21 @@ def main():
                 "avg_launch_ms": round(eps_ms / max(1, sum(per_tag[k]["launches"] for k in ("eps_block", "eps_conv1", "tcm"))), 5),
                 "per_stage_ms": per_tag}
 
+    # ---- which roof binds: the eps-net's arithmetic intensity at block-boundary traffic is 74 FLOP/B (10.29 GFLOP
+    # over 139.3 MB per utterance-step).  The ridge of the six-product bf16 split is 417 TF / 8 TB/s = 52 FLOP/B - matrix-bound; with
+    # three f16 products it is 833 / 8 = 104 FLOP/B: the same work is now HBM-bound, and the line reports that roof (algorithmic
+    # bytes per launch over the same hipEvent time) with the matrix-side fraction beside it.
+    eps_bytes = EPS_MB_PER_UTT_STEP * 1e6 * (T / 401.0) * B * pipe.nsteps
+    ridge = peak * 1e12 / (HBM_PEAK_GBS * 1e9)
+    if args.split_bf16 and not args.bf16 and (eps_flop / eps_bytes) < ridge:
+        gbs = eps_bytes / (eps_ms * 1e-3) / 1e9
+        mf = {k: roofline[k] for k in ("achieved", "peak", "unit", "peak_note", "frac", "frac_of_fp32_mfma_peak")}
+        roofline.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                         "peak_note": "HBM3E 8 TB/s (MI355X_MICROARCH.md); arithmetic intensity %.0f FLOP/B at block-boundary traffic < ridge %.0f "
+                                      "FLOP/B of the f16 dense peak / 3" % (eps_flop / eps_bytes, ridge),
+                         "algorithmic_bytes_per_launch": round(eps_bytes / n_eps_launch), "mfma": mf})
+        del roofline["frac_of_fp32_mfma_peak"]
+
     # ---- the single largest launch of the eps-net: algorithmic FLOPs from its descriptor / its own hipEvent time
     lib = importlib.import_module("prior-diffuse_amd._lib")
 
@@ -388,7 +405,7 @@ def main():
         "kernel": top_name + " BIGLU%s, %d taps, 32 -> 32 -> %d channels, %d x %d x %d positions" % (
             " dual-phase" if top_dual else "", top_d.ntaps, top_d.C2, top_d.B, top_d.Tout, top_d.Fout),
         "ms": round(top_ms, 4), "algorithmic_gflop": round(gconv_flops(top_d) / 1e9, 2),
-        "achieved": round(top_tf, 2), "frac": round(top_tf / peak, 4)}
+        "achieved": round(top_tf, 2), "unit": "TFLOP/s", "frac": round(top_tf / peak, 4), "frac_of": "the matrix roof (%.0f TFLOP/s)" % peak}
 
     if args.bf16:
         # the bf16 row: the BiConv(Trans)GLU launches against the HBM roof (north_star frames configs 2/4/5 as HBM-bound) -

@@ -656,8 +656,11 @@ typedef struct pdse_aham_desc {
  *   three blocks (packing.pack_s3_gather(.., 3, 16)).
  * ------------------------------------------------------------------------------------------------------------- */
 /* f16x2 planes (np == 2) hold (value * 2^PDSE_F16_ACT_EXP) as hi = RN16(.), lo = RN16(. - hi): exact to half an fp32 ulp for
- * 2^-8 <= |value| < 1023 (lo a normal fp16), absolute error <= 2^-31 below, saturating at +-1023.98 (MODE.FP16_OVFL) above. */
-#define PDSE_F16_ACT_EXP 6
+ * 2^-6 <= |value| < 4094 (lo a normal fp16); below, the absolute error is <= 2^-29 (under the fp32 ulp of any value >= 2^-5 it is
+ * added to); a value beyond +-4094 becomes an INFINITY in its planes (IEEE conversion, no saturation), so it surfaces as a
+ * non-finite result (SamplerPipeline.check() raises; the drop-in trainer then re-runs that geometry on the three-plane bf16 split)
+ * instead of a silently clipped one.  Nominal activations of the path (unit-RMS spectrograms): |value| <= ~12 (tools/act_range.py). */
+#define PDSE_F16_ACT_EXP 4
 
 typedef struct pdse_bglu_desc {
   const uint16_t* hp;      /* input planes, or NULL for encoder stage 1 */

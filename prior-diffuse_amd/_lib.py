@@ -257,6 +257,11 @@ class PdseError(RuntimeError):
     """Non-zero status from libpdse.so (the reference raises Python exceptions only)."""
 
 
+class PdseRangeError(PdseError):
+    """A pass on f16x2 operands produced non-finite values: an activation left the fp16 window of include/pdse.h
+    (PDSE_F16_ACT_EXP; its planes became infinities).  The same pass on the three-plane bf16 split has no such window."""
+
+
 _lib = None
 
 

@@ -186,7 +186,6 @@ __global__ __launch_bounds__(PIPE ? 256 : 512, PIPE ? 1 : 2) void bglu_kernel(co
   const int qG = NP == 2 ? d.qexp[0] : 0, qLC = NP == 2 ? d.qexp[1] : 0, qC2 = NP == 2 ? d.qexp[2] : 0, qNX = NP == 2 ? d.qexp[3] : 0;
   [[maybe_unused]] const float s_in = pow2i(PE), s_G = pow2i(-qG), s_LC = pow2i(-(PE + qLC)), s_C2 = pow2i(-qC2), s_NX = pow2i(-qNX),
                                s_C2out = pow2i(-(PE + qC2)), s_NXout = pow2i(-(PE + qNX)), s_NXin = pow2i(PE + qNX);
-  if constexpr (NP == 2) f16_saturate_mode();
 
   // ---- the LDS image: every weight fragment of the launch by LDS-DMA (1 KB per wave instruction), then the floats
   {
@@ -1269,7 +1268,6 @@ __global__ __launch_bounds__(256) void planes_kernel(const pdse_planes_desc d) {
     x[e] = d.in[(int64_t)b * d.in_sb + (int64_t)c * d.in_sc + (int64_t)t * d.in_st + (int64_t)f * d.in_sf];
   }
   uint4 p[NP];
-  if constexpr (NP == 2) f16_saturate_mode();
   split8p<NP>(x, p, NP == 2 ? pow2i(PDSE_F16_ACT_EXP) : 1.0f);
   uint4* const base = reinterpret_cast<uint4*>(d.hp + (int64_t)b * d.hp_sb) + ((int64_t)(t + d.hp_t0) * 4 + g) * (NP * d.hp_Fp) + f + d.hp_f0;
 #pragma unroll

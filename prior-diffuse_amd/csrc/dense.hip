@@ -141,7 +141,6 @@ __global__ __launch_bounds__(512, 1) void dense_kernel(const pdse_dense_desc d, 
   const unsigned lbase = (unsigned)(uintptr_t)lds;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int col = lane & 31, h = lane >> 5;
-  if constexpr (NP == 2) f16_saturate_mode();
 
   // work item: XCD x (= blockIdx % 8) walks items / row blocks x * chunkw ... in order
   const int chunkw = (gm.nwork + 7) >> 3;

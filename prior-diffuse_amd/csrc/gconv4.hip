@@ -178,7 +178,6 @@ __global__ __launch_bounds__(512, 2) void gconv4_kernel(const pdse_gconv_desc d)
   const int mtiles = (d.Cout + 31) >> 5;
   const int mt0 = blockIdx.z * MT;
 
-  if constexpr (NP == 2) f16_saturate_mode();
   const int cbn0 = d.in0.C >> 4, cbn1 = d.in1.C >> 4;                    // 16-channel blocks per source
   const int cps0 = (cbn0 + G4_CH - 1) / G4_CH, cps1 = (cbn1 + G4_CH - 1) / G4_CH;   // chunks per (source, tap)
   const int nch0 = d.ntaps * cps0, nch = nch0 + d.ntaps * cps1;

@@ -165,9 +165,8 @@ __device__ __forceinline__ f32x16 mfma_f16(const uint4& a, const uint4& b, const
 // 2^e as a float (|e| < 127)
 __device__ __forceinline__ float pow2i(const int e) { return __uint_as_float((uint32_t)(127 + e) << 23); }
 
-// MODE.FP16_OVFL = 1: a conversion to fp16 that overflows gives +-65504 instead of +-infinity (the planes of a value beyond
-// the fp16 range saturate instead of poisoning every sum they enter)
-__device__ __forceinline__ void f16_saturate_mode() { __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1); }
+// Conversions are IEEE (MODE.FP16_OVFL stays 0): a scaled value beyond the fp16 range becomes an infinity in its planes and a
+// non-finite number in every sum it enters - it surfaces at the end of the path (SamplerPipeline.check) instead of passing for a value.
 
 // x[0..7] * sc -> two planes of 8 fp16 (element j in the low / high half of dword j >> 1): v_pk_mul, v_cvt_pk_f16_f32,
 // two v_cvt_f32_f16, v_pk_add, v_cvt_pk_f16_f32 per pair of values (the bf16 three-way split takes eleven)

@@ -176,7 +176,6 @@ __device__ __forceinline__ void tcm2_block(const pdse_tcm2_desc& d, float* const
   constexpr int PE = NP == 2 ? PDSE_F16_ACT_EXP : 0;
   [[maybe_unused]] const float s_pl = pow2i(PE), s_A = pow2i(-(PE + (NP == 2 ? d.qexp[0] : 0))), s_2 = pow2i(-(PE + (NP == 2 ? d.qexp[1] : 0))),
                                s_N = pow2i(-(PE + (NP == 2 ? d.qexp[2] : 0)));
-  if constexpr (NP == 2) f16_saturate_mode();
 #ifdef PDSE_DIAG
   long long* trace = (HSA == 0) ? g_trace : nullptr;
 #else

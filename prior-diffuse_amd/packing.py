@@ -502,7 +502,7 @@ def bf16_to_f32(u):
 # f16x2 operands (np == 2; include/pdse.h: PDSE_F16_ACT_EXP, csrc/gconv_common.h: split8h): a value, scaled by a power of two
 # into the fp16 range, is hi = RN16(x), lo = RN16(x - hi) - 22 significand bits and the sign of lo, |x - hi - lo| <= 2^-23 |x|
 # while lo is a normal fp16 - and a product is a1 b1 + a1 b2 + a2 b1 on the f16 matrix cores (fp32 accumulation).
-F16_ACT_EXP = 6            # activations: planes hold value * 2^6 (exact for 2^-8 <= |value| < 1023)
+F16_ACT_EXP = 4            # activations: planes hold value * 2^4 (exact for 2^-6 <= |value| < 4094; include/pdse.h)
 F16_MAX = 65504.0
 
 
@@ -517,11 +517,13 @@ def f16_wexp(*mats):
 
 
 def split_f16x2(x):
-    """float32 array (already scaled) -> (hi, lo) uint16 fp16 bit patterns: hi = RN16(x) saturated at +-65504 (what the
-    kernels' MODE.FP16_OVFL conversion does), lo = RN16(x - hi)."""
+    """float32 array (already scaled) -> (hi, lo) uint16 fp16 bit patterns: hi = RN16(x), lo = RN16(x - hi), IEEE conversions as
+    the kernels' v_cvt_pk_f16_f32: a value beyond the fp16 range gives hi = +-inf, lo = -+inf (their sum is not a number: an
+    overflow never passes for a value)."""
     x = np.ascontiguousarray(x, np.float32)
-    hi = np.clip(x, -F16_MAX, F16_MAX).astype(np.float16)
-    lo = np.clip(x - hi.astype(np.float32), -F16_MAX, F16_MAX).astype(np.float16)      # beyond the window: lo saturates too
+    with np.errstate(over="ignore", invalid="ignore"):
+        hi = x.astype(np.float16)
+        lo = (x - hi.astype(np.float32)).astype(np.float16)
     return hi.view(np.uint16), lo.view(np.uint16)
 
 

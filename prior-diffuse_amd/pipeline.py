@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from . import _lib as L
-from . import nets
+from . import nets, packing
 from .params import PRIOR_SCALE_C, params as default_params
 from .schedule import inference_schedule, step_coefficients
 
@@ -231,6 +231,10 @@ class SamplerPipeline:
                     st.zero_()
                     raise L.PdseError((what % (code - 1)) + ": its workgroups wait for each other and were not all resident in time (is "
                                       "another workload sharing the GPU?); build the pipeline with exclusive=False")
+        if self.split == "f16x2" and self.split_bf16 and self.dtype == "f32" and not bool(torch.isfinite(self.spec).all()):
+            raise L.PdseRangeError("non-finite values in the enhanced spectrogram of an f16x2 pass: an activation beyond +-%g left the fp16 "
+                                   "window (include/pdse.h: PDSE_F16_ACT_EXP), or the input was not finite; build the pipeline with "
+                                   "split='bf16x3' (ComplexDDPMTrainer does so for this geometry by itself)" % (65504.0 / 2 ** packing.F16_ACT_EXP))
 
     def sample(self, feat, x_T, graph=False):
         """feat, x_T [B,2,T,161] -> (enhanced compressed spectrogram, X_init); the

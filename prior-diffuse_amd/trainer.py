@@ -118,6 +118,8 @@ class ComplexDDPMTrainer(object):
         a new plan re-records its descriptors (milliseconds) against the weights already packed in ``self.bank``;
         only ``MAX_PLANS`` geometries keep their activation buffers, the least recently used one is dropped."""
         key = (B, T, L_, bool(getattr(self.args, "sigma", False)), bool(self.params.fast_sampling))
+        if not hasattr(self, "_range_fallback"):
+            self._range_fallback = set()       # geometries whose f16x2 pass left the fp16 window once: they run on the three-plane bf16 split
         pipe = self._pipes.get(key)
         self._hits[key] = self._hits.get(key, 0) + 1 if pipe is not None else 0
         if pipe is None:
@@ -126,10 +128,29 @@ class ComplexDDPMTrainer(object):
             pipe = self._pipes[key] = SamplerPipeline(
                 self.device, self.prior_name, self.prior_sd, self.ddpm_sd, B, T=T, L_=L_,
                 fast_sampling=self.params.fast_sampling, use_sigma=key[3], params=self.params, deltamu=self.deltamu,
-                cond=self.cond, bank=self.bank, xT_plus_init=self.xT_plus_init, exclusive=self.exclusive, dtype=self.dtype)
+                cond=self.cond, bank=self.bank, xT_plus_init=self.xT_plus_init, exclusive=self.exclusive, dtype=self.dtype,
+                split="bf16x3" if key in self._range_fallback else None)
         else:
             self._pipes.move_to_end(key)
         return pipe
+
+    def _checked(self, run, **geom):
+        """``run(pipe) -> result`` on the plan of a geometry, verified (``SamplerPipeline.check``: synchronises).  A pass on f16x2
+        operands whose activations left the fp16 window shows as non-finite output (include/pdse.h: PDSE_F16_ACT_EXP): the geometry
+        is then rebuilt on the exact three-plane bf16 split - no window - and the pass repeated; later calls stay on it."""
+        pipe = self._pipe(**geom)
+        res = run(pipe)
+        try:
+            pipe.check()
+        except L.PdseRangeError as e:
+            key = next(reversed(self._pipes))
+            logging.warning("%s - repeating this geometry with split='bf16x3'", e)
+            self._range_fallback.add(key)
+            del self._pipes[key]
+            pipe = self._pipe(**geom)
+            res = run(pipe)
+            pipe.check()
+        return res
 
     def _x_T(self, shape, x_T):
         if x_T is None:                                               # :947-950 randn_like(init)
@@ -166,9 +187,8 @@ class ComplexDDPMTrainer(object):
         batch = torch.nn.utils.rnn.pad_sequence(wavs, batch_first=True).to(self.device)
         B, L_ = batch.shape
         T = 1 + L_ // 160
-        pipe = self._pipe(B, L_=L_)
-        out, _ = pipe.enhance(batch, self._x_T((B, 2, T, 161), x_T), lens=lens)
-        pipe.check()
+        x_T = self._x_T((B, 2, T, 161), x_T)
+        out = self._checked(lambda pipe: pipe.enhance(batch, x_T, lens=lens)[0], B=B, L_=L_)
         cut = [(n // 160) * 160 if trim_to_frames else n for n in lens]
         return [out[i, :cut[i]].clone() for i in range(B)]
 
@@ -193,8 +213,11 @@ class ComplexDDPMTrainer(object):
                 except (ValueError, EOFError, wavio.wave.Error) as e:
                     logging.warning("skipping %s: %s", path, e)
                     continue
-                out = self.enhance(wav)[0].cpu().numpy()
-                self._pipes[next(reversed(self._pipes))].check()
+                L_ = wav.shape[1]
+                x_T = self._x_T((1, 2, 1 + L_ // 160, 161), None)             # :947-950 randn_like(init): the file's draw, kept for a repeat
+                wav_d = wav.to(self.device, torch.float32)
+                out = self._checked(lambda pipe: pipe.enhance(wav_d, x_T, graph=self._hits.get(next(reversed(self._pipes)), 0) >= 1)[0],
+                                    B=1, L_=L_)[0].cpu().numpy()
                 if rng_fidelity:
                     shape = (1, 2, 1 + wav.shape[1] // 160, 161)
                     for _ in range(len(self._pipes[next(reversed(self._pipes))].schedule[0]) - 1):

@@ -173,15 +173,90 @@ def test_f16x2_sampling_full_size_b32(L, weights):
         assert e < 1e-4
 
 
-def test_f16x2_planes_saturate(L):
-    """A value beyond the fp16 window (|x| * 2^6 > 65504) leaves finite, saturated planes (MODE.FP16_OVFL), never an infinity; values
-    inside it come back within half an fp32 ulp."""
+@pytest.mark.parametrize("scale_x,scale_w", [(2.0 ** -6, 1.0), (0.25, 1.0), (4.0, 1.0), (1.0, 2.0 ** -5), (1.0, 0.5)])
+def test_f16x2_is_fp32_equivalent_across_input_and_weight_scales(L, weights, scale_x, scale_w):
+    """What "fp32-equivalent" means away from the unit-scale fixtures.  The eps-net is evaluated on inputs 64 times smaller and 4 times
+    larger than the fixtures' spectrograms, and with the gather weights of every stage scaled (the host picks a power-of-two exponent
+    per weight group, so weight magnitude must not matter), by: the oracle in float64 (the exact answer), the oracle in fp32, the
+    f16x2 kernels and the exact-fp32 MFMA kernels.  The random network amplifies rounding noise with the input scale (at 16 x
+    every fp32 implementation, the reference's own arithmetic included, is 0.2 from the float64 answer; with the gather weights doubled
+    the activations grow by 2 per stage, the fp32 oracle is 0.35 from it and the f16x2 pass ends non-finite - loudly, see the next test),
+    so the bound is relative: the
+    f16x2 kernels must sit no further from the exact answer than 1.5 x the fp32 oracle does (+ 1e-6)."""
+    import importlib
+
+    R = importlib.import_module("oracle.restate")
+    nets = pkg("nets")
+    sd = dict(weights("DiffUNet1"))
+    if scale_w != 1.0:
+        for k in list(sd):
+            if k.endswith((".l.weight", ".r.weight")):
+                sd[k] = sd[k] * scale_w
+    B, T = 2, 40
+    x, xi = seeded((B, 2, T, 161), 31) * scale_x, seeded((B, 2, T, 161), 32) * (0.3 * scale_x)
+    t = torch.full((B,), 10.451817)
+    with torch.no_grad():
+        ref32 = R.diffunet1_forward(sd, x, xi, t)
+        exact = R.diffunet1_forward({k: v.double() for k, v in sd.items()}, x.double(), xi.double(), t.double())
+    outs = {}
+    for tag, kw in (("f16x2", dict(planes=2)), ("fp32", dict(split_bf16=False))):
+        net = nets.EpsNetPlan(nets.Ctx(DEV), sd, B, T, time_cond=True, nsteps=1, **kw)
+        net.build_time()
+        net.build_step(0)
+        net.finish()
+        net.x.copy_(x)
+        net.x_init.copy_(xi)
+        net.tsteps.copy_(t.view(1, B))
+        net.plan.run()
+        torch.cuda.synchronize()
+        assert (tag == "fp32") == (not any(isinstance(d, L.BgluDesc) for d, _ in net.descs))
+        outs[tag] = net.out.cpu().clone()
+    e16, e32k, e32o = rel_l2(outs["f16x2"], exact), rel_l2(outs["fp32"], exact), rel_l2(ref32, exact)
+    print("input scale %g, gather-weight scale %g: distance to the float64 answer - f16x2 %.2e | fp32 MFMA kernels %.2e | fp32 oracle %.2e" % (
+        scale_x, scale_w, e16, e32k, e32o))
+    assert torch.isfinite(outs["f16x2"]).all() and e16 < 1.5 * e32o + 1e-6
+
+
+def test_f16x2_window_overflow_is_loud_and_the_trainer_falls_back(L, weights, tmp_path):
+    """An activation beyond the fp16 window (|value| 2^4 > 65504) must not pass for a value: its planes are infinities (IEEE
+    conversion), the pass ends non-finite, SamplerPipeline.check() raises PdseRangeError - and the drop-in trainer repeats the
+    geometry on the three-plane bf16 split, whose result it returns (bit-identical to a pipeline built with split="bf16x3")."""
+    import argparse
+
+    sd = dict(weights("DiffUNet1"))
+    sd["en.conv3.conv1.bias"] = sd["en.conv3.conv1.bias"] + 3.0e4          # conv1 output of encoder stage 3: far outside +-4094
+    wav, x_T = pkg("synth").synthetic_waveforms(2, 4000, seed=77)
+    P = pkg("pipeline").SamplerPipeline
+    pipe = P(DEV, "GCRN", weights("GCRN"), sd, 2, L_=4000)
+    assert pipe.split == "f16x2"
+    pipe.enhance(wav.to(DEV), x_T.to(DEV))
+    with pytest.raises(L.PdseRangeError, match="fp16"):
+        pipe.check()
+    ref = P(DEV, "GCRN", weights("GCRN"), sd, 2, L_=4000, split="bf16x3")
+    want, _ = ref.enhance(wav.to(DEV), x_T.to(DEV))
+    ref.check()
+    assert torch.isfinite(want).all()
+    ns = argparse.Namespace
+    tr = pkg("trainer").ComplexDDPMTrainer(
+        ns(retrain=False, joint=True, draw=False, sigma=False, checkpoint="x", generated_wav=str(tmp_path)),
+        ns(model=ns(name="GCRN"), train=ns(fft_num=320, win_size=320, win_shift=160, feat_type="sqrt")),
+        device=DEV, prior_state_dict=weights("GCRN"), ddpm_state_dict=sd, exclusive=False)
+    got = tr.enhance_batch([wav[0], wav[1]], x_T=x_T)
+    assert len(tr._range_fallback) == 1 and torch.equal(torch.stack(got), want)
+    got2 = tr.enhance_batch([wav[0], wav[1]], x_T=x_T)                      # the geometry stays on the fallback: no second warning, same bits
+    assert torch.equal(torch.stack(got2), want)
+
+
+def test_f16x2_planes_of_values_beyond_the_window_are_infinities(L):
+    """The split kernel against its host restatement bit for bit; values inside the window come back within half an fp32 ulp, a value
+    beyond it as hi = +-inf, lo = -+inf (never a clipped number)."""
     Pk = pkg("packing")
     B, T, F = 1, 3, 5
+    top = 65504.0 / 2 ** Pk.F16_ACT_EXP                                       # the largest plane value in true scale
     x = seeded((B, 32, T, F), 21)
     x[0, 3, 1, 2] = 1.0e6
-    x[0, 4, 1, 2] = -3.0e4
-    x[torch.abs(x) < 2.0 ** -8] = 0.5
+    x[0, 4, 1, 2] = -2.0 * top
+    x[torch.abs(x) < 2.0 ** (-2 - Pk.F16_ACT_EXP)] = 0.5
     shp = Pk.hp_shape(B, T, F, 2)
     hp = torch.zeros(*shp, dtype=torch.int16, device=DEV)
     d = L.PlanesDesc()
@@ -194,13 +269,13 @@ def test_f16x2_planes_saturate(L):
     plan.run()
     torch.cuda.synchronize()
     raw = hp.cpu().numpy().view(np.uint16)
-    back = Pk.hp_join(raw)
-    assert np.all(np.isfinite(back))
     assert np.array_equal(raw, Pk.hp_split(x.numpy(), 2))                     # the host restatement of the split, bit for bit
+    with np.errstate(invalid="ignore"):
+        back = Pk.hp_join(raw)
     xs = x.numpy().copy()
-    inside = np.abs(xs) < 1000.0
+    inside = np.abs(xs) < 0.97 * top
     assert np.max(np.abs(back - xs)[inside] / np.abs(xs)[inside]) <= 2.0 ** -23
-    assert 1023.0 < back[0, 3, 1, 2] < 2048.0 and -2048.0 < back[0, 4, 1, 2] < -1023.0
+    assert not np.isfinite(back[0, 3, 1, 2]) and not np.isfinite(back[0, 4, 1, 2]) and np.isfinite(back[inside]).all()
 
 
 def test_rccl_leg_of_the_sharded_path_single_rank(L, weights, tmp_path):

@@ -253,10 +253,11 @@ def test_eps_net_plan_f16x2_mode_vs_oracle(weights):
     back = Pk.unpack_bglu_gather(Pk.pack_bglu_gather(w, 3, 2, q), 3, q)
     assert 2.0 ** 13 <= np.abs(w).max() * 2.0 ** q < 2.0 ** 14 and np.max(np.abs(back - w) / np.abs(w)) <= 2.0 ** -23
     h = np.asarray(seeded((1, 32, 3, 9), 10))
-    h[np.abs(h) < 2.0 ** -8] = 0.25
+    h[np.abs(h) < 2.0 ** (-2 - Pk.F16_ACT_EXP)] = 0.25
     assert np.max(np.abs(Pk.hp_join(Pk.hp_split(h, 2)) - h) / np.abs(h)) <= 2.0 ** -23
-    big = np.full((1, 32, 1, 1), 1e6, np.float32)                                # beyond the window: saturates, no infinity
-    assert np.all(np.isfinite(Pk.hp_join(Pk.hp_split(big, 2)))) and Pk.hp_join(Pk.hp_split(big, 2)).max() < 2100.0
+    big = np.full((1, 32, 1, 1), 1e6, np.float32)                                # beyond the window: infinities in the planes, never a clipped value
+    with np.errstate(invalid="ignore"):
+        assert not np.isfinite(Pk.hp_join(Pk.hp_split(big, 2))).any()
 
 
 def test_priors_one_plane_gemm_mode_vs_oracle(weights):
