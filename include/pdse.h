@@ -640,7 +640,8 @@ typedef struct pdse_aham_desc {
  *  - BatchNorm is folded into conv2 (W' = diag(s) Wc2, b' = s bc2 + t), -log2(e) into l_conv / r_conv
  *    (sigmoid(m) = rcp(1 + exp2(m'))), the gather biases seed the accumulators: all on the host, in float64.
  *
- * hp tensor (uint16 = bf16 bit patterns), np planes (3: exact split, fp32-equivalent; 1: plain bf16):
+ * hp tensor (uint16 = bf16 bit patterns; np == 2: fp16 bit patterns), np planes (3: exact bf16 split, fp32-equivalent; 2: f16x2 - fp16
+ * hi / lo of value * 2^PDSE_F16_ACT_EXP, fp32-equivalent, see below; 1: plain bf16):
  *     hp[b][tp][g][plane][fp][e],   tp in [0, Tp), g in [0, 4), fp in [0, Fp), e in [0, 8)
  *   holds channel c = 16 (g >> 1) + 8 (e >> 2) + 4 (g & 1) + (e & 3) of frame t = tp - t0, bin f = fp - f0: group
  *   g = 2 q + h is what lane half h feeds to K block q, and (q, h, e) is the accumulator register order of the

@@ -55,6 +55,7 @@ class ComplexDDPMTrainer(object):
 
             exclusive = not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
         self.exclusive = bool(exclusive)
+        self._range_fallback = set()           # geometries whose f16x2 pass left the fp16 window once: they run on the three-plane bf16 split (_checked)
         self.c = PRIOR_SCALE_C                                        # :30
         self.args = deepcopy(args)
         self.config = deepcopy(config)
@@ -118,8 +119,6 @@ class ComplexDDPMTrainer(object):
         a new plan re-records its descriptors (milliseconds) against the weights already packed in ``self.bank``;
         only ``MAX_PLANS`` geometries keep their activation buffers, the least recently used one is dropped."""
         key = (B, T, L_, bool(getattr(self.args, "sigma", False)), bool(self.params.fast_sampling))
-        if not hasattr(self, "_range_fallback"):
-            self._range_fallback = set()       # geometries whose f16x2 pass left the fp16 window once: they run on the three-plane bf16 split
         pipe = self._pipes.get(key)
         self._hits[key] = self._hits.get(key, 0) + 1 if pipe is not None else 0
         if pipe is None:
