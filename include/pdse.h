@@ -344,6 +344,12 @@ typedef struct pdse_glstm_desc {
   int64_t y_sb, y_st, y_su, y_sg;
   int32_t B, Bp, T, H, G;
   float eps;
+  /* ABI 8: slices of 8 hidden units per workgroup - 0 / 1: one (3 x 128 workgroups per step at B <= 32; what plans that share the
+     GPU with other batches take), 2: two slices from ONE fetch of the group's state (3 x 64 workgroups, a CU each: 10.8 instead of
+     11.7 us per step when the plan owns the GPU; measured slower by 1 % with three batches in flight).  Same summation orders:
+     bit-identical results. */
+  int32_t slices;
+  int32_t pad_;
 } pdse_glstm_desc;
 
 /* The same grouped LSTM (both layers + LayerNorm 1, gcrn.py:22-35) as ONE persistent launch for small batches

@@ -101,7 +101,7 @@ class GlstmDesc(C.Structure):
     _fields_ = [("gx1", _fp), ("whh1", _fp), ("wih2", _fp), ("r2", _fp), ("c2", _fp), ("whh2", _fp),
                 ("hT1", _fp), ("cst1", _fp), ("hT2", _fp), ("cst2", _fp), ("gx2", _fp), ("part", _fp), ("y", _fp),
                 ("y_sb", _i64), ("y_st", _i64), ("y_su", _i64), ("y_sg", _i64),
-                ("B", _i32), ("Bp", _i32), ("T", _i32), ("H", _i32), ("G", _i32), ("eps", _f32)]
+                ("B", _i32), ("Bp", _i32), ("T", _i32), ("H", _i32), ("G", _i32), ("eps", _f32), ("slices", _i32), ("pad_", _i32)]
 
 
 class GlstmpDesc(C.Structure):

@@ -134,13 +134,20 @@ __device__ long long* g_trace_l = nullptr;   // PDSE_GLSTM_TRACE=1 (diagnostic):
           (i) == 0 ? wall_clock64() : clock64();                                                                \
   } while (0)
 
+// NS = slices of 8 hidden units (32 gate rows) per workgroup.  NS = 1 (rounds 2-4): 3 x 128 workgroups per step, each pulling its
+// 64 KB weight slice AND the 64 KB state of its group through one CU's L2 port - 48 MB per step, half of it the state, and 128 of
+// the 256 CUs hold two workgroups (A alone 6.9 us, A + C 11.3: the stages queue for the same ports).  NS = 2 (round 4): the two
+// slices of a workgroup share ONE fetch of the state (36 MB per step), 3 x 64 workgroups sit on a CU of their own, every summation
+// keeps its order (reduction over the 8 waves per row, LayerNorm partials per 8 units): results are bit-identical to NS = 1.
+template <int NS>
 __global__ __launch_bounds__(512) void glstm_wave_kernel(const pdse_glstm_desc d, const int s, const int stage_mask) {
-  __shared__ float red[8][32][33];
-  __shared__ float stat[16][32][2];
-  __shared__ __attribute__((aligned(16))) float gxs[4][32][8];   // stage A: this frame's gate pre-activations [gate][item][unit]
+  extern __shared__ __attribute__((aligned(16))) float lds_[];
+  float (*red)[32 * NS][33] = reinterpret_cast<float (*)[32 * NS][33]>(lds_);                    // [8 waves][rows][items + 1]
+  float (*stat)[32][2] = reinterpret_cast<float (*)[32][2]>(lds_ + 8 * 32 * NS * 33);             // [16][32][2]
+  float (*gxs)[32][8 * NS] = reinterpret_cast<float (*)[32][8 * NS]>(lds_ + 8 * 32 * NS * 33 + 16 * 32 * 2);   // stage A: gate pre-activations [gate][item][unit]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = lane & 31, h = lane >> 5;
-  const int slice = blockIdx.x, g = blockIdx.y;
+  const int slice = blockIdx.x * NS, g = blockIdx.y;
   const int nbt = d.Bp >> 5;
   const int stage = blockIdx.z / nbt, bt = blockIdx.z - stage * nbt;
   const int t = s - stage;
@@ -180,19 +187,22 @@ __global__ __launch_bounds__(512) void glstm_wave_kernel(const pdse_glstm_desc d
   }
   const float4* A4 = reinterpret_cast<const float4*>(Aw) + ((size_t)(g * (H / 8) + slice) * (H / 8)) * 64 + lane;
 
-  f32x16 acc;
+  f32x16 acc[NS];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int n = 0; n < NS; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
   if (!skip) {
-    // wave w multiplies k-groups 8w .. 8w+7 (32 k-steps); all 16 loads are requested before the first MFMA
-    float4 av[8], bv[8];
+    // wave w multiplies k-groups 8w .. 8w+7 (32 k-steps); all loads are requested before the first MFMA
+    float4 av[NS][8], bv[8];
     const int q0 = wave * 8;
     const float* hs = q0 < 32 ? hsrc0 : hsrc1;
     const int kq = (q0 < 32 ? kq0 : kq1) + (q0 & 31);
     const float4* B4 = reinterpret_cast<const float4*>(hs) + ((size_t)kq * 2 + h) * Bp + bt * 32 + col;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      av[i] = A4[(size_t)(q0 + i) * 64];
+#pragma unroll
+      for (int n = 0; n < NS; ++n) av[n][i] = A4[((size_t)n * (H / 8) + q0 + i) * 64];   // slice + n: the next (H/8) k-groups of the packed weights
       bv[i] = B4[(size_t)i * 2 * Bp];
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -202,27 +212,32 @@ __global__ __launch_bounds__(512) void glstm_wave_kernel(const pdse_glstm_desc d
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].x, bv[i].x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].y, bv[i].y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].z, bv[i].z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].w, bv[i].w, acc, 0, 0, 0);
+#pragma unroll
+      for (int n = 0; n < NS; ++n) {
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[n][i].x, bv[i].x, acc[n], 0, 0, 0);
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[n][i].y, bv[i].y, acc[n], 0, 0, 0);
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[n][i].z, bv[i].z, acc[n], 0, 0, 0);
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[n][i].w, bv[i].w, acc[n], 0, 0, 0);
+      }
     }
   }
 
   // ---- epilogue operands, requested before the reduction barrier
-  const int u = (threadIdx.x >> 5) & 7, bb = threadIdx.x & 31;   // threads 0..255: (unit, batch item)
+  constexpr int NFIN = 256 * NS;                                 // (unit, batch item) threads
+  const int uu = (threadIdx.x >> 5) & (8 * NS - 1), bb = threadIdx.x & 31;
+  const int sl = uu >> 3, u = uu & 7;                            // slice within the workgroup, unit within the slice
   const int b = bt * 32 + bb;
-  const int hu = slice * 8 + u;
+  const int hu = (slice + sl) * 8 + u;
   float pre[4] = {0.f, 0.f, 0.f, 0.f};
   float4 gx4 = make_float4(0.f, 0.f, 0.f, 0.f);
   float c_old = 0.f;
   const size_t ci = ((size_t)g * H + hu) * Bp + b;
-  if (threadIdx.x < 256) {
+  if (threadIdx.x < NFIN) {
     if (stage == 0) {
       // gx1 [G][T][Bp][4H] (gate rows innermost, pdse.h): thread i fetches four consecutive units of one gate and item
       // as ONE 16-byte load (one instruction per thread, 32 lines per wave instead of 4 x 32) and the values reach
       // their (unit, item) threads through LDS behind the reduction barrier
-      const int lq = threadIdx.x >> 6, lb = (threadIdx.x >> 1) & 31, lu = (threadIdx.x & 1) * 4;
+      const int lq = threadIdx.x / (64 * NS), lb = (threadIdx.x / (2 * NS)) & 31, lu = (threadIdx.x & (2 * NS - 1)) * 4;
       gx4 = *reinterpret_cast<const float4*>(d.gx1 + (((size_t)g * d.T + t) * Bp + bt * 32 + lb) * (4 * H) + (size_t)lq * H + slice * 8 + lu);
       if (t > 0) c_old = d.cst1[ci];
     } else if (stage == 2) {
@@ -247,23 +262,25 @@ __global__ __launch_bounds__(512) void glstm_wave_kernel(const pdse_glstm_desc d
   }
   LSTAMP(3);
 #pragma unroll
-  for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * h][col] = acc[r];
-  if (stage == 0 && threadIdx.x < 256) {
-    const int lq = threadIdx.x >> 6, lb = (threadIdx.x >> 1) & 31, lu = (threadIdx.x & 1) * 4;
+  for (int n = 0; n < NS; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][32 * n + (r & 3) + 8 * (r >> 2) + 4 * h][col] = acc[n][r];
+  if (stage == 0 && threadIdx.x < NFIN) {
+    const int lq = threadIdx.x / (64 * NS), lb = (threadIdx.x / (2 * NS)) & 31, lu = (threadIdx.x & (2 * NS - 1)) * 4;
     *reinterpret_cast<float4*>(&gxs[lq][lb][lu]) = gx4;
   }
   __syncthreads();
-  if (stage == 0 && threadIdx.x < 256) {
+  if (stage == 0 && threadIdx.x < NFIN) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) pre[q] = gxs[q][bb][u];
+    for (int q = 0; q < 4; ++q) pre[q] = gxs[q][bb][uu];
   }
   LSTAMP(4);
-  const bool fin = threadIdx.x < 256;               // (unit, item) threads; every wave still reaches the barrier below
+  const bool fin = threadIdx.x < NFIN;              // (unit, item) threads; every wave still reaches the barrier below
   float gate[4] = {0.f, 0.f, 0.f, 0.f};
   if (fin) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int i = q * 8 + u;
+      const int i = 32 * sl + q * 8 + u;
       float sum = 0.f;
 #pragma unroll
       for (int w = 0; w < 8; ++w) sum += red[w][i][bb];
@@ -299,7 +316,7 @@ __global__ __launch_bounds__(512) void glstm_wave_kernel(const pdse_glstm_desc d
     if (stage == 0) {
       d.cst1[ci] = c;
       d.hT1[((size_t)(par ^ 1) * G + g) * hsz + hidx(hu, b, Bp)] = hv;
-      stat[u][bb][0] = hv;                          // stat[] is unused in stages 0 / 2: staging for the partial sums
+      stat[uu][bb][0] = hv;                         // stat[] is unused in stages 0 / 2: staging for the partial sums
     } else {
       d.cst2[ci] = c;
       d.hT2[((size_t)(par ^ 1) * G + g) * hsz + hidx(hu, b, Bp)] = hv;
@@ -309,19 +326,21 @@ __global__ __launch_bounds__(512) void glstm_wave_kernel(const pdse_glstm_desc d
   LSTAMP(5);
   if (stage != 0) return;
   __syncthreads();
-  // LayerNorm partial sums over this workgroup's 8 units (the same summation order at every batch size)
-  if (threadIdx.x < 32) {
+  // LayerNorm partial sums over the 8 units of each slice (the same summation order at every batch size and for every NS)
+  if (threadIdx.x < 32 * NS) {
+    const int ps = threadIdx.x >> 5;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const float v = stat[k][bb][0];
+      const float v = stat[8 * ps + k][bb][0];
       s1 += v;
       s2 += v * v;
     }
-    float2* P2 = reinterpret_cast<float2*>(d.part) + (((size_t)par * G + g) * (H / 8) + slice) * Bp + b;
+    float2* P2 = reinterpret_cast<float2*>(d.part) + (((size_t)par * G + g) * (H / 8) + slice + ps) * Bp + b;
     *P2 = make_float2(s1, s2);
   }
 }
+
 
 int pdse_glstm_launch(const pdse_glstm_desc* d, hipStream_t s) {
   if (!d || !d->gx1 || !d->whh1 || !d->wih2 || !d->r2 || !d->c2 || !d->whh2 || !d->hT1 || !d->cst1 || !d->hT2 ||
@@ -333,7 +352,15 @@ int pdse_glstm_launch(const pdse_glstm_desc* d, hipStream_t s) {
     pdse_set_error("glstm: bad sizes (H == 512, G == 2 as in gcrn.py:9-16, Bp % 32 == 0, Bp >= B)");
     return 1;
   }
-  const dim3 grid(d->H / 8, d->G, 3 * (d->Bp / 32)), block(512);
+  if (d->slices < 0 || d->slices > 2) {
+    pdse_set_error("glstm: slices is 0 / 1 (one slice of 8 units per workgroup) or 2");
+    return 1;
+  }
+  const int NS = d->slices == 2 ? 2 : 1;
+  const dim3 grid(d->H / 8 / NS, d->G, 3 * (d->Bp / 32)), block(512);
+  const size_t lds = (size_t)(8 * 32 * NS * 33 + 16 * 32 * 2 + 4 * 32 * 8 * NS) * sizeof(float);
+  static unsigned long long attr_mask = 0;
+  if (NS == 2 && pdse_lds_attr((const void*)glstm_wave_kernel<2>, &attr_mask, "glstm lds attribute")) return 1;
   // PDSE_GLSTM_MASK (diagnostic, tools/time_glstm.py): run only some stages to time them apart - results are then wrong
   static const int mask = PDSE_DIAG_ENV("PDSE_GLSTM_MASK") ? atoi(PDSE_DIAG_ENV("PDSE_GLSTM_MASK")) : 7;
   static const bool tracing = PDSE_DIAG_ENV("PDSE_GLSTM_TRACE") != nullptr;
@@ -346,7 +373,10 @@ int pdse_glstm_launch(const pdse_glstm_desc* d, hipStream_t s) {
     }
     (void)hipMemsetAsync(tbuf, 0, nw * 64, s);
   }
-  for (int st = 0; st < d->T + 2; ++st) hipLaunchKernelGGL(glstm_wave_kernel, grid, block, 0, s, *d, st, mask);
+  for (int st = 0; st < d->T + 2; ++st) {
+    if (NS == 2) hipLaunchKernelGGL(glstm_wave_kernel<2>, grid, block, lds, s, *d, st, mask);
+    else hipLaunchKernelGGL(glstm_wave_kernel<1>, grid, block, lds, s, *d, st, mask);
+  }
   if (tracing) {   // diagnostic: stamps of wavefront step T/2 - start spread (100 MHz clock) and shader clocks since the wave started
     (void)hipStreamSynchronize(s);
     long long* h = (long long*)malloc(nw * 64);

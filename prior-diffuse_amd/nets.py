@@ -1195,6 +1195,7 @@ class GcrnPlan(PlanBase):
                 raise ValueError("planes is 3 (bf16x3), 2 (f16x2) or 1 (bf16 mode); the one- and two-plane forms run on the GEMM kernels (split_bf16)")
             self.gemm_planes = int(planes)
         self.persist = bool(self.persist_lstm and self.fused_glstm and exclusive and B <= self.PERSIST_MAX_B and not self.force_generic)
+        self.exclusive = bool(exclusive)
         super().__init__(ctx, plan, ns=(ctx.bank.token(sd), self.fused_last, self.fused_glstm, self.split_bf16, self.block8, self.persist,
                                         self.gemm_planes))
         self.sd, self.B, self.T = sd, B, T
@@ -1302,6 +1303,7 @@ class GcrnPlan(PlanBase):
         d.hT1, d.cst1, d.hT2, d.cst2 = self.hT.data_ptr(), self.cst.data_ptr(), self.hT2.data_ptr(), self.cst2.data_ptr()
         d.y, d.y_sb, d.y_st, d.y_su, d.y_sg = self.y.data_ptr(), T * 1024, 1024, 1, 512     # cat: index g*512 + u
         d.B, d.Bp, d.T, d.H, d.G, d.eps = B, Bp, T, 512, 2, 1e-5
+        d.slices = 2 if self.exclusive else 1     # a plan that owns the GPU: two slices per workgroup share one fetch of the state (bit-identical)
         self.add(d, TAG_LSTM)
 
     def _glstm_persistent(self, proj1):

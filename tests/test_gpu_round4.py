@@ -368,3 +368,28 @@ def test_dense_layers_and_relayout_vs_fp64(L, B, T, F_, npl):
     d.g_out, d.dil = 0, 16
     with pytest.raises(L.PdseError, match="dilation"):
         L.launch(d, st)
+
+
+@pytest.mark.parametrize("B,T", [(32, 60), (5, 33), (16, 401)])
+def test_glstm_two_slices_per_workgroup_is_bit_identical(L, weights, B, T):
+    """pdse_glstm_f32 with two slices of 8 hidden units per workgroup (pdse_glstm_desc.slices = 2: one fetch of the group's state for
+    both - what a plan that owns the GPU takes since round 4) against one slice per workgroup: every summation keeps its order, so the
+    whole GCRN prior is bit-identical - at the bench's batch, at a padded batch and over 401 frames."""
+    nets = pkg("nets")
+    x = seeded((B, 2, T, 161), 91).to(DEV)
+    outs = []
+    for exclusive in (False, True):
+        net = nets.GcrnPlan(nets.Ctx(DEV), weights("GCRN"), B, T, exclusive=exclusive)
+        net.build()
+        net.finish()
+        gl = [d for d, _ in net.descs if isinstance(d, L.GlstmDesc)]
+        assert not net.persist and len(gl) == 1 and gl[0].slices == (2 if exclusive else 1)
+        net.x.copy_(x)
+        net.plan.run()
+        torch.cuda.synchronize()
+        outs.append((net.out.clone(), net.glstm_out().clone()))
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][0], outs[1][0])
+    d = L.GlstmDesc.from_buffer_copy(gl[0])
+    d.slices = 3
+    with pytest.raises(L.PdseError, match="slices"):
+        L.launch(d, torch.cuda.current_stream().cuda_stream)
