@@ -736,7 +736,11 @@ typedef struct pdse_bglu_desc {
   int32_t qexp[4];
 } pdse_bglu_desc;
 
-/* fp32 [B, 32, T, F] -> hp planes (the standalone conv1 of the first decoder stage) */
+/* fp32 [B, 32, T, F] -> hp planes (the standalone conv1 of the first decoder stage).
+ * ABI 8, w[0] != NULL: the 32 channels are COMPUTED here - the 1x1 convolution over `in` (cin0 channels) and `in1` (cin1 channels, the
+ * same strides; cin0 + cin1 <= 128) with per-item biases, y[c] = bias[b][c] + sum_k w[k][c] x[k] as one fp32 fmaf chain in k order -
+ * for nd = 1 or 2 weight sets at once (the two decoders' stage-5 conv1 over the same two sources: model/diff3.py:343-345), whose
+ * planes go to hp (set 0) and hp1 (set 1).  Replaces pdse_gconv_f32 + pdse_split_planes of each decoder (4 launches per forward). */
 typedef struct pdse_planes_desc {
   const float* in;
   int64_t in_sb, in_sc, in_st, in_sf;
@@ -744,6 +748,12 @@ typedef struct pdse_planes_desc {
   int64_t hp_sb;
   int32_t hp_Tp, hp_Fp, hp_t0, hp_f0;
   int32_t B, T, F, np;
+  const float* in1;        /* second source or NULL (cin1 == 0) */
+  const float* w[2];       /* [cin0 + cin1][32] fp32, k-major; w[0] == NULL: plain split of `in` */
+  const float* bias[2];    /* [B][bias_sb] (+ 32 floats) or NULL */
+  int64_t bias_sb;
+  uint16_t* hp1;           /* planes of weight set 1 (nd == 2) */
+  int32_t cin0, cin1, nd, pad_;
 } pdse_planes_desc;
 
 enum pdse_op_kind {

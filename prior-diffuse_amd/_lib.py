@@ -209,7 +209,9 @@ class BgluDesc(C.Structure):
 class PlanesDesc(C.Structure):
     _fields_ = [("in_", _fp), ("in_sb", _i64), ("in_sc", _i64), ("in_st", _i64), ("in_sf", _i64),
                 ("hp", _fp), ("hp_sb", _i64), ("hp_Tp", _i32), ("hp_Fp", _i32), ("hp_t0", _i32), ("hp_f0", _i32),
-                ("B", _i32), ("T", _i32), ("F", _i32), ("np", _i32)]
+                ("B", _i32), ("T", _i32), ("F", _i32), ("np", _i32),
+                ("in1", _fp), ("w", _fp * 2), ("bias", _fp * 2), ("bias_sb", _i64), ("hp1", _fp),
+                ("cin0", _i32), ("cin1", _i32), ("nd", _i32), ("pad_", _i32)]
 
 
 class CrmDesc(C.Structure):

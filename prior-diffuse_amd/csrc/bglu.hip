@@ -1274,6 +1274,57 @@ __global__ __launch_bounds__(256) void planes_kernel(const pdse_planes_desc d) {
   for (int pl = 0; pl < NP; ++pl) base[pl * d.hp_Fp] = p[pl];
 }
 
+// The same planes, of a 1x1 convolution computed here (pdse_planes_desc.w; F == 4): a wave owns 8 frames x 4 bins = 32 positions and all
+// 32 output channels on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, one fmaf chain in k order per output - the
+// arithmetic of the gather-GEMM launch this replaces); the accumulator registers of lane half h ARE plane groups h and 2 + h, so the
+// split and the 64-byte-per-frame plane stores are those of the block kernels' tails.  (As a vector kernel - one thread per position,
+// wave-uniform weights from scalar loads or broadcast LDS reads - the launch took 52-55 us: 256 dependent scalar loads, or an LDS
+// array busy with 1024 broadcast reads, per thread.)
+template <int NP>
+__global__ __launch_bounds__(256) void planes_conv_kernel(const pdse_planes_desc d) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, h = lane >> 5;
+  const int di = blockIdx.z, b = blockIdx.y;
+  const int t = (blockIdx.x * 4 + wave) * 8 + (col >> 2), f = col & 3;
+  const bool live = t < d.T;
+  const int64_t xo = (int64_t)b * d.in_sb + (int64_t)(live ? t : d.T - 1) * d.in_st + (int64_t)f * d.in_sf;
+  const float* const w = d.w[di] + col;                 // A operand: lane (row = output channel, k = 2 i + h)
+  f32x16 acc;
+  if (d.bias[di]) {
+    acc = ld16(d.bias[di] + (int64_t)b * d.bias_sb + 4 * h);
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  }
+  const int K = d.cin0 + d.cin1;                        // multiples of 32 per source (validated)
+  float av[2][16], bv[2][16];
+  auto request = [&](const int k0, const int s_) {      // the 32 loads of a chunk of 32 input channels
+    const float* const src = (k0 < d.cin0 ? d.in + (int64_t)k0 * d.in_sc : d.in1 + (int64_t)(k0 - d.cin0) * d.in_sc) + xo;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      av[s_][i] = w[(k0 + 2 * i + h) * 32];
+      bv[s_][i] = src[(int64_t)(2 * i + h) * d.in_sc];
+    }
+  };
+  request(0, 0);
+  for (int k0 = 0; k0 < K; k0 += 64) {                  // two chunks per iteration: the next chunk's loads fly under this chunk's MFMAs
+    if (k0 + 32 < K) request(k0 + 32, 1);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0][i], bv[0][i], acc, 0, 0, 0);
+    if (k0 + 32 >= K) break;
+    if (k0 + 64 < K) request(k0 + 64, 0);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1][i], bv[1][i], acc, 0, 0, 0);
+  }
+  if (!live) return;
+  uint4 p[2][NP];
+  split16p<NP>(acc, p, NP == 2 ? pow2i(PDSE_F16_ACT_EXP) : 1.0f);
+  uint4* const base = reinterpret_cast<uint4*>((di ? d.hp1 : d.hp) + (int64_t)b * d.hp_sb) + ((int64_t)(t + d.hp_t0) * 4 + h) * (NP * d.hp_Fp) + f + d.hp_f0;
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl) base[(2 * q * NP + pl) * d.hp_Fp] = p[q][pl];
+}
+
 template <int NT, int P1MASK, int C2, int NXN, bool IN4, int NP, bool PIPE, bool SPR = false>
 int launch_(const pdse_bglu_desc* d, hipStream_t s) {
   using CF = bglu_cfg<NT, P1MASK, C2, NXN, IN4, NP, PIPE>;
@@ -1491,6 +1542,22 @@ int pdse_planes_launch(const pdse_planes_desc* d, hipStream_t s) {
   if (d->hp_t0 < 0 || d->hp_f0 < 0 || d->hp_t0 + d->T > d->hp_Tp || d->hp_f0 + d->F > d->hp_Fp) {
     pdse_set_error("planes: the tensor does not fit hp");
     return 1;
+  }
+  if (d->w[0]) {   // the planes of a 1x1 convolution computed here
+    if (d->nd < 1 || d->nd > 2 || d->cin0 < 32 || d->cin1 < 0 || (d->cin0 & 31) || (d->cin1 & 31) || d->cin0 + d->cin1 > 128 || (d->cin1 > 0 && !d->in1) || (d->nd == 2 && (!d->w[1] || !d->hp1)) ||
+        d->B > 65535) {
+      pdse_set_error("planes: the convolution form takes 1 or 2 weight sets, up to 128 input channels (multiples of 32) over one or two sources");
+      return 1;
+    }
+    if (d->F != 4 || (reinterpret_cast<uintptr_t>(d->bias[0]) & 15) || (reinterpret_cast<uintptr_t>(d->bias[1]) & 15) || (d->bias_sb & 3)) {
+      pdse_set_error("planes: the convolution form is built for F == 4 (decoder stage 5) and 16-byte aligned bias rows");
+      return 1;
+    }
+    const dim3 cgrid((unsigned)((d->T + 31) / 32), (unsigned)d->B, (unsigned)d->nd), cblock(256);
+    if (d->np == 3) hipLaunchKernelGGL(planes_conv_kernel<3>, cgrid, cblock, 0, s, *d);
+    else if (d->np == 2) hipLaunchKernelGGL(planes_conv_kernel<2>, cgrid, cblock, 0, s, *d);
+    else hipLaunchKernelGGL(planes_conv_kernel<1>, cgrid, cblock, 0, s, *d);
+    return pdse_check_launch("planes (conv)");
   }
   const int64_t n = (int64_t)d->B * d->T * d->F * 4;
   const dim3 grid((unsigned)((n + 255) / 256)), block(256);

@@ -442,7 +442,7 @@ class EpsNetPlan(PlanBase):
             # (B + 1 items: item B takes the stores of lanes beyond the last position)
             self.hp_en = {k: ctx.alloc_u16(*P.hp_shape(B + 1, T, self.ENC_F[k - 1], self.planes)) for k in range(2, 6)}
             self.hp_de = {k: ctx.alloc_u16(*P.hp_shape(B + 1, T, self.ENC_F[k], self.planes)) for k in range(1, 6)}
-            self.H5 = a(B, 32, T, 4)                 # first decoder stage: conv1 output in fp32 before it is split
+            self.hp_de5b = ctx.alloc_u16(*P.hp_shape(B + 1, T, self.ENC_F[5], self.planes))   # stage 5 of the second decoder (both conv1 are computed by one launch)
         if time_cond:
             self.tsteps = a(nsteps, B, zero=True)
             self.tbias = a(nsteps, B, self.NSLOT * 32)
@@ -962,20 +962,21 @@ class EpsNetPlan(PlanBase):
         """Both decoders on plane tensors.  Stage 5's conv1 (over the TCM output and the encoder's stage-5 output) is its
         own fp32 launch followed by the split into planes; every later conv1 rides on the previous stage's tail."""
         B, T, npl = self.B, self.T, self.planes
+        # stage 5's conv1 of BOTH decoders over (TCM output, encoder stage-5 output) and its split into planes: one launch
+        # (pdse_planes_desc.w; until round 4: a gather-GEMM launch and a split launch per decoder)
+        pd = L.PlanesDesc()
+        pd.in_, pd.in1 = tcm_out.data_ptr(), self.en[4].data_ptr()          # [B,64,4,T] read as [B,64,T,4]
+        pd.in_sb, pd.in_sc, pd.in_st, pd.in_sf = 256 * T, 4 * T, 1, T
+        shp = P.hp_shape(B + 1, T, 4, npl)
+        pd.hp, pd.hp1 = self.hp_de[5].data_ptr(), self.hp_de5b.data_ptr()
+        pd.hp_sb, pd.hp_Tp, pd.hp_Fp, pd.hp_t0, pd.hp_f0 = int(np.prod(shp[1:])), shp[1], shp[4], P.HP_T0, P.HP_F0
+        pd.B, pd.T, pd.F, pd.np, pd.cin0, pd.cin1, pd.nd = B, T, 4, npl, 64, 64, 2
         for di, de in enumerate(("de_real", "de_imag")):
-            in0 = self.src(tcm_out, 64, 256 * T, 4 * T, 1, T)               # [B,64,4,T] viewed as [B,64,T,4]
-            in1 = self.src(self.en[4], 64, 256 * T, 4 * T, 1, T)
-            p5 = "%s.de5.0" % de
             tb, off, sbb = self._bias_for(step, 5 + 5 * di)
-            self.gconv(in0=in0, in1=in1, Tin=T, Fin=4, taps=[(0, 0)], sf_in=1, W=lambda p5=p5: dict(wk0=self.w(p5 + ".conv1.weight")[:, :, 0, 0]),
-                       Cout=32, bias0=tb, bias0_off=off, bias0_sb=sbb, out=self.H5, out_strides=nchw_out(32, T, 4), B=B, Tout=T,
-                       Fout=4, tag=TAG_EPS_CONV1, label=p5 + ".conv1")
-            pd = L.PlanesDesc()
-            pd.in_, (pd.in_sb, pd.in_sc, pd.in_st, pd.in_sf) = self.H5.data_ptr(), nchw(32, T, 4)
-            shp = P.hp_shape(B + 1, T, 4, npl)
-            pd.hp, pd.hp_sb, pd.hp_Tp, pd.hp_Fp, pd.hp_t0, pd.hp_f0 = self.hp_de[5].data_ptr(), int(np.prod(shp[1:])), shp[1], shp[4], P.HP_T0, P.HP_F0
-            pd.B, pd.T, pd.F, pd.np = B, T, 4, npl
-            self.add(pd, TAG_EPS_CONV1)
+            pd.w[di] = self.upw("%s.de5.0.conv1.kmajor" % de, lambda de=de: self.w("%s.de5.0.conv1.weight" % de)[:, :, 0, 0]).data_ptr()   # ConvTranspose: [in, out]
+            pd.bias[di], pd.bias_sb = Ctx.ptr(tb, off), sbb
+        self.add(pd, TAG_EPS_CONV1)
+        for di, de in enumerate(("de_real", "de_imag")):
             for n, k in enumerate((5, 4, 3, 2, 1)):
                 p = "%s.de%d.0" % (de, k)
                 Fin = self.ENC_F[k]
@@ -995,7 +996,7 @@ class EpsNetPlan(PlanBase):
                     f["bias0"], f["bias1"] = self.ctx.up(self.w(p + ".l.bias")).data_ptr(), self.ctx.up(self.w(p + ".r.bias")).data_ptr()
                     return f
 
-                kwargs = dict(hp=self.hp_de[k], F_in=Fin, taps=taps0, sf_in=1, Fout=(Fo + 1) // 2, p1mask=mask, Fout1=Fo // 2,
+                kwargs = dict(hp=self.hp_de5b if (k == 5 and di == 1) else self.hp_de[k], F_in=Fin, taps=taps0, sf_in=1, Fout=(Fo + 1) // 2, p1mask=mask, Fout1=Fo // 2,
                               slope=self._slope("%s.de%d.3.weight" % (de, k)) if k > 1 else 1.0, C2=C2,
                               bias=(None, 0, 0, None, None, 0))
                 if k > 1:
@@ -1032,6 +1033,11 @@ class EpsNetPlan(PlanBase):
                         v = d2.nx_bias[i]
                         if v and lo <= v < hi:
                             d2.nx_bias[i] = v + delta
+                elif isinstance(d2, L.PlanesDesc):
+                    for i in range(2):
+                        v = d2.bias[i]
+                        if v and lo <= v < hi:
+                            d2.bias[i] = v + delta
                 elif isinstance(d2, L.BgluDesc):
                     for f in ("bias0", "bias1", "bias0_t0", "bias1_t0"):
                         v = getattr(d2, f)

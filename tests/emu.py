@@ -586,14 +586,33 @@ def _bf16_round(v):
 
 
 def run_planes(d, mem):
-    """pdse_planes_desc: fp32 [B, 32, T, F] -> hp planes."""
-    flat, off = mem.view(d.in_)
-    b, c, t, f = np.meshgrid(np.arange(d.B), np.arange(32), np.arange(d.T), np.arange(d.F), indexing="ij")
-    x = flat[off + b * d.in_sb + c * d.in_sc + t * d.in_st + f * d.in_sf]
-    hpf, hoff = mem.view(d.hp, np.int16)
-    hp = hpf.view(np.uint16)[hoff:hoff + d.B * d.hp_sb].reshape(d.B, d.hp_Tp, 4, d.np, d.hp_Fp, 8)
+    """pdse_planes_desc: fp32 [B, 32, T, F] -> hp planes; with w: the planes of the 1x1 convolution over one or two sources, for
+    one or two weight sets (the two decoders' stage-5 conv1)."""
     assert d.hp_t0 == P.HP_T0 and d.hp_f0 == P.HP_F0 and d.hp_Tp == d.T + P.HP_T0 and d.hp_Fp == d.F + 2 * P.HP_F0
-    hp[...] = P.hp_split(x, d.np)
+
+    def gather(ptr, C):
+        flat, off = mem.view(ptr)
+        b, c, t, f = np.meshgrid(np.arange(d.B), np.arange(C), np.arange(d.T), np.arange(d.F), indexing="ij")
+        return flat[off + b * d.in_sb + c * d.in_sc + t * d.in_st + f * d.in_sf]
+
+    def put(ptr, x):
+        hpf, hoff = mem.view(ptr, np.int16)
+        hp = hpf.view(np.uint16)[hoff:hoff + d.B * d.hp_sb].reshape(d.B, d.hp_Tp, 4, d.np, d.hp_Fp, 8)
+        hp[...] = P.hp_split(x.astype(np.float32), d.np)
+
+    if not d.w[0]:
+        put(d.hp, gather(d.in_, 32))
+        return
+    x = gather(d.in_, d.cin0).astype(np.float64)
+    if d.cin1:
+        x = np.concatenate([x, gather(d.in1, d.cin1).astype(np.float64)], 1)
+    for i in range(d.nd):
+        w = mem.arr(d.w[i], (d.cin0 + d.cin1) * 32).reshape(-1, 32).astype(np.float64)             # [k][c]
+        y = np.einsum("kc,bktf->bctf", w, x)
+        if d.bias[i]:
+            flat, off = mem.view(d.bias[i])
+            y = y + flat[off + np.arange(d.B)[:, None] * d.bias_sb + np.arange(32)[None, :]][:, :, None, None]
+        put(d.hp1 if i else d.hp, y)
 
 
 def run_bglu(d, mem):

@@ -48,7 +48,8 @@ def test_eps_net_plan_vs_oracle(weights, chained, split, plane_h, parity, monkey
     net.build_step(0)
     n_conv1 = sum(1 for _, tag in net.descs if tag == nets.TAG_EPS_CONV1)
     n_planes = {False: 0, True: 15}[plane_h]   # stages on plane tensors: the encoder / every stage
-    assert n_conv1 == (2 if chained else 16) + (2 if plane_h is True else 0)   # chained: only decoder stage 5 x 2 (+ its split into planes)
+    # chained: only decoder stage 5 x 2; on plane tensors those two conv1 and their split into planes are ONE launch (pdse_planes_desc.w)
+    assert n_conv1 == (1 if plane_h is True else (2 if chained else 16))
     n_split = sum(1 for d, _ in net.descs if isinstance(d, pkg("_lib").GconvDesc) and d.korder == 2)
     assert n_split == (15 - n_planes if split else 0)     # encoder stages 1-5 + 2 x 5 decoder stages
     assert sum(1 for d, _ in net.descs if isinstance(d, pkg("_lib").BgluDesc)) == n_planes
@@ -163,8 +164,11 @@ def test_step_descriptors_are_cloned_not_repacked(weights):
         if isinstance(a, (L.TcmDesc, L.Tcm2Desc, L.Tcm2sDesc)):         # fused TCM blocks carry no time bias: identical clones
             assert bytes(a) == bytes(b)
             continue
-        if isinstance(a, L.PlanesDesc):                      # fp32 -> planes of the first decoder stage's conv1: no bias
-            assert bytes(a) == bytes(b)
+        if isinstance(a, L.PlanesDesc):                      # the decoders' stage-5 conv1 computed into planes: two time biases move
+            assert a.w[0] == b.w[0] and a.w[1] == b.w[1] and a.hp == b.hp and a.hp1 == b.hp1
+            for i in range(2):
+                assert b.bias[i] - a.bias[i] == delta
+                moved += 1
             continue
         assert a.w0 == b.w0 and a.out == b.out
         for f in ("bias0", "bias1", "bias0_t0", "bias1_t0"):
