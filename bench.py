@@ -465,7 +465,7 @@ def main():
                              "enhance + wav write per file, plan and weights resident, hipGraph replay once a length comes back; the trainer owns "
                              "the GPU (exclusive): the prior's LSTM is one persistent launch (csrc/lstmp.hip), the TCM stack one launch per forward"}
     cpu = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:      # the CPU leg belongs to the N = 1 line only (rank 0 of a larger job skips it)
         from oracle import restate as R
 
         t_cpu0 = time.perf_counter()
