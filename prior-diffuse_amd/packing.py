@@ -508,7 +508,7 @@ F16_MAX = 65504.0
 
 def f16_wexp(*mats):
     """Power-of-two exponent q for a group of weight matrices that share one accumulator: max |w| * 2^q in [2^13, 2^14), so
-    every weight down to 2^-16 of the largest keeps a normal lo part (the kernel undoes 2^q where it re-scales the
+    every weight down to 2^-15 of the largest keeps a normal lo part (the kernel undoes 2^q where it re-scales the
     accumulator; exact)."""
     m = max((float(np.max(np.abs(np.asarray(w, np.float64)))) if np.asarray(w).size else 0.0) for w in mats)
     if not np.isfinite(m) or m <= 0.0:

@@ -170,3 +170,25 @@ def test_split_tcm_operands_round_trip():
     hs[0, 0, 0, 0, 0, 3, 0] = 1                                               # a write into the margin is caught
     with pytest.raises(AssertionError):
         P.tcm2_join_h(hs, 3, 9)
+
+
+def test_f16x2_split_and_weight_exponent_edge_cases():
+    """packing.split_f16x2 / f16_wexp (the host side of the f16x2 operand form, include/pdse.h PDSE_F16_ACT_EXP): zeros, values whose
+    lo part is subnormal or zero, the largest finite fp16, an overflow (infinities, never a clipped value), all-zero and tiny weight
+    groups, and the exponent that puts the largest weight in [2^13, 2^14)."""
+    P = pkg("packing")
+    x = np.array([0.0, -0.0, 1.0, 1.0 + 2.0 ** -11, 3.0e-5, 6.0e-8, 65504.0, -65504.0, 65519.9, 70000.0, -1.0e9], np.float32)
+    hi, lo = P.split_f16x2(x)
+    h, l = P.f16_to_f32(hi), P.f16_to_f32(lo)
+    fin = np.abs(x) < 65520.0                                       # RN16 keeps values below 65520 finite
+    assert np.array_equal(np.isfinite(h), fin) and np.all(np.isinf(h[~fin]) & np.isinf(l[~fin]) & (np.sign(h[~fin]) == -np.sign(l[~fin])))
+    assert np.array_equal((h + l)[:3], x[:3]) and (h + l)[3] == x[3]                 # 1 + 2^-11: hi = 1, lo = 2^-11 exactly
+    assert np.all(np.abs((h + l)[fin] - x[fin]) <= np.maximum(2.0 ** -23 * np.abs(x[fin]), 2.0 ** -25))
+    for w, q in ((np.zeros((4, 4)), 0), (np.full((2, 2), 0.3), 15), (np.array([[1e-12, -3e-12]]), 40), (np.array([[3.0e5]]), -5)):
+        assert P.f16_wexp(w) == q, (w.ravel()[:2], P.f16_wexp(w))
+    w = np.array([[0.3, -0.01, 2.0e-6]])
+    q = P.f16_wexp(w)
+    assert 2.0 ** 13 <= 0.3 * 2.0 ** q < 2.0 ** 14
+    back = P.from_planes(P.to_planes(w.astype(np.float32), 2, q), q)
+    err = np.abs(back - w.astype(np.float32)) / np.abs(w)
+    assert err[0, :2].max() <= 2.0 ** -23 and err[0, 2] <= 2.0 ** -21      # down to 2^-15 of the largest: half an fp32 ulp; 2e-6 (2^-17 of it): 21 bits
